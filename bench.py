@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- novel-pose rendering throughput of the InstantAvatar hot path on MI355X.
+
+A "step" is one frame of DNeRFModel.render_image_fast (models/DNeRF.py:72-97) at
+512x512: SMPL joint chain -> skinning-voxel precompute -> per-frame occupancy
+build (5 x 64^3 probes through the deformer + field) -> occupancy-grid ray march
+with Fast-SNARF root finding, hash-grid + MLP field and alpha compositing.
+Inputs (camera rays, SMPL poses, weights) are resident in HBM before the timed
+region.  Synthetic SMPL-like body, procedural pose track, synthetic field
+(see instantavatar_amd/synthetic.py): no dataset / checkpoint exists offline.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded
+   across ranks, no data-path collective -> weak scaling)
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
+    """The CPU restatement (oracle/) timed on this box's host cores on a bounded
+    sample: `n_frames` full frames of the same workload (kind = "port")."""
+    from oracle import oracle as orc
+    from instantavatar_amd import synthetic as syn
+    fd = model.deformer.deformer
+    init = dict(tfs_inv_t=model.deformer.tfs_inv_t[0].cpu().numpy(),
+                lbs_voxel=np.ascontiguousarray(fd.lbs_voxel_final[0].cpu().numpy()),
+                offset_kernel=fd.offset_kernel.reshape(3).cpu().numpy().astype(np.float32),
+                scale_kernel=fd.scale_kernel.reshape(3).cpu().numpy().astype(np.float32),
+                bbox=model.deformer.bbox.cpu().numpy(), D=fd.resolution // 4, H=fd.resolution, W=fd.resolution)
+    ro, rd = syn.make_camera_rays(res)
+    rng = np.random.RandomState(0)
+    orc.lib()
+    t0 = time.time()
+    for i in range(n_frames):
+        world = orc.make_world(body, init, fp, np.zeros(10, np.float32), poses[i, 3:], poses[i, :3], tr[i], syn.INIT_BONES)
+        jit = rng.rand(5, 64 ** 3, 3).astype(np.float32)
+        orc.render_image_fast(world, ro, rd, jit)
+    dt = time.time() - t0
+    cores = os.cpu_count() or 1
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d full %dx%d frames (occupancy build + render) through oracle/ (C + OpenMP, fp32)" % (n_frames, res, res),
+            "seconds": dt}
+
+
+def main():
+    args = parse()
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from instantavatar_amd import _lib, synthetic as syn
+    from instantavatar_amd.pipeline import build_synthetic_model, make_batch
+
+    torch.manual_seed(42 + rank)
+    model, body, fp = build_synthetic_model(dev, resolution=128, n_levels=16)
+    res = args.res
+    n_total = args.steps + args.warmup
+    poses, tr = syn.procedural_pose_track(max(200, n_total * world_size))
+    # frames are sharded round-robin over ranks (config 3: embarrassingly parallel)
+    my = [rank + i * world_size for i in range(n_total)]
+    batches = [make_batch(dev, res, poses[f % len(poses)], tr[f % len(poses)]) for f in my[:8]]
+    # share the (identical) camera rays between batches: one resident copy
+    for b in batches[1:]:
+        b["rays_o"], b["rays_d"] = batches[0]["rays_o"], batches[0]["rays_d"]
+    pose_t = torch.as_tensor(poses, device=dev)
+    tr_t = torch.as_tensor(tr, device=dev)
+
+    def frame(i):
+        f = my[i] % len(poses)
+        b = batches[i % len(batches)]
+        b["global_orient"], b["body_pose"], b["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
+        d = float(np.sqrt((tr[f] ** 2).sum()))
+        b["near"].fill_(d - 1)
+        b["far"].fill_(d + 1)
+        return model.render_image_fast(b, (res, res))
+
+    L = _lib.lib()
+    for i in range(args.warmup):
+        out = frame(i)
+    torch.cuda.synchronize()
+    prof = not args.no_profile
+    if prof:
+        _lib.check(L.ia_profile_enable(1))
+        _lib.check(L.ia_profile_reset())
+    if world_size > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cnt_sum = torch.zeros((), device=dev)
+    cov_sum = torch.zeros((), device=dev)
+    for i in range(args.warmup, n_total):
+        rgb, depth, alpha, counter = frame(i)
+        cnt_sum += counter.mean()
+        cov_sum += (alpha > 0.5).float().mean()
+    torch.cuda.synchronize()
+    if world_size > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    kernels = {}
+    if prof:
+        for kid, name in ((0, "k_search"), (1, "k_field")):
+            ms, n, units = C.c_double(), C.c_int64(), (C.c_uint64 * 2)()
+            _lib.check(L.ia_profile_get(kid, C.byref(ms), C.byref(n), units))
+            kernels[name] = dict(ms=ms.value, launches=n.value, units=[int(units[0]), int(units[1])])
+        _lib.check(L.ia_profile_enable(0))
+        ks, kf = kernels["k_search"], kernels["k_field"]
+        # algorithmic bytes: field = 512 B gathered (16 lv x 8 corners x 2 x fp16)
+        # + 12 B in + 16 B out per sample; search = 384 B per trilinear fetch (8 corners x 12 ch
+        # x 4 B) + 12 B in per point + 12 B out per surviving root (bounded by solves).
+        kf["bytes"] = kf["units"][0] * (512 + 12 + 16)
+        ks["bytes"] = ks["units"][1] * 384 + ks["units"][0] // 13 * 12
+        dom = "k_field" if kf["ms"] >= ks["ms"] else "k_search"
+        k = kernels[dom]
+        per_launch_ms = k["ms"] / max(k["launches"], 1)
+        achieved = k["bytes"] / max(k["launches"], 1) / (per_launch_ms * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": per_launch_ms * 1e3, "launches": k["launches"],
+                "algorithmic_bytes_per_launch": k["bytes"] / max(k["launches"], 1),
+                "other": {n: {"avg_launch_us": v["ms"] * 1e3 / max(v["launches"], 1), "launches": v["launches"],
+                              "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0),
+                              "units": v["units"]} for n, v in kernels.items()}}
+
+    frames = args.steps * world_size
+    fps = frames / dt
+    result = {
+        "metric": "novel_pose_render_frames_per_sec_512x512", "value": fps, "unit": "frames/s",
+        "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "render_image_fast %dx%d, SNARF_NGP defaults (13 init bones, 128^2x32 skinning voxels, "
+                               "16-level hash grid T=2^19, 64^3 occupancy rebuilt per frame with 5 probes, "
+                               "MAX_SAMPLES 256, MAX_BATCH 291600), synthetic SMPL-like body + procedural poses" % (res, res),
+                   "frames_sharded_over": world_size},
+        "rays_per_sec": fps * res * res,
+        "samples_per_ray": float(cnt_sum.item()) / args.steps,
+        "alpha_coverage": float(cov_sum.item()) / args.steps,
+        "render_loop_iters": model.renderer.last_iters,
+    }
+    if roof is not None:
+        result["roofline"] = roof
+    if rank == 0 and world_size == 1 and args.cpu_frames > 0:
+        result["cpu_baseline"] = cpu_baseline(body, fp, model, poses, tr, res, args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(result))
+    if world_size > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,281 @@
+/*
+ * instantavatar_hip.h -- C ABI of libinstantavatar_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the volumetric-rendering hot path of InstantAvatar.
+ * Every entry point replaces one pybind11/ATen op (or one torch-level fused
+ * sequence) of the reference; the reference interface is cited per function
+ * (paths relative to the reference tree).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller unless marked HOST.
+ *  - `stream` is a hipStream_t passed as void*.  No call synchronises the
+ *    device, none touches the default stream, none allocates device memory:
+ *    scratch comes from the caller through `ws`/`ws_bytes` (query the size
+ *    with the matching *_workspace_bytes function).
+ *  - Return value: 0 = IA_OK, negative = error (ia_last_error() gives text).
+ *  - All float data is fp32 unless a parameter says fp16 (IEEE binary16,
+ *    passed as uint16_t*).
+ *  - Batch is 1 frame (the reference kernels are only correct for B = 1:
+ *    fast_snarf/cuda/filter/filter.cu:21-22, precompute.cu:56).
+ */
+#ifndef INSTANTAVATAR_HIP_H
+#define INSTANTAVATAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IA_OK 0
+#define IA_ERR_ARG (-1)
+#define IA_ERR_LAUNCH (-2)
+#define IA_ERR_WORKSPACE (-3)
+
+#define IA_N_JOINTS 24      /* SMPL joints                                   */
+#define IA_N_INIT_MAX 16    /* >= 13 init bones (deformer_torch.py:28)        */
+#define IA_MAX_LEVELS 16    /* hash-grid levels (ngp.py:30-37)                */
+
+/* ---- descriptors (HOST structs, passed by pointer, copied at call time) -- */
+
+/* Fast-SNARF skinning voxel grid: deformer_torch.py:130-169
+ * (offset_kernel = -centre, scale_kernel = 1/scale with z * ratio).          */
+typedef struct ia_snarf_grid {
+  int D, H, W;          /* 32,128,128 for resolution 128                      */
+  float offset[3];      /* offset_kernel                                      */
+  float scale[3];       /* scale_kernel                                       */
+} ia_snarf_grid;
+
+/* tcnn-v1.6 HashGrid level table (restated; see oracle/ia_oracle.c header).  */
+typedef struct ia_hash_desc {
+  int n_levels;                       /* 16                                   */
+  float scale[IA_MAX_LEVELS];         /* exp2f(l*log2f(pls))*base - 1         */
+  uint32_t res[IA_MAX_LEVELS];        /* ceilf(scale)+1                       */
+  uint32_t offset[IA_MAX_LEVELS + 1]; /* entry offsets (x2 features each)     */
+} ia_hash_desc;
+
+/* NeRFNGPNet (models/networks/ngp.py:23-83): normalisation + weights.
+ * table: fp16 [n_entries][2].  MLP weights fp16 row-major [out][in]:
+ * sig_w1[64][32], sig_w2[16][64]; col_w1[64][16], col_w2[64][64],
+ * col_w3[16][64] (tcnn FullyFusedMLP layout, no biases).                     */
+typedef struct ia_field {
+  float center[3];
+  float scale[3];
+  ia_hash_desc hash;
+  const uint16_t *table;
+  const uint16_t *sig_w1, *sig_w2;
+  const uint16_t *col_w1, *col_w2, *col_w3;
+} ia_field;
+
+/* Occupancy grid (models/structures/density_grid.py): G^3 cells over aabb.   */
+typedef struct ia_occ_grid {
+  int G;                 /* 64                                                */
+  float aabb_min[3];
+  float aabb_max[3];
+} ia_occ_grid;
+
+/* ---- library ------------------------------------------------------------- */
+int ia_version(void);
+const char *ia_last_error(void);
+
+/* Level table as tcnn computes it on the host (grid.h: grid_scale /
+ * grid_resolution / offset table; call site ngp.py:30-37).                   */
+int ia_hash_desc_init(ia_hash_desc *out, int n_levels, int log2_hashmap_size,
+                      int base_resolution, float per_level_scale);
+
+/* ---- a1/a2: SMPL pose -> bone transforms --------------------------------
+ * Replaces smplx lbs() joint chain (deformers/smplx/lbs.py:152-250,295-401),
+ * transl folding (body_models.py:353-360) and SNARFDeformer.prepare_deformer
+ * (snarf_deformer.py:71-93): tfs = inv(A[0]) . A . inv(A_rest).
+ * joints_rest: [24,3] shaped rest joints (J_regressor . v_shaped), parents:
+ * [24] int32, pose: [72] axis-angle, transl: [3], tfs_inv_t: [24,4,4]
+ * = inv(A) of the canonical pose.  Outputs: tfs [24,4,4], w2s [4,4], A[24,4,4]
+ * (A may be NULL).                                                           */
+int ia_smpl_tfs(const float *joints_rest, const int32_t *parents,
+                const float *pose, const float *transl, const float *tfs_inv_t,
+                float *tfs, float *w2s, float *A, void *stream);
+
+/* ---- a3: precompute -------------------------------------------------------
+ * Replaces precompute(voxel_w, tfs, voxel_d, voxel_J, offset, scale)
+ * (fast_snarf/cuda/precompute/precompute.cpp:7-13, precompute.cu:24-71).
+ * voxel_w: [24,D,H,W].  voxel_J: OUT, channel-LAST [D,H,W,12] (native layout:
+ * one trilinear corner = 48 contiguous bytes).  voxel_d: OUT [3,D,H,W] or
+ * NULL.  bbox: OUT [6] = min xyz, max xyz of voxel_d (what
+ * SNARFDeformer.get_bbox_deformed, snarf_deformer.py:105-107, reduces) or
+ * NULL.  No device synchronise (the reference's cudaDeviceSynchronize at
+ * precompute.cu:102 is dropped).                                             */
+int ia_precompute(const float *voxel_w, const float *tfs, float *voxel_J,
+                  float *voxel_d, float *bbox, const ia_snarf_grid *grid,
+                  void *stream);
+
+/* ---- a4 + a5: Broyden search + duplicate filter ----------------------------
+ * Replaces fuse_broyden(...) + filter(x, mask)
+ * (fast_snarf/cuda/fuse_kernel/fuse_cuda.cpp:14-28,
+ *  fuse_cuda_kernel_fast.cu:252-413, filter/filter.cpp:12-21, filter.cu:10-55)
+ * as called by ForwardDeformer.broyden_cuda (deformer_torch.py:100-116).
+ * xd: [P,3].  bone_ids: HOST int[n_init].  Outputs (fully written, caller need
+ * not zero them): xc [P,n_init,3] (0 where not converged&valid),
+ * valid [P,n_init] uint8 AFTER the duplicate filter, valid_raw [P,n_init] (before
+ * the filter; may be NULL), J_inv [P,n_init,3,3] or NULL.                    */
+int ia_snarf_search(const float *xd, int P, const float *voxel_J,
+                    const float *tfs, const int32_t *bone_ids, int n_init,
+                    const ia_snarf_grid *grid, float cvg_thresh,
+                    float dvg_thresh, float *xc, uint8_t *valid,
+                    uint8_t *valid_raw, float *J_inv, void *stream);
+
+/* Fused form used by the fast path: same search + filter, but the surviving
+ * candidates are compacted on device (wavefront ballot + prefix sum):
+ *   cand_xc   [cap,3]  canonical positions of valid candidates
+ *   pt_off    [P]      first candidate of point p   (int32)
+ *   pt_cnt    [P]      number of valid candidates   (uint8, <= n_init)
+ *   n_cand    [1]      total (int32, device; must be zeroed by the caller or
+ *                      by zero_counter != 0)
+ * n_pts_dev: optional DEVICE int32* holding the live point count (<= P); P is
+ * then only the launch upper bound.  Candidates of one point are contiguous
+ * and ordered by init index (snarf_deformer.py:139 takes the first maximum). */
+int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
+                            const float *voxel_J, const float *tfs,
+                            const int32_t *bone_ids, int n_init,
+                            const ia_snarf_grid *grid, float cvg_thresh,
+                            float dvg_thresh, float *cand_xc, int32_t cand_cap,
+                            int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand,
+                            int zero_counter, void *stream);
+
+/* ---- a9 + a10 + a11: canonical field ---------------------------------------
+ * Replaces NeRFNGPNet.forward (ngp.py:73-83) = tcnn NetworkWithInputEncoding
+ * (HashGrid -> FullyFusedMLP 32-64-16) + tcnn Network (16-64-64-16, sigmoid).
+ * x: [V,3] canonical points (un-normalised).  rgb [V,3], sigma [V] fp32.
+ * n_dev: optional DEVICE int32* live count (V = upper bound).                */
+int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
+                 const ia_field *field, float *rgb, float *sigma,
+                 void *stream);
+/* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */
+int ia_hashgrid_fwd(const float *x, int V, const ia_field *field,
+                    uint16_t *feat, void *stream);
+
+/* ---- a6: candidate reduction ----------------------------------------------
+ * Replaces SNARFDeformer.deform_test tail (snarf_deformer.py:130-141):
+ * nan_to_num, sigma = max over candidates (invalid contribute 0 in test mode,
+ * `fill` = -1e5 in train mode, snarf_deformer.py:147), rgb of the arg-max.   */
+int ia_candidate_max(const float *cand_rgb, const float *cand_sigma,
+                     const int32_t *pt_off, const uint8_t *pt_cnt, int P,
+                     const int32_t *n_pts_dev, int n_init, float fill,
+                     int nan_to_num, float *rgb, float *sigma, void *stream);
+
+/* ---- a13: raymarch_test ----------------------------------------------------
+ * Replaces raymarch_test(rays_o, rays_d, nears, fars, alive, grid, scale,
+ * offset, step, N_steps) (renderers/cuda/raymarcher.cpp:16-36,
+ * raymarcher.cu:13-112).  occ_bits: bit-packed G^3 grid, bit index
+ * (x*G+y)*G+z.  nears is updated in place (raymarcher.cu:72).  Outputs are
+ * fully written (zeros where no sample): pts [n_alive,N_steps,3],
+ * deltas/depths [n_alive,N_steps].                                           */
+int ia_raymarch_test(const float *rays_o, const float *rays_d, float *nears,
+                     const float *fars, const int64_t *alive, int n_alive,
+                     const uint32_t *occ_bits, const ia_occ_grid *occ,
+                     const float *step_size, int N_steps, float *pts,
+                     float *deltas, float *depths, void *stream);
+
+/* ---- a14: composite_test ---------------------------------------------------
+ * Replaces composite_test(rgb, sigma, delta, depth, alive, color, depth_out,
+ * no_hit, thresh) (raymarcher.cpp:57-75, raymarcher.cu:200-262).             */
+int ia_composite_test(const float *rgb, const float *sigma, const float *delta,
+                      const float *depth, const int64_t *alive, int n_alive,
+                      int N_steps, float *color, float *depth_out,
+                      float *no_hit, float thresh, void *stream);
+
+/* ---- a15: raymarch_train ---------------------------------------------------
+ * Replaces raymarch_train(...) (raymarcher.cpp:38-55, raymarcher.cu:116-198):
+ * depths [n_rays,N_steps] (zeros where unused).                              */
+int ia_raymarch_train(const float *rays_o, const float *rays_d,
+                      const float *nears, const float *fars, int n_rays,
+                      const uint32_t *occ_bits, const ia_occ_grid *occ,
+                      const float *step_size, int N_steps, float *depths,
+                      void *stream);
+
+/* ---- a16 + a18: occupancy-grid post-processing -----------------------------
+ * Replaces the tail of DensityGrid.initialize (density_grid.py:104-110) and
+ * max_connected_component (density_grid.py:118-125):
+ *   f = 1-exp(-0.01*density); maxpool3; f > min(mean(f), 0.01);
+ *   keep the largest 26-connected component.
+ * density: [G,G,G] indexed [x][y][z].  Outputs: occ_bits (bit-packed),
+ * occ_bool [G^3] uint8 or NULL.                                              */
+size_t ia_occupancy_workspace_bytes(int G);
+int ia_occupancy_from_density(const float *density, int G, uint32_t *occ_bits,
+                              uint8_t *occ_bool, void *ws, size_t ws_bytes,
+                              void *stream);
+/* Pack a bool grid (e.g. loaded from a checkpoint) into occ_bits.            */
+int ia_occupancy_pack(const uint8_t *occ_bool, int G, uint32_t *occ_bits,
+                      void *stream);
+
+/* ---- a6+a9..a11 fused: observation-space field query ------------------------
+ * deformer(pts, net) of the reference (snarf_deformer.py:161-165 eval branch,
+ * §3.2 of SURVEY.md) as one call with no host sync: search+filter+compact ->
+ * field on valid candidates -> max over candidates.
+ * dmax: optional [P] running maximum that sigma is max-ed into (used by the
+ * occupancy probes, density_grid.py:99-102); rgb may be NULL.                */
+size_t ia_query_workspace_bytes(int P, int n_init);
+int ia_deform_query(const float *pts, int P, const int32_t *n_pts_dev,
+                    const float *voxel_J, const float *tfs,
+                    const int32_t *bone_ids, int n_init,
+                    const ia_snarf_grid *grid, const ia_field *field,
+                    float *rgb, float *sigma, float *dmax, void *ws,
+                    size_t ws_bytes, void *stream);
+
+/* ---- a16 fused: DensityGrid.initialize -------------------------------------
+ * (density_grid.py:95-110).  jitter: [iters,G^3,3] uniform [0,1) numbers (what
+ * torch.rand_like draws at density_grid.py:100).  aabb: DEVICE [6] bbox of
+ * the deformed voxels (ia_precompute's bbox).  Outputs occ_bits / occ_bool /
+ * density [G^3].                                                             */
+size_t ia_density_init_workspace_bytes(int G, int n_init);
+int ia_density_grid_init(const float *jitter, int iters, int G,
+                         const float *aabb, const float *voxel_J,
+                         const float *tfs, const int32_t *bone_ids, int n_init,
+                         const ia_snarf_grid *grid, const ia_field *field,
+                         float *density, uint32_t *occ_bits, uint8_t *occ_bool,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* ---- a12 fused: Raymarcher.render_test --------------------------------------
+ * (raymarcher_acc.py:83-138) with the model closure specialised to
+ * (SNARFDeformer, NeRFNGPNet).  Same N_step schedule
+ * max(min(MAX_BATCH // n_alive, MAX_SAMPLES), 1), computed on device; alive
+ * compaction by ballot/prefix sum; no host synchronisation: `n_iters` loop
+ * iterations are enqueued and iterations with no alive ray exit immediately.
+ * n_alive_out (DEVICE int32[1]) holds the alive count after the last enqueued
+ * iteration (0 = frame complete; >0 = call again with resume = 1).
+ * rays_o/rays_d: [R,3] (SMPL-root frame, after transform_rays_w2s), near/far
+ * [R].  aabb: DEVICE [6] occupancy aabb.  bg: [R,3] or NULL (white).
+ * Outputs: rgb [R,3], depth [R], alpha [R], counter [R].                     */
+size_t ia_render_workspace_bytes(int R, int max_batch, int n_init);
+int ia_render_test(const float *rays_o, const float *rays_d, const float *near,
+                   const float *far, int R, const float *bg,
+                   const uint32_t *occ_bits, int G, const float *aabb,
+                   const float *voxel_J, const float *tfs,
+                   const int32_t *bone_ids, int n_init,
+                   const ia_snarf_grid *grid, const ia_field *field,
+                   int max_samples, int max_batch, int n_iters, int resume,
+                   float *rgb, float *depth, float *alpha, float *counter,
+                   int32_t *n_alive_out, void *ws, size_t ws_bytes,
+                   void *stream);
+
+/* transform_rays_w2s (snarf_deformer.py:95-103): o' = R o + t, d' = R d,
+ * near = |o'| - 1, far = |o'| + 1.  w2s: DEVICE [4,4].                        */
+int ia_transform_rays_w2s(const float *rays_o, const float *rays_d,
+                          const float *w2s, int R, float *o_out, float *d_out,
+                          float *near, float *far, void *stream);
+
+/* ---- measurement hooks (bench.py only) --------------------------------------
+ * When enabled, every launch of the Broyden-search kernel (id 0) and of the
+ * field kernel (id 1) is bracketed by HIP events on the caller's stream and the
+ * kernels count the units they processed.  ia_profile_get synchronises.
+ * units: id 0 -> {(point,init) solves, trilinear grid fetches};
+ *        id 1 -> {samples evaluated, 0}.                                      */
+int ia_profile_enable(int on);
+int ia_profile_reset(void);
+int ia_profile_get(int kernel_id, double *total_ms, int64_t *launches,
+                   uint64_t *units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSTANTAVATAR_HIP_H */

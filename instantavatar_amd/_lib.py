@@ -1,0 +1,134 @@
+"""ctypes binding of libinstantavatar_hip.so (the C ABI in include/instantavatar_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.
+Tensors are passed as raw device pointers + the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinstantavatar_hip.so")
+
+IA_MAX_LEVELS = 16
+IA_N_INIT_MAX = 16
+
+
+class SnarfGrid(C.Structure):
+    _fields_ = [("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("offset", C.c_float * 3), ("scale", C.c_float * 3)]
+
+
+class HashDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("scale", C.c_float * IA_MAX_LEVELS),
+                ("res", C.c_uint32 * IA_MAX_LEVELS), ("offset", C.c_uint32 * (IA_MAX_LEVELS + 1))]
+
+
+class Field(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("scale", C.c_float * 3), ("hash", HashDesc),
+                ("table", C.c_void_p), ("sig_w1", C.c_void_p), ("sig_w2", C.c_void_p),
+                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p)]
+
+
+class OccGrid(C.Structure):
+    _fields_ = [("G", C.c_int), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+
+
+_lib = None
+
+_VP = C.c_void_p
+_SIGS = {
+    "ia_version": (C.c_int, []),
+    "ia_last_error": (C.c_char_p, []),
+    "ia_hash_desc_init": (C.c_int, [C.POINTER(HashDesc), C.c_int, C.c_int, C.c_int, C.c_float]),
+    "ia_smpl_tfs": (C.c_int, [_VP] * 8 + [_VP]),
+    "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
+    "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
+                                  C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
+    "ia_snarf_search_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
+                                          C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, C.c_int32, _VP, _VP,
+                                          _VP, C.c_int, _VP]),
+    "ia_field_fwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP]),
+    "ia_hashgrid_fwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP]),
+    "ia_candidate_max": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_float, C.c_int, _VP, _VP, _VP]),
+    "ia_raymarch_test": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), _VP, C.c_int,
+                                   _VP, _VP, _VP, _VP]),
+    "ia_composite_test": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_float, _VP]),
+    "ia_raymarch_train": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), _VP, C.c_int, _VP, _VP]),
+    "ia_occupancy_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ia_occupancy_from_density": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "ia_occupancy_pack": (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    "ia_query_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ia_deform_query": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
+                                  C.POINTER(SnarfGrid), C.POINTER(Field), _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "ia_density_init_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ia_density_grid_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
+                                       C.POINTER(SnarfGrid), C.POINTER(Field), _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "ia_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ia_render_test": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP,
+                                 C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid), C.POINTER(Field), C.c_int,
+                                 C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "ia_transform_rays_w2s": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "ia_profile_enable": (C.c_int, [C.c_int]),
+    "ia_profile_reset": (C.c_int, []),
+    "ia_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+}
+EXPORTED = sorted(_SIGS)
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "instantavatar_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class IAError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ia_last_error()
+        raise IAError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise IAError("instantavatar_amd kernels need tensors on the GPU (got %s); there is no CPU path" % t.device)
+
+
+def bone_array(bone_ids):
+    arr = (C.c_int32 * len(bone_ids))(*[int(b) for b in bone_ids])
+    return arr
+
+
+def make_hash_desc(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5):
+    hd = HashDesc()
+    check(lib().ia_hash_desc_init(C.byref(hd), n_levels, log2_hashmap_size, base_resolution, per_level_scale),
+          "ia_hash_desc_init")
+    return hd

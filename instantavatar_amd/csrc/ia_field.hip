@@ -1,0 +1,339 @@
+// ia_field.hip -- canonical field for gfx950: multiresolution hash-grid encoding
+// fused with the sigma / colour tiny MLPs (MFMA 32x32x16 f16).
+//
+// Replaces NeRFNGPNet.forward (models/networks/ngp.py:73-83), i.e. tiny-cuda-nn
+// v1.6 HashGrid + FullyFusedMLP(32-64-16) + FullyFusedMLP(16-64-64-16, sigmoid).
+// Arithmetic contract (stated in DESIGN.md; the CPU checker restates it):
+//   * table fp16; per level the 8 corner products are computed in fp32, rounded
+//     to half and accumulated in half (tcnn kernel_grid);
+//   * MLP: fp16 weights and activations, fp32 accumulation, activations rounded
+//     to half between layers; sigma = half(out[0]); rgb = half(sigmoid(out)).
+//
+// Work decomposition (wave64):
+//   * one lane = one sample during encoding; the level loop is wave-uniform, so
+//     all 64 lanes gather from the SAME level table at the same time (coarse
+//     levels: neighbouring samples share cache lines; level constants in SGPRs);
+//   * the 32 features of a sample are the MFMA B operand (k = feature, n =
+//     sample).  A 32x32x16 MFMA wants lane (n, h) to hold 8 consecutive k of
+//     half h, so lanes j and j+32 exchange half of their features with
+//     v_permlane32_swap: afterwards the wave holds two 32-sample column blocks;
+//   * layer chaining needs no data movement: the C/D layout of one layer
+//     (row = (r&3)+8(r>>2)+4h) is used directly as the B operand of the next,
+//     the k-permutation is folded into the A (weight) fragments, which are
+//     built once per workgroup in LDS (22 fragments x 64 lanes x 16 B).
+#include "ia_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define N_FRAG 22
+#define F_SIG1 0   // [rb(2)][s(2)]
+#define F_SIG2 4   // [s(4)]
+#define F_COL1 8   // [rb(2)]
+#define F_COL2 10  // [rb(2)][s(4)]
+#define F_COL3 18  // [s(4)]
+
+int ia_make_field_dev(const ia_field *f, FieldDev *o) {
+  if (!f || !f->table || !f->sig_w1 || !f->sig_w2 || !f->col_w1 || !f->col_w2 || !f->col_w3) return -1;
+  const int L = f->hash.n_levels;
+  if (L != 8 && L != 16) return -2;
+  for (int i = 0; i < 3; i++) { o->center[i] = f->center[i]; o->scale[i] = f->scale[i]; o->inv_unused[i] = 0; }
+  o->lv.n_levels = L;
+  for (int l = 0; l < IA_MAX_LEVELS; l++) {
+    if (l < L) {
+      const uint32_t size = f->hash.offset[l + 1] - f->hash.offset[l];
+      const uint64_t r = f->hash.res[l];
+      const bool dense = r * r * r <= (uint64_t)size;  // tcnn grid_index: hash iff size < stride
+      if (!dense && (size & (size - 1)) != 0) return -3;  // hashed levels must be 2^k
+      o->lv.scale[l] = f->hash.scale[l];
+      o->lv.res[l] = f->hash.res[l];
+      o->lv.offset[l] = f->hash.offset[l];
+      o->lv.size[l] = size;
+      o->lv.hashed[l] = dense ? 0u : 1u;
+    } else {
+      o->lv.scale[l] = 0; o->lv.res[l] = 1; o->lv.offset[l] = 0; o->lv.size[l] = 1; o->lv.hashed[l] = 0;
+    }
+  }
+  o->table = reinterpret_cast<const uint32_t *>(f->table);
+  o->sig_w1 = f->sig_w1; o->sig_w2 = f->sig_w2;
+  o->col_w1 = f->col_w1; o->col_w2 = f->col_w2; o->col_w3 = f->col_w3;
+  return 0;
+}
+
+__device__ __forceinline__ _Float16 ld_h(const uint16_t *w, int idx) {
+  union { uint16_t u; _Float16 h; } c;
+  c.u = w[idx];
+  return c.h;
+}
+
+// Weight value of A-fragment f at lane (i = out row in its 32-block, h) and
+// position p (0..7).  k-permutations explained in the file header.
+template <int L>
+__device__ _Float16 frag_value(const FieldDev &F, int f, int i, int h, int p) {
+  const int kk = (p & 3) + 8 * (p >> 2) + 4 * h;  // C/D row order inside a 16-row slab
+  if (f < F_SIG2) {
+    const int rb = f >> 1, s = f & 1;
+    if (s >= L / 8) return (_Float16)0.f;
+    return ld_h(F.sig_w1, (rb * 32 + i) * (2 * L) + h * L + 8 * s + p);
+  }
+  if (f < F_COL1) {
+    const int s = f - F_SIG2;
+    return i < 16 ? ld_h(F.sig_w2, i * 64 + 16 * s + kk) : (_Float16)0.f;
+  }
+  if (f < F_COL2) {
+    // colour input c[m] = out[m+1] (m < 15), c[15] = 1 (tcnn identity padding);
+    // our B slot kk holds out[kk] for kk >= 1 and the constant 1 at kk == 0.
+    const int rb = f - F_COL1;
+    return ld_h(F.col_w1, (rb * 32 + i) * 16 + (kk == 0 ? 15 : kk - 1));
+  }
+  if (f < F_COL3) {
+    const int rb = (f - F_COL2) >> 2, s = (f - F_COL2) & 3;
+    return ld_h(F.col_w2, (rb * 32 + i) * 64 + 16 * s + kk);
+  }
+  const int s = f - F_COL3;
+  return i < 16 ? ld_h(F.col_w3, i * 64 + 16 * s + kk) : (_Float16)0.f;
+}
+
+__device__ __forceinline__ void normalise(const FieldDev &F, const float *__restrict__ x, size_t i,
+                                          float xn[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    float v = (x[i * 3 + d] - F.center[d]) / F.scale[d] + 0.5f;  // ngp.py:75
+    v = v < 0.f ? 0.f : v;                                       // ngp.py:77 clamp
+    v = v > 1.f ? 1.f : v;
+    xn[d] = v;
+  }
+}
+
+// One level of the hash grid for one sample -> packed (f0,f1) half2.
+__device__ __forceinline__ uint32_t encode_level(const uint32_t *__restrict__ tab, float scale,
+                                                 uint32_t res, uint32_t size, bool hashed,
+                                                 const float xn[3]) {
+  float w[3];
+  uint32_t g[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {  // tcnn pos_fract
+    const float pos = xn[d] * scale + 0.5f;
+    const float fl = floorf(pos);
+    g[d] = (uint32_t)(int)fl;
+    w[d] = pos - fl;
+  }
+  uint32_t v[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const uint32_t cx = g[0] + (idx & 1), cy = g[1] + ((idx >> 1) & 1), cz = g[2] + ((idx >> 2) & 1);
+    uint32_t index;
+    if (hashed) {
+      index = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1);
+    } else {
+      index = cx + cy * res + cz * res * res;  // < 2*size for clamped inputs
+      if (index >= size) index -= size;
+      index = min(index, size - 1);  // memory safety for non-finite inputs
+    }
+    v[idx] = tab[index];
+  }
+  _Float16 r0 = (_Float16)0.f, r1 = (_Float16)0.f;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    float wt = 1.f;
+    wt *= (idx & 1) ? w[0] : 1.f - w[0];
+    wt *= (idx & 2) ? w[1] : 1.f - w[1];
+    wt *= (idx & 4) ? w[2] : 1.f - w[2];
+    union { uint32_t u; half2v h; } c;
+    c.u = v[idx];
+    r0 = r0 + (_Float16)(wt * (float)c.h.x);
+    r1 = r1 + (_Float16)(wt * (float)c.h.y);
+  }
+  union { uint32_t u; half2v h; } o;
+  o.h.x = r0; o.h.y = r1;
+  return o.u;
+}
+
+template <bool RELU>
+__device__ __forceinline__ half8 pack_slab(const floatx16 &acc, int sub) {
+  half8 o;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    float v = acc[8 * sub + p];
+    if (RELU) v = v < 0.f ? 0.f : v;
+    o[p] = (_Float16)v;
+  }
+  return o;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+template <int L>
+__global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int V,
+                                               const int32_t *__restrict__ n_dev, FieldDev F,
+                                               float *__restrict__ rgb, float *__restrict__ sigma,
+                                               unsigned long long *prof) {
+  __shared__ __attribute__((aligned(16))) half8 s_frag[N_FRAG][64];
+  if (n_dev) V = min(V, *n_dev);
+  if (prof && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(prof, (unsigned long long)V);
+  const int n_tiles = (V + 63) >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int waves_total = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  if (blockIdx.x * 4 >= n_tiles) return;  // whole workgroup idle
+  // build the A fragments once per workgroup
+  for (int e = threadIdx.x; e < N_FRAG * 64 * 8; e += 256) {
+    const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
+    reinterpret_cast<_Float16 *>(&s_frag[f][l])[p] = frag_value<L>(F, f, l & 31, l >> 5, p);
+  }
+  __syncthreads();
+  const int h = lane >> 5, j = lane & 31;
+  for (; tile < n_tiles; tile += waves_total) {
+    const int i = tile * 64 + lane;
+    float xn[3] = {0.f, 0.f, 0.f};
+    if (i < V) normalise(F, x, (size_t)i, xn);
+    uint32_t feat[L];
+#pragma unroll
+    for (int l = 0; l < L; l++)
+      feat[l] = encode_level(F.table + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l],
+                             F.lv.hashed[l] != 0, xn);
+    // exchange: lane j gives its upper-half levels to lane j+32 and receives that
+    // lane's lower-half levels (see header)
+#pragma unroll
+    for (int q = 0; q < L / 2; q++) {
+      auto r = __builtin_amdgcn_permlane32_swap(feat[q], feat[q + L / 2], false, false);
+      feat[q] = r[0];
+      feat[q + L / 2] = r[1];
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+      floatx16 a1[2], a3[2], a4[2], a2, a5;
+      // ---- sigma net layer 1: [64 x 2L] ----
+#pragma unroll
+      for (int rb = 0; rb < 2; rb++) {
+        a1[rb] = (floatx16){0.f};
+#pragma unroll
+        for (int s = 0; s < L / 8; s++) {
+          union { uint32_t u[4]; half8 v; } b;
+#pragma unroll
+          for (int q = 0; q < 4; q++) b.u[q] = feat[cb * (L / 2) + 4 * s + q];
+          a1[rb] = MFMA(s_frag[F_SIG1 + rb * 2 + s][lane], b.v, a1[rb]);
+        }
+      }
+      // ---- sigma net layer 2: [16 x 64] ----
+      a2 = (floatx16){0.f};
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        a2 = MFMA(s_frag[F_SIG2 + s][lane], (s & 1) ? pack_slab<true>(a1[s >> 1], 1) : pack_slab<true>(a1[s >> 1], 0), a2);
+      half8 cin = pack_slab<false>(a2, 0);  // out[kk], kk = C/D rows 0..15
+      const float sig = (float)cin[0];      // row 0 lives in lanes h == 0
+      if (h == 0) cin[0] = (_Float16)1.0f;  // identity-encoding padding constant
+      // ---- colour net ----
+#pragma unroll
+      for (int rb = 0; rb < 2; rb++) a3[rb] = MFMA(s_frag[F_COL1 + rb][lane], cin, (floatx16){0.f});
+#pragma unroll
+      for (int rb = 0; rb < 2; rb++) {
+        a4[rb] = (floatx16){0.f};
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          a4[rb] = MFMA(s_frag[F_COL2 + rb * 4 + s][lane],
+                        (s & 1) ? pack_slab<true>(a3[s >> 1], 1) : pack_slab<true>(a3[s >> 1], 0), a4[rb]);
+      }
+      a5 = (floatx16){0.f};
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        a5 = MFMA(s_frag[F_COL3 + s][lane], (s & 1) ? pack_slab<true>(a4[s >> 1], 1) : pack_slab<true>(a4[s >> 1], 0), a5);
+      const int o = tile * 64 + cb * 32 + j;
+      if (h == 0 && o < V) {
+        sigma[o] = sig;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float sg = 1.0f / (1.0f + expf(-a5[c]));  // tcnn logistic
+          rgb[(size_t)o * 3 + c] = (float)(_Float16)sg;
+        }
+      }
+    }
+  }
+}
+
+// Encoding only: feat fp16 [V,32] level-major (tcnn output order).
+template <int L>
+__global__ __launch_bounds__(256) void k_hashgrid(const float *__restrict__ x, int V, FieldDev F,
+                                                  uint32_t *__restrict__ feat) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    float xn[3];
+    normalise(F, x, (size_t)i, xn);
+    uint32_t f[L];
+#pragma unroll
+    for (int l = 0; l < L; l++)
+      f[l] = encode_level(F.table + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l],
+                          F.lv.hashed[l] != 0, xn);
+    uint4 *o = reinterpret_cast<uint4 *>(feat + (size_t)i * L);
+#pragma unroll
+    for (int q = 0; q < L / 4; q++) o[q] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  }
+}
+
+int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb,
+                    float *sigma, hipStream_t s) {
+  if (V <= 0) return IA_OK;
+  const int tiles = (V + 63) / 64;
+  int blocks = (tiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  unsigned long long *prof = ia_prof_units(IA_PROF_FIELD);
+  ia_prof_begin(IA_PROF_FIELD, s);
+  if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof);
+  ia_prof_end(IA_PROF_FIELD, s);
+  IA_LAUNCH_CHECK("k_field");
+  return IA_OK;
+}
+
+extern "C" int ia_field_fwd(const float *x, int V, const int32_t *n_dev, const ia_field *field, float *rgb,
+                            float *sigma, void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_field_fwd: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(x && rgb && sigma, "ia_field_fwd: null pointer");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_field_fwd: bad field descriptor (%d)", rc);
+  return ia_launch_field(x, V, n_dev, F, rgb, sigma, (hipStream_t)stream);
+}
+
+extern "C" int ia_hashgrid_fwd(const float *x, int V, const ia_field *field, uint16_t *feat, void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_hashgrid_fwd: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(x && feat, "ia_hashgrid_fwd: null pointer");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_hashgrid_fwd: bad field descriptor (%d)", rc);
+  int blocks = (V + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F,
+                       reinterpret_cast<uint32_t *>(feat));
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F,
+                       reinterpret_cast<uint32_t *>(feat));
+  IA_LAUNCH_CHECK("k_hashgrid");
+  return IA_OK;
+}
+
+extern "C" int ia_hash_desc_init(ia_hash_desc *o, int n_levels, int log2_hashmap_size, int base_resolution,
+                                 float per_level_scale) {
+  IA_CHECK_ARG(o && n_levels > 0 && n_levels <= IA_MAX_LEVELS, "ia_hash_desc_init: bad arguments");
+  // tcnn grid.h: grid_scale(), grid_resolution(), GridEncodingTemplated ctor (host arithmetic)
+  const float l2 = log2f(per_level_scale);
+  uint32_t off = 0;
+  o->n_levels = n_levels;
+  for (int l = 0; l < n_levels; l++) {
+    const float s = exp2f((float)l * l2) * (float)base_resolution - 1.0f;
+    const uint32_t r = (uint32_t)ceilf(s) + 1;
+    const uint32_t max_params = 0xffffffffu / 2;
+    uint32_t n = powf((float)r, 3.f) > (float)max_params ? max_params : r * r * r;
+    n = (n + 7u) / 8u * 8u;
+    if (n > (1u << log2_hashmap_size)) n = 1u << log2_hashmap_size;
+    o->scale[l] = s; o->res[l] = r; o->offset[l] = off;
+    off += n;
+  }
+  o->offset[n_levels] = off;
+  return IA_OK;
+}

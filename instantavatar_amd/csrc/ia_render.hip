@@ -1,0 +1,827 @@
+// ia_render.hip -- occupancy-grid ray marcher, compositor, occupancy build and
+// the fused per-frame pipelines (no host synchronisation anywhere).
+//
+// Reference semantics: renderers/cuda/raymarcher.cu:13-73 (march test),
+// :116-161 (march train), :200-235 (composite test);
+// renderers/raymarcher_acc.py:83-138 (render_test loop);
+// models/structures/density_grid.py:95-125 (occupancy build);
+// deformers/snarf_deformer.py:95-103,127-141.
+#include "ia_common.h"
+
+int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb,
+                    float *sigma, hipStream_t s);
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+__device__ __forceinline__ bool occ_test(const uint32_t *__restrict__ bits, int G, int nx, int ny, int nz) {
+  const uint32_t idx = (uint32_t)((nx * G + ny) * G + nz);
+  return (bits[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+struct MarchRay {
+  float ox, oy, oz, dx, dy, dz, cx, cy, cz, sx, sy, sz, far, dt;
+};
+
+__device__ __forceinline__ bool march_occupied(const MarchRay &r, const uint32_t *__restrict__ bits, int G,
+                                               float t, float &x, float &y, float &z) {
+  x = r.ox + t * r.dx; y = r.oy + t * r.dy; z = r.oz + t * r.dz;
+  const int nx = (int)clampf((x - r.cx) * r.sx, 0.0f, G - 1.0f);  // raymarcher.cu:49-51
+  const int ny = (int)clampf((y - r.cy) * r.sy, 0.0f, G - 1.0f);
+  const int nz = (int)clampf((z - r.cz) * r.sz, 0.0f, G - 1.0f);
+  return occ_test(bits, G, nx, ny, nz);
+}
+
+__device__ __forceinline__ MarchRay load_ray(const float *__restrict__ o, const float *__restrict__ d,
+                                             const float *__restrict__ fars, const float *__restrict__ step,
+                                             size_t n, const float *aabb_mn, const float *aabb_mx, int G) {
+  MarchRay r;
+  r.ox = o[n * 3]; r.oy = o[n * 3 + 1]; r.oz = o[n * 3 + 2];
+  r.dx = d[n * 3]; r.dy = d[n * 3 + 1]; r.dz = d[n * 3 + 2];
+  r.cx = aabb_mn[0]; r.cy = aabb_mn[1]; r.cz = aabb_mn[2];
+  // scale = max_corner - min_corner (raymarcher_acc.py:105); sx = grid_size / scale (:41)
+  r.sx = G / (aabb_mx[0] - aabb_mn[0]); r.sy = G / (aabb_mx[1] - aabb_mn[1]); r.sz = G / (aabb_mx[2] - aabb_mn[2]);
+  r.far = fars[n]; r.dt = step[n];
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// a13 raymarch_test (dense reference layout)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raymarch_test(const float *__restrict__ rays_o,
+                                                       const float *__restrict__ rays_d, float *nears,
+                                                       const float *__restrict__ fars,
+                                                       const int64_t *__restrict__ alive, int n_alive,
+                                                       const uint32_t *__restrict__ bits, OccDev occ,
+                                                       const float *__restrict__ step, int N_steps,
+                                                       float *__restrict__ pts, float *__restrict__ deltas,
+                                                       float *__restrict__ depths) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const size_t n = (size_t)alive[i];
+  const MarchRay r = load_ray(rays_o, rays_d, fars, step, n, occ.mn, occ.mx, occ.G);
+  int s = 0;
+  float t = nears[n];
+  while (t < r.far && s < N_steps) {
+    float x, y, z;
+    if (march_occupied(r, bits, occ.G, t, x, y, z)) {
+      const size_t o = (size_t)i * N_steps + s;
+      pts[o * 3] = x; pts[o * 3 + 1] = y; pts[o * 3 + 2] = z;
+      deltas[o] = r.dt; depths[o] = t;
+      s++;
+    }
+    t += r.dt;
+  }
+  for (; s < N_steps; s++) {  // the reference zero-fills (raymarcher.cu:89-91)
+    const size_t o = (size_t)i * N_steps + s;
+    pts[o * 3] = 0.f; pts[o * 3 + 1] = 0.f; pts[o * 3 + 2] = 0.f;
+    deltas[o] = 0.f; depths[o] = 0.f;
+  }
+  nears[n] = t;
+}
+
+// a15 raymarch_train
+__global__ __launch_bounds__(256) void k_raymarch_train(const float *__restrict__ rays_o,
+                                                        const float *__restrict__ rays_d,
+                                                        const float *__restrict__ nears,
+                                                        const float *__restrict__ fars, int n_rays,
+                                                        const uint32_t *__restrict__ bits, OccDev occ,
+                                                        const float *__restrict__ step, int N_steps,
+                                                        float *__restrict__ depths) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rays) return;
+  const MarchRay r = load_ray(rays_o, rays_d, fars, step, (size_t)n, occ.mn, occ.mx, occ.G);
+  int s = 0;
+  float t = nears[n];
+  while (t < r.far && s < N_steps) {
+    float x, y, z;
+    if (march_occupied(r, bits, occ.G, t, x, y, z)) { depths[(size_t)n * N_steps + s] = t; s++; }
+    t += r.dt;
+  }
+  for (; s < N_steps; s++) depths[(size_t)n * N_steps + s] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// a14 composite_test (dense reference layout)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void composite_step(float sg, float dl, float tdepth, const float *rgb3,
+                                               float thresh, float &T, float &c0, float &c1, float &c2,
+                                               float &dep) {
+  const float tau = __expf(-sg * dl);  // raymarcher.cu:219
+  const float alpha = 1.0f - tau;
+  if (alpha < thresh) return;          // :221-224 (T unchanged)
+  const float w = alpha * T;
+  c0 += w * rgb3[0]; c1 += w * rgb3[1]; c2 += w * rgb3[2];
+  dep += w * tdepth;
+  T *= tau;
+}
+
+__global__ __launch_bounds__(256) void k_composite_test(const float *__restrict__ rgb,
+                                                        const float *__restrict__ sigma,
+                                                        const float *__restrict__ delta,
+                                                        const float *__restrict__ depth,
+                                                        const int64_t *__restrict__ alive, int n_alive,
+                                                        int N_steps, float *color, float *depth_out,
+                                                        float *nohit, float thresh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const size_t n = (size_t)alive[i];
+  float T = nohit[n];
+  float c0 = color[n * 3], c1 = color[n * 3 + 1], c2 = color[n * 3 + 2], dep = depth_out[n];
+  int s = 0;
+  while (s < N_steps && (double)T > 1e-4 && delta[(size_t)i * N_steps + s] > 0) {
+    const size_t o = (size_t)i * N_steps + s;
+    composite_step(sigma[o], delta[o], depth[o], rgb + o * 3, thresh, T, c0, c1, c2, dep);
+    s++;
+  }
+  color[n * 3] = c0; color[n * 3 + 1] = c1; color[n * 3 + 2] = c2;
+  depth_out[n] = dep;
+  nohit[n] = T;
+}
+
+// ---------------------------------------------------------------------------
+// a6 candidate reduction (snarf_deformer.py:130-141 / 147-158)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cand_max(const float *__restrict__ cand_rgb,
+                                         const float *__restrict__ cand_sigma, int off, int cnt, int n_init,
+                                         float fill, bool nan_to_num, float &sg, float *rgb3) {
+  // slots are ordered by init index; invalid slots carry `fill` and rgb 0.  The
+  // first maximum wins (torch.max), so a valid candidate must EXCEED every
+  // earlier slot.  With cnt < n_init at least one invalid slot exists; whether
+  // it precedes the valid ones only matters for ties with `fill`, where rgb of
+  // a tied valid candidate would be taken only if it came first -- keep exact
+  // semantics by scanning valid candidates in order against the running best,
+  // seeded with `fill` when an invalid slot exists.
+  float best;
+  int bi = -1;
+  rgb3[0] = rgb3[1] = rgb3[2] = 0.f;
+  if (cnt < n_init) best = fill; else best = -INFINITY;
+  for (int c = 0; c < cnt; c++) {
+    float s = cand_sigma[off + c];
+    if (nan_to_num && !isfinite(s)) s = 0.f;
+    if (s > best || (bi < 0 && cnt >= n_init && c == 0)) { best = s; bi = c; }
+  }
+  if (bi >= 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float v = cand_rgb[(size_t)(off + bi) * 3 + k];
+      if (nan_to_num && !isfinite(v)) v = 0.f;
+      rgb3[k] = v;
+    }
+  }
+  sg = best;
+}
+
+__global__ __launch_bounds__(256) void k_candidate_max(const float *__restrict__ cand_rgb,
+                                                       const float *__restrict__ cand_sigma,
+                                                       const int32_t *__restrict__ pt_off,
+                                                       const uint8_t *__restrict__ pt_cnt, int P,
+                                                       const int32_t *__restrict__ n_pts_dev, int n_init,
+                                                       float fill, int nan_to_num, float *__restrict__ rgb,
+                                                       float *__restrict__ sigma, float *__restrict__ dmax) {
+  if (n_pts_dev) P = min(P, *n_pts_dev);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float sg, c[3];
+  cand_max(cand_rgb, cand_sigma, pt_off[p], pt_cnt[p], n_init, fill, nan_to_num != 0, sg, c);
+  if (sigma) sigma[p] = sg;
+  if (rgb) { rgb[(size_t)p * 3] = c[0]; rgb[(size_t)p * 3 + 1] = c[1]; rgb[(size_t)p * 3 + 2] = c[2]; }
+  if (dmax) dmax[p] = fmaxf(dmax[p], sg);  // density_grid.py:102 torch.maximum
+}
+
+// ---------------------------------------------------------------------------
+// a16/a18 occupancy post-processing
+// ---------------------------------------------------------------------------
+struct OccWs {
+  double sum;               // sum of the max-pooled field
+  unsigned long long best;  // (count << 32) | (~label)
+};
+
+__global__ void k_occ_reset(OccWs *w) { w->sum = 0.0; w->best = 0ull; }
+
+// f = 1 - exp(0.01 * -density); g = maxpool3(f); accumulate sum(g)
+__global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ density, int G,
+                                                  float *__restrict__ pooled, OccWs *ws) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  if (i < n) {
+    const int x = i / (G * G), y = i / G % G, z = i % G;
+    m = -INFINITY;
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++) {
+          const int xx = x + a, yy = y + b, zz = z + c;
+          if (xx < 0 || yy < 0 || zz < 0 || xx >= G || yy >= G || zz >= G) continue;
+          const float f = 1.f - expf(0.01f * -density[(xx * G + yy) * G + zz]);  // density_grid.py:104
+          m = (f > m || isnan(f)) ? f : m;
+        }
+    pooled[i] = m;
+  }
+  double v = (i < n) ? (double)m : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (ia_lane() == 0) atomicAdd(&ws->sum, v);
+}
+
+// grid = g > clamp(mean, max=0.01); union-find parent init
+__global__ __launch_bounds__(256) void k_occ_threshold(const float *__restrict__ pooled, int G,
+                                                       const OccWs *__restrict__ ws,
+                                                       int32_t *__restrict__ parent) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mean = (float)(ws->sum / (double)n);
+  const float thr = mean > 0.01f ? 0.01f : mean;  // density_grid.py:106
+  parent[i] = pooled[i] > thr ? i : -1;
+}
+
+__device__ __forceinline__ int uf_find(int32_t *parent, int i) {
+  int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (p != i) { i = p; p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  return i;
+}
+
+// 26-connected union (max_pool3d 3x3x3 label propagation, density_grid.py:118-125):
+// the surviving label of a component is its LARGEST linear index (+1), so roots
+// are the maximum index (parent[i] >= i).
+__global__ __launch_bounds__(256) void k_occ_union(int G, int32_t *parent) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || parent[i] < 0) return;
+  const int x = i / (G * G), y = i / G % G, z = i % G;
+  // the 13 neighbours with a larger linear index
+  for (int a = 0; a <= 1; a++)
+    for (int b = -1; b <= 1; b++)
+      for (int c = -1; c <= 1; c++) {
+        if (a == 0 && (b < 0 || (b == 0 && c <= 0))) continue;
+        const int xx = x + a, yy = y + b, zz = z + c;
+        if (xx >= G || yy < 0 || yy >= G || zz < 0 || zz >= G) continue;
+        const int j = (xx * G + yy) * G + zz;
+        if (__hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) continue;
+        int ra = i, rb = j;
+        while (true) {
+          ra = uf_find(parent, ra); rb = uf_find(parent, rb);
+          if (ra == rb) break;
+          if (ra > rb) { const int t = ra; ra = rb; rb = t; }
+          const int old = atomicCAS(&parent[ra], ra, rb);  // link smaller root under larger
+          if (old == ra) break;
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void k_occ_count(int G, int32_t *parent, int32_t *__restrict__ label,
+                                                   int32_t *count) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int l = -1;
+  if (parent[i] >= 0) { l = uf_find(parent, i); atomicAdd(&count[l], 1); }
+  label[i] = l;
+}
+
+// torch.mode(mcc[field]): most frequent label, smallest label on ties (:109)
+__global__ __launch_bounds__(256) void k_occ_best(int G, const int32_t *__restrict__ count, OccWs *ws) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = count[i];
+  if (c > 0) atomicMax(&ws->best, ((unsigned long long)c << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i));
+}
+
+__global__ __launch_bounds__(256) void k_occ_final(int G, const int32_t *__restrict__ label,
+                                                   const OccWs *__restrict__ ws, uint32_t *__restrict__ bits,
+                                                   uint8_t *__restrict__ occ_bool) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long best = ws->best;
+  const int best_label = best ? (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu)) : -2;
+  const bool on = (i < n) && label[i] == best_label;
+  if (i < n && occ_bool) occ_bool[i] = on;
+  const unsigned long long m = __ballot(on);
+  const int lane = ia_lane();
+  if (i < n || (i - lane) < n) {
+    if (lane == 0) bits[(i >> 5)] = (uint32_t)m;
+    if (lane == 32) bits[(i >> 5)] = (uint32_t)(m >> 32);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_occ_pack(const uint8_t *__restrict__ occ_bool, int n,
+                                                  uint32_t *__restrict__ bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = (i < n) && occ_bool[i] != 0;
+  const unsigned long long m = __ballot(on);
+  const int lane = ia_lane();
+  if ((i - lane) < n) {
+    if (lane == 0) bits[(i >> 5)] = (uint32_t)m;
+    if (lane == 32 && i < ((n + 31) / 32) * 32) bits[(i >> 5)] = (uint32_t)(m >> 32);
+  }
+}
+
+__global__ void k_fill_f32(float *p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_i32(int32_t *p, int32_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// probe points of DensityGrid.initialize (density_grid.py:100):
+// coords = (idx/G + rand/G) * (aabb1 - aabb0) + aabb0
+__global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G,
+                                                      const float *__restrict__ aabb,
+                                                      float *__restrict__ pts) {
+  const int n = G * G * G;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int idx[3] = {i / (G * G), i / G % G, i % G};
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float c0 = (float)idx[d] / (float)G;
+    const float c = c0 + jitter[(size_t)i * 3 + d] / (float)G;
+    pts[(size_t)i * 3 + d] = c * (aabb[3 + d] - aabb[d]) + aabb[d];
+  }
+}
+
+// transform_rays_w2s (snarf_deformer.py:95-103)
+__global__ __launch_bounds__(256) void k_transform_rays(const float *__restrict__ o, const float *__restrict__ d,
+                                                        const float *__restrict__ w2s, int R,
+                                                        float *__restrict__ o2, float *__restrict__ d2,
+                                                        float *__restrict__ near, float *__restrict__ far) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const float ox = o[(size_t)i * 3], oy = o[(size_t)i * 3 + 1], oz = o[(size_t)i * 3 + 2];
+  const float dx = d[(size_t)i * 3], dy = d[(size_t)i * 3 + 1], dz = d[(size_t)i * 3 + 2];
+  float po[3], pd[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    po[a] = ox * w2s[a * 4] + oy * w2s[a * 4 + 1] + oz * w2s[a * 4 + 2] + w2s[a * 4 + 3];
+    pd[a] = dx * w2s[a * 4] + dy * w2s[a * 4 + 1] + dz * w2s[a * 4 + 2];
+  }
+  const float dist = sqrtf(po[0] * po[0] + po[1] * po[1] + po[2] * po[2]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) { o2[(size_t)i * 3 + a] = po[a]; d2[(size_t)i * 3 + a] = pd[a]; }
+  near[i] = dist - 1; far[i] = dist + 1;
+}
+
+// ---------------------------------------------------------------------------
+// fused render_test loop state (device resident)
+// ---------------------------------------------------------------------------
+struct RenderState {
+  int32_t n_alive;       // rays alive at the start of the current iteration
+  int32_t n_alive_next;  // compaction counter for the next iteration
+  int32_t n_step;        // N_step of the current iteration
+  int32_t k;             // samples-per-ray budget consumed (raymarcher_acc.py:107,127)
+  int32_t n_samples;     // compact sample counter
+  int32_t n_cand;        // compact candidate counter
+  int32_t iters;         // iterations actually executed
+  int32_t pad;
+};
+
+__global__ void k_render_init_state(RenderState *st, int R) {
+  st->n_alive = 0; st->n_alive_next = R; st->n_step = 0; st->k = 0;
+  st->n_samples = 0; st->n_cand = 0; st->iters = 0; st->pad = 0;
+}
+
+__global__ __launch_bounds__(256) void k_render_init_rays(int R, const float *__restrict__ near,
+                                                          const float *__restrict__ far,
+                                                          float *__restrict__ near_w, float *__restrict__ step,
+                                                          float *__restrict__ color, float *__restrict__ depth,
+                                                          float *__restrict__ nohit, float *__restrict__ counter,
+                                                          int32_t *__restrict__ alive, int max_samples) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  near_w[i] = near[i];
+  step[i] = (far[i] - near[i]) / max_samples;  // raymarcher_acc.py:101
+  color[(size_t)i * 3] = 0.f; color[(size_t)i * 3 + 1] = 0.f; color[(size_t)i * 3 + 2] = 0.f;
+  depth[i] = 0.f; nohit[i] = 1.f; counter[i] = 0.f;
+  alive[i] = i;
+}
+
+// raymarcher_acc.py:107-112: loop condition and N_step schedule, on device.
+__global__ void k_iter_begin(RenderState *st, int max_samples, int max_batch) {
+  int na = st->n_alive_next;
+  if (st->k >= max_samples) na = 0;  // while k < MAX_SAMPLES
+  st->n_alive = na;
+  st->n_alive_next = 0;
+  st->n_samples = 0;
+  st->n_cand = 0;
+  if (na > 0) {
+    int ns = max_batch / na;
+    ns = ns < max_samples ? ns : max_samples;
+    ns = ns > 1 ? ns : 1;
+    st->n_step = ns;
+    st->k += ns;
+    st->iters += 1;
+  } else {
+    st->n_step = 0;
+  }
+}
+
+// march + sample compaction: every alive ray counts its samples (pass 1), the
+// wave reserves a contiguous range with one atomic (prefix sum), pass 2 re-marches
+// and writes positions + depths.  A ray's samples are contiguous and ordered.
+__global__ __launch_bounds__(256) void k_march_compact(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, float *near_w,
+    const float *__restrict__ fars, const float *__restrict__ step, const int32_t *__restrict__ alive,
+    RenderState *st, const uint32_t *__restrict__ bits, int G, const float *__restrict__ aabb,
+    float *__restrict__ s_pts, float *__restrict__ s_t, int32_t *__restrict__ ray_off,
+    int32_t *__restrict__ ray_cnt, float *__restrict__ counter, int sample_cap) {
+  const int n_alive = st->n_alive;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i - ia_lane()) >= n_alive) return;  // whole wave idle
+  const int N_steps = st->n_step;
+  const bool live = i < n_alive;
+  int cnt = 0;
+  size_t n = 0;
+  MarchRay r;
+  float t0 = 0.f, t_end = 0.f;
+  if (live) {
+    n = (size_t)alive[i];
+    r = load_ray(rays_o, rays_d, fars, step, n, aabb, aabb + 3, G);
+    t0 = near_w[n];
+    float t = t0;
+    while (t < r.far && cnt < N_steps) {
+      float x, y, z;
+      if (march_occupied(r, bits, G, t, x, y, z)) cnt++;
+      t += r.dt;
+    }
+    t_end = t;
+  }
+  int total;
+  const int excl = ia_wave_excl_scan(cnt, total);
+  int base = 0;
+  if (ia_lane() == 0 && total > 0) base = atomicAdd(&st->n_samples, total);
+  base = __shfl(base, 0, 64) + excl;
+  if (!live) return;
+  ray_off[i] = base;
+  ray_cnt[i] = cnt;
+  counter[n] += (float)cnt;  // raymarcher_acc.py:116
+  near_w[n] = t_end;         // raymarcher.cu:72
+  int s = 0;
+  float t = t0;
+  while (t < r.far && s < cnt) {
+    float x, y, z;
+    if (march_occupied(r, bits, G, t, x, y, z)) {
+      const int o = base + s;
+      if (o < sample_cap) { s_pts[(size_t)o * 3] = x; s_pts[(size_t)o * 3 + 1] = y; s_pts[(size_t)o * 3 + 2] = z; s_t[o] = t; }
+      s++;
+    }
+    t += r.dt;
+  }
+}
+
+// composite + alive compaction (raymarcher_acc.py:118-127)
+__global__ __launch_bounds__(256) void k_composite_compact(
+    const int32_t *__restrict__ alive, int32_t *__restrict__ alive_next, RenderState *st,
+    const int32_t *__restrict__ ray_off, const int32_t *__restrict__ ray_cnt,
+    const float *__restrict__ s_t, const float *__restrict__ step, const int32_t *__restrict__ pt_off,
+    const uint8_t *__restrict__ pt_cnt, const float *__restrict__ cand_rgb,
+    const float *__restrict__ cand_sigma, int n_init, float *color, float *depth, float *nohit,
+    float thresh) {
+  const int n_alive = st->n_alive;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i - ia_lane()) >= n_alive) return;
+  const int N_steps = st->n_step;
+  bool keep = false;
+  int n = 0;
+  if (i < n_alive) {
+    n = alive[i];
+    const int off = ray_off[i], cnt = ray_cnt[i];
+    const float dt = step[n];
+    float T = nohit[n];
+    float c0 = color[(size_t)n * 3], c1 = color[(size_t)n * 3 + 1], c2 = color[(size_t)n * 3 + 2];
+    float dep = depth[n];
+    int s = 0;
+    // `delta > 0` (raymarcher.cu:218) == slot filled; dt > 0 for filled slots
+    while (s < cnt && (double)T > 1e-4 && dt > 0) {
+      float sg, c[3];
+      cand_max(cand_rgb, cand_sigma, pt_off[off + s], pt_cnt[off + s], n_init, 0.f, true, sg, c);
+      composite_step(sg, dt, s_t[off + s], c, thresh, T, c0, c1, c2, dep);
+      s++;
+    }
+    color[(size_t)n * 3] = c0; color[(size_t)n * 3 + 1] = c1; color[(size_t)n * 3 + 2] = c2;
+    depth[n] = dep;
+    nohit[n] = T;
+    // alive = alive[(no_hit > 1e-4) & (z_new[:, -1] > 0)]  (raymarcher_acc.py:126)
+    const bool last_filled = (cnt == N_steps) && (s_t[off + cnt - 1] > 0.f);
+    keep = ((double)T > 1e-4) && last_filled;
+  }
+  const unsigned long long m = __ballot(keep);
+  const int total = __popcll(m);
+  int base = 0;
+  if (ia_lane() == 0 && total > 0) base = atomicAdd(&st->n_alive_next, total);
+  base = __shfl(base, 0, 64);
+  if (keep) alive_next[base + __popcll(m & ((1ull << ia_lane()) - 1ull))] = n;
+}
+
+__global__ __launch_bounds__(256) void k_render_finalize(int R, const float *__restrict__ color,
+                                                         const float *__restrict__ depth,
+                                                         const float *__restrict__ nohit,
+                                                         const float *__restrict__ counter,
+                                                         const float *__restrict__ bg, const RenderState *st,
+                                                         float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                                                         float *__restrict__ alpha_out,
+                                                         float *__restrict__ counter_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const float T = nohit[i];
+#pragma unroll
+  for (int c = 0; c < 3; c++)  // raymarcher_acc.py:128-132
+    rgb_out[(size_t)i * 3 + c] = color[(size_t)i * 3 + c] + T * (bg ? bg[(size_t)i * 3 + c] : 1.0f);
+  depth_out[i] = depth[i];
+  alpha_out[i] = 1.f - T;
+  counter_out[i] = counter[i];
+}
+
+// After the last enqueued iteration: report whether the loop would continue.
+__global__ void k_render_report(RenderState *st, int max_samples, int32_t *n_alive_out) {
+  int na = st->n_alive_next;
+  if (st->k >= max_samples) na = 0;
+  if (n_alive_out) *n_alive_out = na;
+}
+
+// ---------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------
+static OccDev make_occ(const ia_occ_grid *o) {
+  OccDev d;
+  d.G = o->G;
+  for (int i = 0; i < 3; i++) { d.mn[i] = o->aabb_min[i]; d.mx[i] = o->aabb_max[i]; }
+  return d;
+}
+
+struct WsCarver {
+  char *base; size_t off, cap;
+  WsCarver(void *p, size_t c) : base((char *)p), off(0), cap(c) {}
+  template <typename T> T *take(size_t n) {
+    T *r = (T *)(base + off);
+    off += ia_align(n * sizeof(T));
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+extern "C" int ia_raymarch_test(const float *rays_o, const float *rays_d, float *nears, const float *fars,
+                                const int64_t *alive, int n_alive, const uint32_t *occ_bits,
+                                const ia_occ_grid *occ, const float *step_size, int N_steps, float *pts,
+                                float *deltas, float *depths, void *stream) {
+  IA_CHECK_ARG(n_alive >= 0 && N_steps > 0, "ia_raymarch_test: bad sizes");
+  if (n_alive == 0) return IA_OK;
+  IA_CHECK_ARG(rays_o && rays_d && nears && fars && alive && occ_bits && occ && step_size && pts && deltas && depths,
+               "ia_raymarch_test: null pointer");
+  hipLaunchKernelGGL(k_raymarch_test, dim3(ia_div_up(n_alive, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                     rays_d, nears, fars, alive, n_alive, occ_bits, make_occ(occ), step_size, N_steps, pts, deltas,
+                     depths);
+  IA_LAUNCH_CHECK("k_raymarch_test");
+  return IA_OK;
+}
+
+extern "C" int ia_raymarch_train(const float *rays_o, const float *rays_d, const float *nears,
+                                 const float *fars, int n_rays, const uint32_t *occ_bits,
+                                 const ia_occ_grid *occ, const float *step_size, int N_steps, float *depths,
+                                 void *stream) {
+  IA_CHECK_ARG(n_rays >= 0 && N_steps > 0, "ia_raymarch_train: bad sizes");
+  if (n_rays == 0) return IA_OK;
+  IA_CHECK_ARG(rays_o && rays_d && nears && fars && occ_bits && occ && step_size && depths,
+               "ia_raymarch_train: null pointer");
+  hipLaunchKernelGGL(k_raymarch_train, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                     rays_d, nears, fars, n_rays, occ_bits, make_occ(occ), step_size, N_steps, depths);
+  IA_LAUNCH_CHECK("k_raymarch_train");
+  return IA_OK;
+}
+
+extern "C" int ia_composite_test(const float *rgb, const float *sigma, const float *delta, const float *depth,
+                                 const int64_t *alive, int n_alive, int N_steps, float *color,
+                                 float *depth_out, float *no_hit, float thresh, void *stream) {
+  IA_CHECK_ARG(n_alive >= 0 && N_steps > 0, "ia_composite_test: bad sizes");
+  if (n_alive == 0) return IA_OK;
+  IA_CHECK_ARG(rgb && sigma && delta && depth && alive && color && depth_out && no_hit,
+               "ia_composite_test: null pointer");
+  hipLaunchKernelGGL(k_composite_test, dim3(ia_div_up(n_alive, 256)), dim3(256), 0, (hipStream_t)stream, rgb,
+                     sigma, delta, depth, alive, n_alive, N_steps, color, depth_out, no_hit, thresh);
+  IA_LAUNCH_CHECK("k_composite_test");
+  return IA_OK;
+}
+
+extern "C" int ia_candidate_max(const float *cand_rgb, const float *cand_sigma, const int32_t *pt_off,
+                                const uint8_t *pt_cnt, int P, const int32_t *n_pts_dev, int n_init, float fill,
+                                int nan_to_num, float *rgb, float *sigma, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_candidate_max: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(cand_rgb && cand_sigma && pt_off && pt_cnt, "ia_candidate_max: null pointer");
+  hipLaunchKernelGGL(k_candidate_max, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_rgb,
+                     cand_sigma, pt_off, pt_cnt, P, n_pts_dev, n_init, fill, nan_to_num, rgb, sigma,
+                     (float *)nullptr);
+  IA_LAUNCH_CHECK("k_candidate_max");
+  return IA_OK;
+}
+
+// ---- occupancy -------------------------------------------------------------
+extern "C" size_t ia_occupancy_workspace_bytes(int G) {
+  const size_t n = (size_t)G * G * G;
+  return ia_align(sizeof(OccWs)) + 4 * ia_align(n * 4) + 1024;
+}
+
+extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *occ_bits, uint8_t *occ_bool,
+                                         void *ws, size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(density && occ_bits && ws, "ia_occupancy_from_density: null pointer");
+  IA_CHECK_ARG(G >= 4 && G <= 256 && (G * G * G) % 64 == 0, "ia_occupancy_from_density: unsupported G=%d", G);
+  if (ws_bytes < ia_occupancy_workspace_bytes(G)) return ia_set_error(IA_ERR_WORKSPACE, "ia_occupancy_from_density: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = G * G * G;
+  WsCarver w(ws, ws_bytes);
+  OccWs *ow = w.take<OccWs>(1);
+  float *pooled = w.take<float>(n);
+  int32_t *parent = w.take<int32_t>(n);
+  int32_t *label = w.take<int32_t>(n);
+  int32_t *count = w.take<int32_t>(n);
+  const dim3 grid(ia_div_up(n, 256)), blk(256);
+  hipLaunchKernelGGL(k_occ_reset, dim3(1), dim3(1), 0, s, ow);
+  hipLaunchKernelGGL(k_fill_i32, grid, blk, 0, s, count, 0, n);
+  hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, density, G, pooled, ow);
+  hipLaunchKernelGGL(k_occ_threshold, grid, blk, 0, s, pooled, G, ow, parent);
+  hipLaunchKernelGGL(k_occ_union, grid, blk, 0, s, G, parent);
+  hipLaunchKernelGGL(k_occ_count, grid, blk, 0, s, G, parent, label, count);
+  hipLaunchKernelGGL(k_occ_best, grid, blk, 0, s, G, count, ow);
+  hipLaunchKernelGGL(k_occ_final, grid, blk, 0, s, G, label, ow, occ_bits, occ_bool);
+  IA_LAUNCH_CHECK("occupancy_from_density");
+  return IA_OK;
+}
+
+extern "C" int ia_occupancy_pack(const uint8_t *occ_bool, int G, uint32_t *occ_bits, void *stream) {
+  IA_CHECK_ARG(occ_bool && occ_bits && G > 0 && (G * G * G) % 64 == 0, "ia_occupancy_pack: bad arguments");
+  const int n = G * G * G;
+  hipLaunchKernelGGL(k_occ_pack, dim3(ia_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, occ_bool, n, occ_bits);
+  IA_LAUNCH_CHECK("k_occ_pack");
+  return IA_OK;
+}
+
+// ---- fused deformer query ----------------------------------------------------
+struct QueryWs {
+  int32_t *n_cand; int32_t *pt_off; uint8_t *pt_cnt; float *cand_xc; float *cand_rgb; float *cand_sigma;
+  int cand_cap;
+};
+static size_t query_ws_bytes(int P, int n_init) {
+  const size_t cap = (size_t)P * n_init;
+  return ia_align(256) + ia_align((size_t)P * 4) + ia_align((size_t)P) + 2 * ia_align(cap * 12) + ia_align(cap * 4);
+}
+static QueryWs carve_query(WsCarver &w, int P, int n_init) {
+  QueryWs q;
+  const size_t cap = (size_t)P * n_init;
+  q.n_cand = w.take<int32_t>(64);
+  q.pt_off = w.take<int32_t>(P);
+  q.pt_cnt = w.take<uint8_t>(P);
+  q.cand_xc = w.take<float>(cap * 3);
+  q.cand_rgb = w.take<float>(cap * 3);
+  q.cand_sigma = w.take<float>(cap);
+  q.cand_cap = (int)cap;
+  return q;
+}
+
+extern "C" size_t ia_query_workspace_bytes(int P, int n_init) { return query_ws_bytes(P, n_init) + 1024; }
+
+static int query_impl(const float *pts, int P, const int32_t *n_pts_dev, const float *voxel_J, const float *tfs,
+                      const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid, const FieldDev &F,
+                      const QueryWs &q, hipStream_t s) {
+  int rc = ia_snarf_search_compact(pts, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, 1e-5f, 1e-1f,
+                                   q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, 1, s);
+  if (rc) return rc;
+  return ia_launch_field(q.cand_xc, q.cand_cap, q.n_cand, F, q.cand_rgb, q.cand_sigma, s);
+}
+
+extern "C" int ia_deform_query(const float *pts, int P, const int32_t *n_pts_dev, const float *voxel_J,
+                               const float *tfs, const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
+                               const ia_field *field, float *rgb, float *sigma, float *dmax, void *ws,
+                               size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_deform_query: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pts && ws, "ia_deform_query: null pointer");
+  if (ws_bytes < ia_query_workspace_bytes(P, n_init)) return ia_set_error(IA_ERR_WORKSPACE, "ia_deform_query: workspace too small");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_deform_query: bad field descriptor (%d)", rc);
+  WsCarver w(ws, ws_bytes);
+  QueryWs q = carve_query(w, P, n_init);
+  hipStream_t s = (hipStream_t)stream;
+  rc = query_impl(pts, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, F, q, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_candidate_max, dim3(ia_div_up(P, 256)), dim3(256), 0, s, q.cand_rgb, q.cand_sigma, q.pt_off,
+                     q.pt_cnt, P, n_pts_dev, n_init, 0.f, 1, rgb, sigma, dmax);
+  IA_LAUNCH_CHECK("k_candidate_max");
+  return IA_OK;
+}
+
+// ---- fused DensityGrid.initialize -------------------------------------------
+extern "C" size_t ia_density_init_workspace_bytes(int G, int n_init) {
+  const int n = G * G * G;
+  return ia_align((size_t)n * 12) + query_ws_bytes(n, n_init) + ia_occupancy_workspace_bytes(G) + 4096;
+}
+
+extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const float *aabb,
+                                    const float *voxel_J, const float *tfs, const int32_t *bone_ids, int n_init,
+                                    const ia_snarf_grid *grid, const ia_field *field, float *density,
+                                    uint32_t *occ_bits, uint8_t *occ_bool, void *ws, size_t ws_bytes,
+                                    void *stream) {
+  IA_CHECK_ARG(jitter && aabb && density && occ_bits && ws && iters >= 1, "ia_density_grid_init: bad arguments");
+  if (ws_bytes < ia_density_init_workspace_bytes(G, n_init)) return ia_set_error(IA_ERR_WORKSPACE, "ia_density_grid_init: workspace too small");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_density_grid_init: bad field descriptor (%d)", rc);
+  hipStream_t s = (hipStream_t)stream;
+  const int n = G * G * G;
+  WsCarver w(ws, ws_bytes);
+  float *pts = w.take<float>((size_t)n * 3);
+  QueryWs q = carve_query(w, n, n_init);
+  void *occ_ws = w.take<char>(ia_occupancy_workspace_bytes(G));
+  const dim3 grd(ia_div_up(n, 256)), blk(256);
+  hipLaunchKernelGGL(k_fill_f32, grd, blk, 0, s, density, 0.f, n);  // density_grid.py:98
+  for (int it = 0; it < iters; it++) {
+    hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, aabb, pts);
+    rc = query_impl(pts, n, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_candidate_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n,
+                       (const int32_t *)nullptr, n_init, 0.f, 1, (float *)nullptr, (float *)nullptr, density);
+  }
+  IA_LAUNCH_CHECK("density_grid_init");
+  return ia_occupancy_from_density(density, G, occ_bits, occ_bool, occ_ws, ia_occupancy_workspace_bytes(G), s);
+}
+
+// ---- fused render_test -------------------------------------------------------
+struct RenderWs {
+  RenderState *st; float *near_w, *step, *color, *depth, *nohit, *counter;
+  int32_t *alive_a, *alive_b, *ray_off, *ray_cnt; float *s_pts, *s_t; QueryWs q; int sample_cap;
+};
+static size_t render_ws_bytes(int R, int max_batch, int n_init) {
+  const size_t cap = (size_t)(R > max_batch ? R : max_batch);
+  return ia_align(sizeof(RenderState)) + 4 * ia_align((size_t)R * 4) + ia_align((size_t)R * 12) + ia_align((size_t)R * 4) +
+         4 * ia_align((size_t)R * 4) + ia_align(cap * 12) + ia_align(cap * 4) + query_ws_bytes((int)cap, n_init);
+}
+extern "C" size_t ia_render_workspace_bytes(int R, int max_batch, int n_init) {
+  return render_ws_bytes(R, max_batch, n_init) + 4096;
+}
+
+extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const float *near, const float *far, int R,
+                              const float *bg, const uint32_t *occ_bits, int G, const float *aabb,
+                              const float *voxel_J, const float *tfs, const int32_t *bone_ids, int n_init,
+                              const ia_snarf_grid *grid, const ia_field *field, int max_samples, int max_batch,
+                              int n_iters, int resume, float *rgb, float *depth, float *alpha, float *counter,
+                              int32_t *n_alive_out, void *ws, size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(R > 0 && max_samples > 0 && max_batch > 0 && n_iters >= 0, "ia_render_test: bad sizes");
+  IA_CHECK_ARG(rays_o && rays_d && near && far && occ_bits && aabb && voxel_J && tfs && rgb && depth && alpha && counter && ws,
+               "ia_render_test: null pointer");
+  if (ws_bytes < ia_render_workspace_bytes(R, max_batch, n_init)) return ia_set_error(IA_ERR_WORKSPACE, "ia_render_test: workspace too small");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_render_test: bad field descriptor (%d)", rc);
+  hipStream_t s = (hipStream_t)stream;
+  const int cap = R > max_batch ? R : max_batch;
+  WsCarver w(ws, ws_bytes);
+  RenderWs rw;
+  rw.st = w.take<RenderState>(1);
+  rw.near_w = w.take<float>(R); rw.step = w.take<float>(R); rw.depth = w.take<float>(R); rw.nohit = w.take<float>(R);
+  rw.color = w.take<float>((size_t)R * 3); rw.counter = w.take<float>(R);
+  rw.alive_a = w.take<int32_t>(R); rw.alive_b = w.take<int32_t>(R); rw.ray_off = w.take<int32_t>(R); rw.ray_cnt = w.take<int32_t>(R);
+  rw.s_pts = w.take<float>((size_t)cap * 3); rw.s_t = w.take<float>(cap);
+  rw.q = carve_query(w, cap, n_init);
+  rw.sample_cap = cap;
+  const dim3 blk(256), gR(ia_div_up(R, 256));
+  if (!resume) {
+    hipLaunchKernelGGL(k_render_init_state, dim3(1), dim3(1), 0, s, rw.st, R);
+    hipLaunchKernelGGL(k_render_init_rays, gR, blk, 0, s, R, near, far, rw.near_w, rw.step, rw.color, rw.depth,
+                       rw.nohit, rw.counter, rw.alive_a, max_samples);
+  }
+  // NOTE: alive lists ping-pong; with resume the parity of previously executed
+  // launches must be kept by the caller (n_iters even) -- enforced here.
+  IA_CHECK_ARG(n_iters % 2 == 0, "ia_render_test: n_iters must be even (alive list ping-pong)");
+  for (int it = 0; it < n_iters; it++) {
+    int32_t *cur = (it & 1) ? rw.alive_b : rw.alive_a;
+    int32_t *nxt = (it & 1) ? rw.alive_a : rw.alive_b;
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, s, rw.st, max_samples, max_batch);
+    // upper bounds for the launches: iteration 0 may have R alive rays, later
+    // ones never more than the first compaction leaves; keep R (idle waves exit).
+    hipLaunchKernelGGL(k_march_compact, gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, rw.st, occ_bits,
+                       G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap);
+    rc = query_impl(rw.s_pts, cap, &rw.st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_composite_compact, gR, blk, 0, s, cur, nxt, rw.st, rw.ray_off, rw.ray_cnt, rw.s_t, rw.step,
+                       rw.q.pt_off, rw.q.pt_cnt, rw.q.cand_rgb, rw.q.cand_sigma, n_init, rw.color, rw.depth, rw.nohit,
+                       0.01f);
+  }
+  hipLaunchKernelGGL(k_render_finalize, gR, blk, 0, s, R, rw.color, rw.depth, rw.nohit, rw.counter, bg, rw.st, rgb,
+                     depth, alpha, counter);
+  hipLaunchKernelGGL(k_render_report, dim3(1), dim3(1), 0, s, rw.st, max_samples, n_alive_out);
+  IA_LAUNCH_CHECK("ia_render_test");
+  return IA_OK;
+}
+
+extern "C" int ia_transform_rays_w2s(const float *rays_o, const float *rays_d, const float *w2s, int R, float *o_out,
+                                     float *d_out, float *near, float *far, void *stream) {
+  IA_CHECK_ARG(R >= 0, "ia_transform_rays_w2s: R < 0");
+  if (R == 0) return IA_OK;
+  IA_CHECK_ARG(rays_o && rays_d && w2s && o_out && d_out && near && far, "ia_transform_rays_w2s: null pointer");
+  hipLaunchKernelGGL(k_transform_rays, dim3(ia_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                     w2s, R, o_out, d_out, near, far);
+  IA_LAUNCH_CHECK("k_transform_rays");
+  return IA_OK;
+}

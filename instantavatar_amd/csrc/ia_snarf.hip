@@ -1,0 +1,447 @@
+// ia_snarf.hip -- Fast-SNARF deformer kernels for gfx950 (wave64).
+//
+//   k_smpl_tfs      a1/a2  SMPL joint chain -> bone transforms (one wave)
+//   k_precompute    a3     blended 3x4 transforms per skinning voxel, written
+//                          channel-LAST so a trilinear corner is 48 contiguous B
+//   k_search        a4+a5  Broyden root finding (one wave = 64 points x one init
+//                          bone, n_init waves per workgroup), duplicate filter and
+//                          ballot/prefix-sum compaction of the surviving roots
+//
+// Reference semantics: fast_snarf/cuda/precompute/precompute.cu:24-71,
+// fuse_kernel/fuse_cuda_kernel_fast.cu:23-55,62-108,110-248,252-413,
+// filter/filter.cu:10-55, deformers/smplx/lbs.py:295-401.
+#include "ia_common.h"
+
+// ---------------------------------------------------------------------------
+// a1/a2: rodrigues + kinematic chain + tfs = inv(A0) . A . inv(A_rest)
+// One workgroup of 64 threads; lanes 0..23 own one joint each.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mat4_mul(const float *a, const float *b, float *c) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = 0.f;
+      for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+      c[i * 4 + j] = s;
+    }
+}
+
+__global__ void k_smpl_tfs(const float *__restrict__ joints, const int32_t *__restrict__ parents,
+                           const float *__restrict__ pose, const float *__restrict__ transl,
+                           const float *__restrict__ tfs_inv_t, float *__restrict__ tfs,
+                           float *__restrict__ w2s_out, float *__restrict__ A_out) {
+  __shared__ float tm[24][16];     // local transforms, then chain
+  __shared__ float chain[24][16];
+  __shared__ float A[24][16];
+  __shared__ float w2s[16];
+  const int j = threadIdx.x;
+  if (j < 24) {
+    // batch_rodrigues (lbs.py:295-329)
+    float rx = pose[j * 3], ry = pose[j * 3 + 1], rz = pose[j * 3 + 2];
+    float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    float angle = sqrtf(ax * ax + ay * ay + az * az);
+    float dx = rx / angle, dy = ry / angle, dz = rz / angle;
+    float c = cosf(angle), s = sinf(angle);
+    float K[9] = {0, -dz, dy, dz, 0, -dx, -dy, dx, 0};
+    float KK[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        float v = 0.f;
+        for (int k = 0; k < 3; k++) v += K[a * 3 + k] * K[k * 3 + b];
+        KK[a * 3 + b] = v;
+      }
+    int p = parents[j];
+    float relx = joints[j * 3], rely = joints[j * 3 + 1], relz = joints[j * 3 + 2];
+    if (j > 0) { relx -= joints[p * 3]; rely -= joints[p * 3 + 1]; relz -= joints[p * 3 + 2]; }
+    float rel[3] = {relx, rely, relz};
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++)
+        tm[j][a * 4 + b] = (a == b ? 1.f : 0.f) + s * K[a * 3 + b] + (1.f - c) * KK[a * 3 + b];
+      tm[j][a * 4 + 3] = rel[a];
+    }
+    tm[j][12] = 0; tm[j][13] = 0; tm[j][14] = 0; tm[j][15] = 1;
+  }
+  __syncthreads();
+  if (j == 0) {  // sequential chain (lbs.py:384-389); 23 4x4 products
+    for (int k = 0; k < 16; k++) chain[0][k] = tm[0][k];
+    for (int i = 1; i < 24; i++) mat4_mul(chain[parents[i]], tm[i], chain[i]);
+  }
+  __syncthreads();
+  if (j < 24) {
+    // rel_transforms = transforms - pad(transforms @ [J,0])  (lbs.py:396-399)
+    float jx = joints[j * 3], jy = joints[j * 3 + 1], jz = joints[j * 3 + 2];
+    for (int a = 0; a < 4; a++) {
+      float t = chain[j][a * 4 + 0] * jx + chain[j][a * 4 + 1] * jy + chain[j][a * 4 + 2] * jz;
+      for (int b = 0; b < 3; b++) A[j][a * 4 + b] = chain[j][a * 4 + b];
+      A[j][a * 4 + 3] = chain[j][a * 4 + 3] - t;
+    }
+    // transl folded into A (body_models.py:353-357)
+    if (transl) { A[j][3] += transl[0]; A[j][7] += transl[1]; A[j][11] += transl[2]; }
+    if (A_out) for (int k = 0; k < 16; k++) A_out[j * 16 + k] = A[j][k];
+  }
+  __syncthreads();
+  if (j == 0) {
+    // w2s = inverse(A[0]) (snarf_deformer.py:83-84); general 4x4 inverse by
+    // Gauss-Jordan with partial pivoting (torch.inverse = LU, same result to
+    // rounding; A[0] is a rigid transform).
+    float m[4][8];
+    for (int a = 0; a < 4; a++)
+      for (int b = 0; b < 4; b++) { m[a][b] = A[0][a * 4 + b]; m[a][4 + b] = (a == b) ? 1.f : 0.f; }
+    for (int col = 0; col < 4; col++) {
+      int piv = col;
+      for (int r = col + 1; r < 4; r++) if (fabsf(m[r][col]) > fabsf(m[piv][col])) piv = r;
+      if (piv != col) for (int b = 0; b < 8; b++) { float t = m[col][b]; m[col][b] = m[piv][b]; m[piv][b] = t; }
+      float inv = 1.f / m[col][col];
+      for (int b = 0; b < 8; b++) m[col][b] *= inv;
+      for (int r = 0; r < 4; r++) if (r != col) {
+        float f = m[r][col];
+        for (int b = 0; b < 8; b++) m[r][b] -= f * m[col][b];
+      }
+    }
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) w2s[a * 4 + b] = m[a][4 + b];
+    if (w2s_out) for (int k = 0; k < 16; k++) w2s_out[k] = w2s[k];
+  }
+  __syncthreads();
+  if (j < 24) {  // tfs = w2s @ A @ tfs_inv_t  (snarf_deformer.py:86)
+    float t1[16], t2[16];
+    mat4_mul(w2s, A[j], t1);
+    mat4_mul(t1, tfs_inv_t + j * 16, t2);
+    for (int k = 0; k < 16; k++) tfs[j * 16 + k] = t2[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a3: precompute.  One thread per voxel.  voxel_w is read channel-major
+// (coalesced per joint plane); tfs is wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------
+__global__ void k_bbox_init(float *bbox) {
+  if (threadIdx.x < 3) bbox[threadIdx.x] = __int_as_float(0x7f800000);
+  else if (threadIdx.x < 6) bbox[threadIdx.x] = __int_as_float(0xff800000);
+}
+
+__global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ voxel_w,
+                                                    const float *__restrict__ tfs,
+                                                    float *__restrict__ voxel_J,
+                                                    float *__restrict__ voxel_d,
+                                                    float *__restrict__ bbox, SnarfGridDev g) {
+  const int n = g.D * g.H * g.W;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < n; index += gridDim.x * blockDim.x) {
+    const int hw = g.H * g.W;
+    const int idx_d = index / hw;
+    const int idx_h = index % hw / g.W;
+    const int idx_w = index % hw % g.W;
+    // precompute.cu:42-47
+    const float cx = (((float)idx_w) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];
+    const float cy = (((float)idx_h) / (g.H - 1) * 2 - 1) / g.scl[1] - g.off[1];
+    const float cz = (((float)idx_d) / (g.D - 1) * 2 - 1) / g.scl[2] - g.off[2];
+    float J[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) J[c] = 0.f;
+    // precompute.cu:51-59: J[c] accumulates over j in joint order
+#pragma unroll 4
+    for (int j = 0; j < 24; j++) {
+      const float w = voxel_w[(size_t)j * n + index];
+#pragma unroll
+      for (int c = 0; c < 12; c++) J[c] += w * tfs[j * 16 + c];
+    }
+    float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index * 12);
+    o[0] = make_float4(J[0], J[1], J[2], J[3]);
+    o[1] = make_float4(J[4], J[5], J[6], J[7]);
+    o[2] = make_float4(J[8], J[9], J[10], J[11]);
+    // precompute.cu:66-70
+#pragma unroll
+    for (int i0 = 0; i0 < 3; i0++) {
+      const float xi = J[i0 * 4 + 0] * cx + J[i0 * 4 + 1] * cy + J[i0 * 4 + 2] * cz + J[i0 * 4 + 3];
+      if (voxel_d) voxel_d[(size_t)i0 * n + index] = xi;
+      mn[i0] = fminf(mn[i0], xi);
+      mx[i0] = fmaxf(mx[i0], xi);
+    }
+  }
+  if (bbox) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float a = ia_wave_min(mn[c]), b = ia_wave_max(mx[c]);
+      if (ia_lane() == 0) { ia_atomic_min_f(bbox + c, a); ia_atomic_max_f(bbox + 3 + c, b); }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a4: Broyden.  Trilinear fetch of the 12-channel transform grid, zero padding,
+// align_corners=true (fuse_cuda_kernel_fast.cu:62-108,110-230).  J is
+// channel-last: a corner is 3 x float4.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float src_index(float coord, int size) {
+  coord = ((coord + 1.f) / 2) * (size - 1);
+  if (coord > (float)(INT_MAX - 1) || coord < (float)INT_MIN || !isfinite(coord)) return -100.0f;
+  return coord;
+}
+
+__device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const SnarfGridDev &g, float gx,
+                                        float gy, float gz, float *__restrict__ out) {
+  const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
+  const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+  const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  const float fx1 = x1 - ix, fx0 = ix - x0, fy1 = y1 - iy, fy0 = iy - y0, fz1 = z1 - iz, fz0 = iz - z0;
+  // weights in the reference order tnw,tne,tsw,tse,bnw,bne,bsw,bse (:188-195)
+  const float wgt[8] = {fx1 * fy1 * fz1, fx0 * fy1 * fz1, fx1 * fy0 * fz1, fx0 * fy0 * fz1,
+                        fx1 * fy1 * fz0, fx0 * fy1 * fz0, fx1 * fy0 * fz0, fx0 * fy0 * fz0};
+  const bool bx0 = x0 >= 0 && x0 < g.W, bx1 = x1 >= 0 && x1 < g.W;
+  const bool by0 = y0 >= 0 && y0 < g.H, by1 = y1 >= 0 && y1 < g.H;
+  const bool bz0 = z0 >= 0 && z0 < g.D, bz1 = z1 >= 0 && z1 < g.D;
+#pragma unroll
+  for (int c = 0; c < 12; c++) out[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int xx = (k & 1) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 4) ? z1 : z0;
+    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
+    if (in) {
+      const float4 *p = reinterpret_cast<const float4 *>(vJ + ((size_t)(zz * g.H + yy) * g.W + xx) * 12);
+      const float4 a = p[0], b = p[1], c = p[2];
+      const float w = wgt[k];
+      out[0] += a.x * w; out[1] += a.y * w; out[2] += a.z * w; out[3] += a.w * w;
+      out[4] += b.x * w; out[5] += b.y * w; out[6] += b.z * w; out[7] += b.w * w;
+      out[8] += c.x * w; out[9] += c.y * w; out[10] += c.z * w; out[11] += c.w * w;
+    }
+  }
+}
+
+// fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55)
+__device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float x2, float g0, float g1,
+                                            float g2) {
+  const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
+              J21 = Ji[7], J22 = Ji[8];
+  const float c0 = J00 * x0 + J10 * x1 + J20 * x2;
+  const float c1 = J01 * x0 + J11 * x1 + J21 * x2;
+  const float c2 = J02 * x0 + J12 * x1 + J22 * x2;
+  const float s = c0 * g0 + c1 * g1 + c2 * g2;
+  const float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
+  const float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
+  const float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
+  Ji[0] += c0 * (r0 + x0) / s; Ji[1] += c1 * (r0 + x0) / s; Ji[2] += c2 * (r0 + x0) / s;
+  Ji[3] += c0 * (r1 + x1) / s; Ji[4] += c1 * (r1 + x1) / s; Ji[5] += c2 * (r1 + x1) / s;
+  Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
+}
+
+struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
+
+// One (point, init) solve.  Returns validity; x_out = root, Ji_out = J_inv before
+// the last rank-1 update (what the reference stores, :383-391).
+__device__ __forceinline__ bool broyden_solve(const float *__restrict__ vJ, const float *__restrict__ T,
+                                              const SnarfGridDev &g, float t0, float t1, float t2,
+                                              float cvg2, float dvg2, float *x_out, float *Ji_out,
+                                              int &fetches) {
+  // :287-293  x0 = R^T (xd - t)
+  const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
+  float xl0 = ixd * T[0] + iyd * T[4] + izd * T[8];
+  float xl1 = ixd * T[1] + iyd * T[5] + izd * T[9];
+  float xl2 = ixd * T[2] + iyd * T[6] + izd * T[10];
+  float Jl[12];
+  fetch_J(vJ, g, g.scl[0] * (xl0 + g.off[0]), g.scl[1] * (xl1 + g.off[1]), g.scl[2] * (xl2 + g.off[2]), Jl);
+  float Ji[9] = {Jl[0], Jl[4], Jl[8], Jl[1], Jl[5], Jl[9], Jl[2], Jl[6], Jl[10]};  // transpose :302-311
+  float gx0 = Jl[0] * xl0 + Jl[1] * xl1 + Jl[2] * xl2 + Jl[3];
+  float gx1 = Jl[4] * xl0 + Jl[5] * xl1 + Jl[6] * xl2 + Jl[7];
+  float gx2 = Jl[8] * xl0 + Jl[9] * xl1 + Jl[10] * xl2 + Jl[11];
+  gx0 = gx0 - t0; gx1 = gx1 - t1; gx2 = gx2 - t2;
+  bool valid = false;
+  fetches = 1;
+  for (int i = 0; i < 10; i++) {
+    fetches++;
+    const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
+                J21 = Ji[7], J22 = Ji[8];
+    const float u0 = -J00 * gx0 + -J01 * gx1 + -J02 * gx2;
+    const float u1 = -J10 * gx0 + -J11 * gx1 + -J12 * gx2;
+    const float u2 = -J20 * gx0 + -J21 * gx1 + -J22 * gx2;
+    xl0 += u0; xl1 += u1; xl2 += u2;
+    const float ix = g.scl[0] * (xl0 + g.off[0]);
+    const float iy = g.scl[1] * (xl1 + g.off[1]);
+    const float iz = g.scl[2] * (xl2 + g.off[2]);
+    fetch_J(vJ, g, ix, iy, iz, Jl);
+    const float n0 = Jl[0] * xl0 + Jl[1] * xl1 + Jl[2] * xl2 + Jl[3] - t0;
+    const float n1 = Jl[4] * xl0 + Jl[5] * xl1 + Jl[6] * xl2 + Jl[7] - t1;
+    const float n2 = Jl[8] * xl0 + Jl[9] * xl1 + Jl[10] * xl2 + Jl[11] - t2;
+    const float norm = n0 * n0 + n1 * n1 + n2 * n2;
+    if (norm < cvg2) {
+      valid = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+      if (valid) {
+        x_out[0] = xl0; x_out[1] = xl1; x_out[2] = xl2;
+        if (Ji_out) {
+          Ji_out[0] = J00; Ji_out[1] = J01; Ji_out[2] = J02; Ji_out[3] = J10; Ji_out[4] = J11;
+          Ji_out[5] = J12; Ji_out[6] = J20; Ji_out[7] = J21; Ji_out[8] = J22;
+        }
+      }
+      break;
+    } else if (norm > dvg2) {
+      break;
+    }
+    jinv_update(Ji, u0, u1, u2, n0 - gx0, n1 - gx1, n2 - gx2);
+    gx0 = n0; gx1 = n1; gx2 = n2;
+  }
+  return valid;
+}
+
+// Workgroup = 64 points x n_init waves (blockDim = (64, n_init)).  Every wave
+// runs one init bone for 64 consecutive points, so the lanes of a wave start
+// from neighbouring canonical positions and gather neighbouring voxels.
+// MODE 0: dense outputs (reference layout).  MODE 1: compacted candidates.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_search(
+    const float *__restrict__ xd, int P, const int32_t *__restrict__ n_pts_dev,
+    const float *__restrict__ vJ, const float *__restrict__ tfs, BoneIds bones, int n_init, SnarfGridDev g,
+    float cvg2, float dvg2,
+    // MODE 0
+    float *__restrict__ xc, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ valid_raw,
+    float *__restrict__ J_inv,
+    // MODE 1
+    float *__restrict__ cand_xc, int cand_cap, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
+    int32_t *__restrict__ n_cand, unsigned long long *prof) {
+  __shared__ float s_x[IA_N_INIT_MAX][64][3];
+  __shared__ uint8_t s_valid[IA_N_INIT_MAX][64];
+  __shared__ uint8_t s_keep[IA_N_INIT_MAX][64];
+  __shared__ int s_base[64];
+  if (n_pts_dev) P = min(P, *n_pts_dev);
+  const int lane = threadIdx.x, init = threadIdx.y;
+  const int p0 = blockIdx.x * 64;
+  if (p0 >= P) return;  // uniform per workgroup
+  const int p = p0 + lane;
+  const bool live = p < P;
+  float x[3] = {0.f, 0.f, 0.f};
+  float Ji[9];
+  bool ok = false;
+  int fetches = 0;
+  if (live) {
+    const float t0 = xd[(size_t)p * 3], t1 = xd[(size_t)p * 3 + 1], t2 = xd[(size_t)p * 3 + 2];
+    const float *T = tfs + bones.id[init] * 16;
+    ok = broyden_solve(vJ, T, g, t0, t1, t2, cvg2, dvg2, x, (MODE == 0 && J_inv) ? Ji : nullptr, fetches);
+  }
+  if (prof) {  // bench-only accounting: solves and trilinear fetches per wave
+    int f = fetches, n = live ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); }
+    if (lane == 0) { atomicAdd(prof, (unsigned long long)n); atomicAdd(prof + 1, (unsigned long long)f); }
+  }
+  s_x[init][lane][0] = x[0]; s_x[init][lane][1] = x[1]; s_x[init][lane][2] = x[2];
+  s_valid[init][lane] = ok;
+  __syncthreads();
+  // a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4
+  bool keep = ok;
+  if (ok) {
+    for (int j = init + 1; j < n_init; j++) {
+      if (!s_valid[j][lane]) continue;
+      const float d0 = x[0] - s_x[j][lane][0], d1 = x[1] - s_x[j][lane][1], d2 = x[2] - s_x[j][lane][2];
+      const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+      if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
+    }
+  }
+  if (MODE == 0) {
+    if (live) {
+      const size_t o = (size_t)p * n_init + init;
+      // the reference leaves x zero unless converged AND inside the grid (:376-392)
+      xc[o * 3] = ok ? x[0] : 0.f; xc[o * 3 + 1] = ok ? x[1] : 0.f; xc[o * 3 + 2] = ok ? x[2] : 0.f;
+      valid_out[o] = keep;
+      if (valid_raw) valid_raw[o] = ok;
+      if (J_inv) for (int k = 0; k < 9; k++) J_inv[o * 9 + k] = ok ? Ji[k] : 0.f;
+    }
+    return;
+  }
+  s_keep[init][lane] = keep;
+  __syncthreads();
+  if (init == 0) {  // wave 0: per-point counts, wave scan, one atomic per wave
+    int cnt = 0;
+    for (int j = 0; j < n_init; j++) cnt += s_keep[j][lane];
+    int total;
+    const int excl = ia_wave_excl_scan(cnt, total);
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(n_cand, total);
+    base = __shfl(base, 0, 64);
+    s_base[lane] = base + excl;
+    if (live) { pt_off[p] = base + excl; pt_cnt[p] = (uint8_t)cnt; }
+  }
+  __syncthreads();
+  if (keep) {
+    int rank = 0;
+    for (int j = 0; j < init; j++) rank += s_keep[j][lane];
+    const int o = s_base[lane] + rank;
+    if (o < cand_cap) { cand_xc[(size_t)o * 3] = x[0]; cand_xc[(size_t)o * 3 + 1] = x[1]; cand_xc[(size_t)o * 3 + 2] = x[2]; }
+  }
+}
+
+__global__ void k_zero_i32(int32_t *p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int ia_smpl_tfs(const float *joints_rest, const int32_t *parents, const float *pose,
+                           const float *transl, const float *tfs_inv_t, float *tfs, float *w2s, float *A,
+                           void *stream) {
+  IA_CHECK_ARG(joints_rest && parents && pose && tfs_inv_t && tfs, "ia_smpl_tfs: null pointer");
+  hipLaunchKernelGGL(k_smpl_tfs, dim3(1), dim3(64), 0, (hipStream_t)stream, joints_rest, parents, pose,
+                     transl, tfs_inv_t, tfs, w2s, A);
+  IA_LAUNCH_CHECK("k_smpl_tfs");
+  return IA_OK;
+}
+
+extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxel_J, float *voxel_d,
+                             float *bbox, const ia_snarf_grid *grid, void *stream) {
+  IA_CHECK_ARG(voxel_w && tfs && voxel_J && grid, "ia_precompute: null pointer");
+  IA_CHECK_ARG(grid->D > 1 && grid->H > 1 && grid->W > 1, "ia_precompute: bad grid %d %d %d", grid->D, grid->H, grid->W);
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)grid->D * grid->H * grid->W;
+  if (bbox) { hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox); IA_LAUNCH_CHECK("k_bbox_init"); }
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_precompute, dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
+                     ia_make_grid_dev(grid));
+  IA_LAUNCH_CHECK("k_precompute");
+  return IA_OK;
+}
+
+static int make_bones(const int32_t *bone_ids, int n_init, BoneIds *b) {
+  if (!bone_ids || n_init < 1 || n_init > IA_N_INIT_MAX) return -1;
+  for (int i = 0; i < IA_N_INIT_MAX; i++) b->id[i] = i < n_init ? bone_ids[i] : 0;
+  for (int i = 0; i < n_init; i++) if (bone_ids[i] < 0 || bone_ids[i] >= IA_N_JOINTS) return -1;
+  return 0;
+}
+
+extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, const float *tfs,
+                               const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
+                               float cvg_thresh, float dvg_thresh, float *xc, uint8_t *valid,
+                               uint8_t *valid_raw, float *J_inv, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_snarf_search: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(xd && voxel_J && tfs && grid && xc && valid, "ia_snarf_search: null pointer");
+  BoneIds b;
+  IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search: bad bone ids / n_init=%d", n_init);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, 64)), dim3(64, n_init), 0,
+                     (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
+                     ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
+                     valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
+                     (int32_t *)nullptr, (unsigned long long *)nullptr);
+  IA_LAUNCH_CHECK("k_search<0>");
+  return IA_OK;
+}
+
+extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
+                                       const float *voxel_J, const float *tfs, const int32_t *bone_ids,
+                                       int n_init, const ia_snarf_grid *grid, float cvg_thresh,
+                                       float dvg_thresh, float *cand_xc, int32_t cand_cap, int32_t *pt_off,
+                                       uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_snarf_search_compact: P < 0");
+  IA_CHECK_ARG(n_cand, "ia_snarf_search_compact: n_cand is null");
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(xd && voxel_J && tfs && grid && cand_xc && pt_off && pt_cnt, "ia_snarf_search_compact: null pointer");
+  BoneIds b;
+  IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search_compact: bad bone ids / n_init=%d", n_init);
+  ia_prof_begin(IA_PROF_SEARCH, s);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), dim3(ia_div_up(P, 64)), dim3(64, n_init), 0, s, xd, P,
+                     n_pts_dev, voxel_J, tfs, b, n_init, ia_make_grid_dev(grid), cvg_thresh * cvg_thresh,
+                     dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr,
+                     (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand, ia_prof_units(IA_PROF_SEARCH));
+  ia_prof_end(IA_PROF_SEARCH, s);
+  IA_LAUNCH_CHECK("k_search<1>");
+  return IA_OK;
+}

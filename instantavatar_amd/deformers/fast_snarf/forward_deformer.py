@@ -1,0 +1,202 @@
+"""ForwardDeformer: voxelised-LBS correspondence search on the GPU.
+
+Host-side counterpart of the reference class of the same name
+(instant_avatar/deformers/fast_snarf/deformer_torch.py:22).  The reference
+JIT-builds three CUDA extensions at import time (deformer_torch.py:10-19);
+here the same operations are C-ABI calls into libinstantavatar_hip.so:
+
+    precompute(tfs)            -> ia_precompute          (deformer_torch.py:77-83)
+    broyden_cuda(...) + filter -> ia_snarf_search        (deformer_torch.py:100-116)
+
+`voxel_J` lives channel-LAST ([D,H,W,12], one trilinear corner = 48 contiguous
+bytes); `.voxel_J` gives the reference's [1,12,D,H,W] view of the same memory.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from .. import _opt
+from ... import _lib
+
+INIT_BONES = (0, 1, 2, 4, 5, 10, 11, 12, 15, 16, 17, 18, 19)  # deformer_torch.py:28
+KNN_K = 30
+SMOOTH_PASSES = 30
+SMOOTH_BLEND = 0.7
+
+
+class ForwardDeformer(torch.nn.Module):
+    def __init__(self, opt, **kwargs):
+        super().__init__()
+        self.opt = opt
+        self.init_bones = list(INIT_BONES)
+        self.global_scale = 1.2
+        self.version = _opt.get(opt, "version", 1)
+        self.device = None
+        self._bones_c = _lib.bone_array(self.init_bones)
+        self._grid_c = None
+        self._frame = None
+
+    # -- one-time voxelisation of the skinning weights (deformer_torch.py:130-186)
+    def switch_to_explicit(self, resolution=32, smpl_verts=None, smpl_weights=None, use_smpl=False):
+        if not use_smpl:
+            raise NotImplementedError("the path only uses SMPL-initialised weight voxels (use_smpl=True)")
+        dev = self.device if self.device is not None else smpl_verts.device
+        self.resolution = resolution
+        d, h, w = resolution // 4, resolution, resolution
+        self.ratio = h / d
+        verts = smpl_verts.to(dev).float()
+        lo, hi = verts.min(dim=1).values[0], verts.max(dim=1).values[0]
+        centre = (lo + hi) * 0.5
+        half = (hi - lo).max() / 2 * self.global_scale
+        ext = torch.stack([half, half, half / self.ratio])
+        self.bbox = torch.stack([centre - ext, centre + ext])
+        inv = torch.stack([1.0 / half, 1.0 / half, self.ratio / half])
+        for name, val in (("scale", half), ("offset", centre.view(1, 1, 3)),
+                          ("offset_kernel", -centre.view(1, 1, 3)), ("scale_kernel", inv.view(1, 1, 3))):
+            self.register_buffer(name, val.clone())
+        # voxel centres in (d,h,w) raster order; x<->w, y<->h, z<->d
+        zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, d, device=dev), torch.linspace(-1, 1, h, device=dev),
+                                    torch.linspace(-1, 1, w, device=dev), indexing="ij")
+        unit = torch.stack([xx, yy, zz], dim=-1).reshape(1, -1, 3)
+        grid_denorm = self.denormalize(unit)
+        vox = voxelise_skinning_weights(grid_denorm[0], verts[0], smpl_weights.to(dev).float()[0], (d, h, w))
+        self.register_buffer("lbs_voxel_final", vox[None].contiguous())
+        self.register_buffer("grid_denorm", grid_denorm)
+        self._grid_c = None
+
+    def normalize(self, x):
+        y = (x - self.offset) / self.scale
+        return torch.cat([y[..., :2], y[..., 2:] * self.ratio], dim=-1)
+
+    def denormalize(self, x):
+        y = torch.cat([x[..., :2], x[..., 2:] / self.ratio], dim=-1)
+        return y * self.scale + self.offset
+
+    def grid_desc(self):
+        if self._grid_c is None:
+            g = _lib.SnarfGrid()
+            g.D, g.H, g.W = self.resolution // 4, self.resolution, self.resolution
+            g.offset[:] = self.offset_kernel.reshape(3).float().cpu().tolist()  # init-time host read
+            g.scale[:] = self.scale_kernel.reshape(3).float().cpu().tolist()
+            self._grid_c = g
+        return self._grid_c
+
+    # -- per frame --------------------------------------------------------------
+    def precompute(self, tfs, want_voxel_d=True):
+        _lib.require_cuda(tfs, self.lbs_voxel_final)
+        assert tfs.shape[0] == 1, "skinning-voxel kernels are batch-1 (so are the reference's, SURVEY 2.1)"
+        d, h, w = self.resolution // 4, self.resolution, self.resolution
+        fr = self._frame
+        if fr is None or fr["J"].device != tfs.device or fr["J"].shape[0] != d:
+            mk = lambda *s: torch.empty(s, device=tfs.device, dtype=torch.float32)
+            fr = self._frame = dict(J=mk(d, h, w, 12), d=mk(1, 3, d, h, w), bbox=mk(6))
+        tfs_c = tfs.detach().float().contiguous()
+        _lib.check(_lib.lib().ia_precompute(_lib.ptr(self.lbs_voxel_final), _lib.ptr(tfs_c), _lib.ptr(fr["J"]),
+                                            _lib.ptr(fr["d"]) if want_voxel_d else None, _lib.ptr(fr["bbox"]),
+                                            C.byref(self.grid_desc()), _lib.stream()), "ia_precompute")
+        self.voxel_J_cl, self.voxel_d, self.bbox_deformed = fr["J"], fr["d"], fr["bbox"]
+
+    @property
+    def voxel_J(self):
+        return self.voxel_J_cl.permute(3, 0, 1, 2)[None]
+
+    def broyden_cuda(self, xd_tgt, voxel, voxel_J_cl, tfs, cvg_thresh=1e-5, dvg_thresh=1e-1, want_J_inv=True):
+        _lib.require_cuda(xd_tgt, voxel_J_cl, tfs)
+        b, n, _ = xd_tgt.shape
+        assert b == 1
+        k = len(self.init_bones)
+        mk = lambda shape, dt: torch.empty(shape, device=xd_tgt.device, dtype=dt)
+        xc, valid = mk((1, n, k, 3), torch.float32), mk((1, n, k), torch.uint8)
+        J_inv = mk((1, n, k, 3, 3), torch.float32) if want_J_inv else None
+        xd_c, tfs_c = xd_tgt.detach().float().contiguous(), tfs.detach().float().contiguous()
+        _lib.check(_lib.lib().ia_snarf_search(_lib.ptr(xd_c), n, _lib.ptr(voxel_J_cl), _lib.ptr(tfs_c), self._bones_c, k,
+                                              C.byref(self.grid_desc()), cvg_thresh, dvg_thresh, _lib.ptr(xc),
+                                              _lib.ptr(valid), None, _lib.ptr(J_inv), _lib.stream()), "ia_snarf_search")
+        return {"result": xc, "valid_ids": valid.bool(), "J_inv": J_inv}
+
+    def search(self, xd, cond, tfs, eval_mode=False, want_J_inv=True):
+        with torch.no_grad():
+            out = self.broyden_cuda(xd, self.voxel_d, self.voxel_J_cl, tfs, want_J_inv=want_J_inv)
+        return out["result"], out
+
+    def forward(self, xd, cond, tfs, eval_mode=False):
+        """Canonical correspondences of xd [1,N,3] -> ([1,N,I,3], others).
+        Training adds the implicit-differentiation term of deformer_torch.py:50-67
+        (version 1) or the closed-form inverse skinning of :68-75 (version 2)."""
+        need_grad = (not eval_mode) and tfs.requires_grad
+        xc, others = self.search(xd, cond, tfs, eval_mode=True, want_J_inv=need_grad or not eval_mode)
+        if eval_mode:
+            return xc, others
+        mask = others["valid_ids"]
+        if self.version != 1:
+            T = torch.einsum("pn,nij->pij", self.query_weights(xc, cond, mask=mask)[mask], tfs[0])
+            xd_rep = xd[..., None, :].expand(1, -1, len(self.init_bones), 3)[mask]
+            out = torch.zeros_like(xc)
+            out[mask] = ((xd_rep - T[:, :3, 3]).unsqueeze(-2) @ T[:, :3, :3]).squeeze(1)
+            return out, others
+        xc = xc.detach()  # invalid slots are already zero (ia_snarf_search writes them)
+        if need_grad:
+            # xc + 0 with d(xc) = -J_inv . d(skin(xc)): value unchanged, gradient to tfs
+            skinned = self.forward_skinning(xc, cond, tfs, mask=mask)
+            delta = skinned - skinned.detach()
+            xc = xc.clone()
+            xc[mask] = xc[mask] + bmv(-others["J_inv"][mask], delta.unsqueeze(-1)).squeeze(-1)
+        return xc, others
+
+    def forward_skinning(self, xc, cond, tfs, mask=None):
+        w = self.query_weights(xc, cond, mask=mask)
+        return skinning_mask(xc[mask], w[mask], tfs)
+
+    def query_weights(self, xc, cond=None, mask=None, mode="bilinear"):
+        lead = xc.shape[:-1]
+        g = self.normalize(xc.reshape(1, -1, 3))[:, :, None, None]
+        w = F.grid_sample(self.lbs_voxel_final, g, align_corners=True, mode=mode, padding_mode="border")
+        return w[0, :, :, 0, 0].T.reshape(*lead, -1)
+
+
+def skinning_mask(x, w, tfs, inverse=False):
+    """x [P,3], w [P,24], tfs [1,24,4,4] -> skinned points [P,3]."""
+    T = torch.einsum("pn,nij->pij", w, tfs[0])
+    return (T[:, :3, :3] @ x[:, :, None])[:, :, 0] + T[:, :3, 3]
+
+
+def bmv(m, v):
+    return m @ v
+
+
+def knn(query, verts, K, chunk=16384):
+    """Exact K nearest vertices per query point: (squared distances ascending, indices).
+    Stands in for pytorch3d's knn_points used at deformer_torch.py:227."""
+    out_d, out_i = [], []
+    v2 = (verts * verts).sum(-1)
+    for s in range(0, query.shape[0], chunk):
+        q = query[s:s + chunk]
+        approx = (q * q).sum(-1, keepdim=True) - 2.0 * (q @ verts.T) + v2
+        idx = approx.topk(K, dim=1, largest=False).indices
+        d2 = ((q[:, None] - verts[idx]) ** 2).sum(-1)      # exact distances of the selected K
+        d2, order = d2.sort(dim=1)
+        out_d.append(d2)
+        out_i.append(idx.gather(1, order))
+    return torch.cat(out_d), torch.cat(out_i)
+
+
+def _six_neighbour_mean(w):
+    c = w[:, 1:-1, 1:-1, 1:-1]
+    return (w[:, 2:, 1:-1, 1:-1] + w[:, :-2, 1:-1, 1:-1] + w[:, 1:-1, 2:, 1:-1] + w[:, 1:-1, :-2, 1:-1] +
+            w[:, 1:-1, 1:-1, 2:] + w[:, 1:-1, 1:-1, :-2]) / 6.0, c
+
+
+def voxelise_skinning_weights(points, verts, vert_weights, dims):
+    """deformer_torch.py:225-244: inverse-distance blend of the K=30 nearest SMPL
+    vertices' weights, then 30 rounds of 6-neighbour smoothing + renormalisation.
+    points [N,3] in (d,h,w) raster order -> [24,d,h,w]."""
+    d2, idx = knn(points, verts, KNN_K)
+    inv = 1.0 / d2.sqrt().clamp(1e-4, 1.0)
+    inv = inv / inv.sum(-1, keepdim=True)
+    vox = (inv[..., None] * vert_weights[idx]).sum(-2).T.reshape(24, *dims).contiguous()
+    for _ in range(SMOOTH_PASSES):
+        mean, centre = _six_neighbour_mean(vox)
+        vox[:, 1:-1, 1:-1, 1:-1] = (centre - mean) * SMOOTH_BLEND + mean
+        vox = vox / vox.sum(0, keepdim=True)
+    return vox

@@ -1,0 +1,232 @@
+"""SNARFDeformer plugin (drop-in for instant_avatar/deformers/snarf_deformer.py:33).
+
+Same constructor and methods as the reference class so that
+`confs/deformer/fast_snarf.yaml` only needs its `_target_` re-pointed:
+
+    SNARFDeformer(model_path, gender, opt)
+    .prepare_deformer(smpl_params)   .transform_rays_w2s(rays)
+    .get_bbox_deformed()             .__call__(pts, model, eval_mode)
+    attributes: bbox, vertices, w2s, tfs, initialized, body_model
+
+Per-frame work runs on the GPU without host synchronisation: the SMPL joint
+chain + tfs in `ia_smpl_tfs`, the voxel transforms in `ia_precompute`; the
+field query `deformer(pts, net)` is the fused `ia_deform_query` when `net` is
+an instantavatar_amd NeRFNGPNet, and the generic masked path (reference
+structure, snarf_deformer.py:127-159) for any other callable.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _opt
+from .. import _lib
+from .fast_snarf.forward_deformer import ForwardDeformer
+from .smplx import SMPL
+
+
+def get_predefined_rest_pose(cano_pose, device="cuda"):
+    """snarf_deformer.py:6-18"""
+    presets = {"da_pose": {2: torch.pi / 6, 5: -torch.pi / 6},
+               "a_pose": {2: 0.2, 5: -0.2, 47: -0.8, 50: 0.8}}
+    key = cano_pose.lower()
+    if key not in presets:
+        raise ValueError("Unknown cano_pose: {}".format(cano_pose))
+    pose = torch.zeros((1, 69), device=device)
+    for i, v in presets[key].items():
+        pose[:, i] = v
+    return pose
+
+
+def get_bbox_from_smpl(vs, factor=1.2):
+    """snarf_deformer.py:20-31: cube around the vertices, half-size = factor * max half extent."""
+    assert vs.shape[0] == 1
+    lo, hi = vs.min(dim=1).values, vs.max(dim=1).values
+    c = (hi + lo) / 2
+    s = ((hi - lo) / 2).max(dim=-1).values * factor
+    return torch.cat([c - s[:, None], c + s[:, None]], dim=0)
+
+
+def _abs_path(p):
+    try:
+        import hydra
+        return hydra.utils.to_absolute_path(p)
+    except Exception:
+        return os.path.abspath(p) if isinstance(p, str) else p
+
+
+class SNARFDeformer():
+    def __init__(self, model_path, gender, opt, body_model=None) -> None:
+        # body_model: optional pre-built SMPL (e.g. SMPL.from_dict(synthetic.make_body()))
+        self.body_model = body_model if body_model is not None else SMPL(_abs_path(model_path), gender=gender)
+        self.deformer = ForwardDeformer(opt)
+        self.initialized = False
+        self.opt = opt
+        self.dtype = torch.float32
+        self._ws = None
+
+    # ------------------------------------------------------------------ init
+    def initialize(self, betas, device):
+        cano = _opt.get(self.opt, "cano_pose", "A_pose")
+        if isinstance(cano, str):
+            body_pose_t = get_predefined_rest_pose(cano, device=device)
+        else:
+            body_pose_t = torch.zeros((1, 69), device=device)
+            for slot, val in zip((2, 5, 47, 50), cano):
+                body_pose_t[:, slot] = val
+        rest = self.body_model(betas=betas[:1], body_pose=body_pose_t)
+        self.tfs_inv_t = torch.inverse(rest.A.float().detach()).contiguous()
+        self.vs_template = rest.vertices
+        self.deformer.device = device
+        self.deformer.switch_to_explicit(resolution=_opt.get(self.opt, "resolution", 128),
+                                         smpl_verts=rest.vertices.float().detach(),
+                                         smpl_weights=self.body_model.lbs_weights.clone()[None].detach(),
+                                         use_smpl=True)
+        self.bbox = get_bbox_from_smpl(rest.vertices.detach())
+        # constants of the per-frame kernel
+        self._joints_rest = self.body_model.rest_joints(betas[:1].float()).contiguous()
+        self._parents32 = self.body_model.parents.to(torch.int32).contiguous()
+        self._frame_out = dict(tfs=torch.empty((1, 24, 4, 4), device=device), w2s=torch.empty((1, 4, 4), device=device),
+                               A=torch.empty((1, 24, 4, 4), device=device))
+
+    # ------------------------------------------------------------- per frame
+    def prepare_deformer(self, smpl_params):
+        """snarf_deformer.py:71-93.  betas are assumed constant per subject after
+        the first call (the reference re-evaluates blend shapes every frame; with
+        constant betas the rest joints are identical)."""
+        device = smpl_params["betas"].device
+        if self.body_model.v_template.device != device:
+            self.body_model = self.body_model.to(device)
+        if not self.initialized:
+            self.initialize(smpl_params["betas"], device)
+            self.initialized = True
+        go, bp, tr = smpl_params["global_orient"], smpl_params["body_pose"], smpl_params["transl"]
+        needs_grad = any(t.requires_grad for t in (go, bp, tr))
+        if needs_grad or not go.is_cuda:
+            # differentiable / CPU route (SMPL-parameter refinement, config 4): torch ops
+            out = self.body_model(betas=smpl_params["betas"], body_pose=bp, global_orient=go, transl=tr,
+                                  return_verts=False)
+            s2w = out.A[:, 0].float()
+            w2s = torch.inverse(s2w)
+            tfs = (w2s[:, None] @ out.A.float() @ self.tfs_inv_t).type(self.dtype)
+            A = out.A
+        else:
+            fo = self._frame_out
+            pose = torch.cat([go.reshape(1, 3), bp.reshape(1, 69)], dim=1).float().contiguous()
+            trc = tr.reshape(3).float().contiguous()
+            _lib.check(_lib.lib().ia_smpl_tfs(_lib.ptr(self._joints_rest), _lib.ptr(self._parents32), _lib.ptr(pose),
+                                              _lib.ptr(trc), _lib.ptr(self.tfs_inv_t), _lib.ptr(fo["tfs"]),
+                                              _lib.ptr(fo["w2s"]), _lib.ptr(fo["A"]), _lib.stream()), "ia_smpl_tfs")
+            tfs, w2s, A = fo["tfs"], fo["w2s"], fo["A"]
+        self.deformer.precompute(tfs)
+        self.w2s = w2s
+        self.tfs = tfs
+        self.A = A
+        self.smpl_params = smpl_params
+        self._vertices = None
+
+    @property
+    def vertices(self):
+        """posed vertices in the SMPL-root frame (snarf_deformer.py:89); only the
+        smpl_init occupancy bootstrap reads them, so they are computed lazily."""
+        if self._vertices is None:
+            p = self.smpl_params
+            out = self.body_model(betas=p["betas"], body_pose=p["body_pose"], global_orient=p["global_orient"],
+                                  transl=p["transl"])
+            w2s = self.w2s
+            self._vertices = (out.vertices @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]
+        return self._vertices
+
+    def transform_rays_w2s(self, rays):
+        """snarf_deformer.py:95-103 (in place on the Rays object)."""
+        o, d = rays.o, rays.d
+        if o.is_cuda and o.dtype == torch.float32 and not (o.requires_grad or self.w2s.requires_grad):
+            oc, dc = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+            R = oc.shape[0]
+            o2, d2 = torch.empty_like(oc), torch.empty_like(dc)
+            near, far = torch.empty(R, device=o.device), torch.empty(R, device=o.device)
+            w2s = self.w2s.reshape(4, 4).float().contiguous()
+            _lib.check(_lib.lib().ia_transform_rays_w2s(_lib.ptr(oc), _lib.ptr(dc), _lib.ptr(w2s), R, _lib.ptr(o2),
+                                                        _lib.ptr(d2), _lib.ptr(near), _lib.ptr(far), _lib.stream()),
+                       "ia_transform_rays_w2s")
+            rays.o, rays.d = o2.reshape(o.shape), d2.reshape(d.shape)
+            rays.near, rays.far = near.reshape(o.shape[:-1]), far.reshape(o.shape[:-1])
+            return
+        w2s = self.w2s
+        rays.o = (o @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]
+        rays.d = (d @ w2s[:, :3, :3].permute(0, 2, 1)).to(d)
+        dist = torch.norm(rays.o, dim=-1)
+        rays.near, rays.far = dist - 1, dist + 1
+
+    def get_bbox_deformed(self):
+        """snarf_deformer.py:105-107; the min/max were reduced inside ia_precompute."""
+        b = self.deformer.bbox_deformed
+        return [b[:3], b[3:]]
+
+    # ------------------------------------------------------------ field query
+    def deform(self, pts, eval_mode):
+        """snarf_deformer.py:109-125: canonical candidates [P,13,3] + validity [P,13]."""
+        point_size = pts.shape[0]
+        pts_cano, others = self.deformer.forward(pts.reshape(1, -1, 3), cond=None, tfs=self.tfs, eval_mode=eval_mode)
+        return pts_cano.reshape(point_size, -1, 3), others["valid_ids"].reshape(point_size, -1)
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _is_native_field(self, model):
+        from ..models.networks.ngp import NeRFNGPNet
+        return isinstance(model, NeRFNGPNet)
+
+    @torch.no_grad()
+    def deform_test(self, pts, model):
+        """snarf_deformer.py:127-141."""
+        pts = pts.type(self.dtype)
+        if self._is_native_field(model) and pts.is_cuda:
+            return self.query_fused(pts, model)
+        pts_cano_all, valid = self.deform(pts, eval_mode=True)
+        rgb_cano = torch.zeros_like(pts_cano_all).float()
+        sigma_cano = torch.zeros_like(pts_cano_all[..., 0]).float()
+        if valid.any():
+            r, s = model(pts_cano_all[valid], None)
+            sigma_cano[valid] = torch.nan_to_num(s.float(), 0, 0, 0)
+            rgb_cano[valid] = torch.nan_to_num(r.float(), 0, 0, 0)
+        sigma_cano, idx = torch.max(sigma_cano, dim=-1)
+        rgb_cano = torch.gather(rgb_cano, 1, idx[:, None, None].repeat(1, 1, 3))
+        return rgb_cano.reshape(-1, 3), sigma_cano.reshape(-1)
+
+    @torch.no_grad()
+    def query_fused(self, pts, net, dmax=None, want_rgb=True):
+        """deform_test as ONE C-ABI call: search + filter + compaction + field on the
+        surviving candidates + max over candidates; no host synchronisation."""
+        pts = pts.reshape(-1, 3).contiguous()
+        P = pts.shape[0]
+        k = len(self.deformer.init_bones)
+        L = _lib.lib()
+        ws = self._workspace(L.ia_query_workspace_bytes(P, k), pts.device)
+        rgb = torch.empty((P, 3), device=pts.device) if want_rgb else None
+        sigma = torch.empty(P, device=pts.device)
+        tfs = self.tfs.detach().float().contiguous()
+        _lib.check(L.ia_deform_query(_lib.ptr(pts), P, None, _lib.ptr(self.deformer.voxel_J_cl), _lib.ptr(tfs),
+                                     self.deformer._bones_c, k, C.byref(self.deformer.grid_desc()),
+                                     C.byref(net.field_desc()), _lib.ptr(rgb), _lib.ptr(sigma), _lib.ptr(dmax),
+                                     _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_deform_query")
+        return rgb, sigma
+
+    def deform_train(self, pts, model):
+        """snarf_deformer.py:143-159."""
+        pts_cano_all, valid = self.deform(pts.type(self.dtype), eval_mode=False)
+        rgb_cano = torch.zeros_like(pts_cano_all).float()
+        sigma_cano = -torch.ones_like(pts_cano_all[..., 0]).float() * 1e5
+        if valid.any():
+            r, s = model(pts_cano_all[valid], None)
+            rgb_cano[valid], sigma_cano[valid] = r.float(), s.float()
+        sigma_cano, idx = torch.max(sigma_cano, dim=-1)
+        rgb_cano = torch.gather(rgb_cano, 1, idx[:, None, None].repeat(1, 1, 3))
+        return rgb_cano.reshape(-1, 3), sigma_cano.reshape(-1)
+
+    def __call__(self, pts, model, eval_mode=True):
+        if eval_mode:
+            return self.deform_test(pts, model)
+        return self.deform_train(pts, model)

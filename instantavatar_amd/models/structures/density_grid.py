@@ -1,0 +1,148 @@
+"""DensityGrid plugin (drop-in for instant_avatar/models/structures/density_grid.py:17).
+
+64^3 boolean occupancy grid.  `initialize` (per rendered frame, density_grid.py:95-110)
+is ONE C-ABI call (`ia_density_grid_init`: 5 jittered probe sets -> fused deformer
+query -> running max -> 1-exp(-0.01 s) -> 3^3 max-pool -> relative threshold ->
+largest 26-connected component by union-find) when deformer/net are the native
+plugins, and the same sequence through the `deformer(pts, net)` closure +
+`ia_occupancy_from_density` otherwise.  `update` is the training-time EMA version
+(density_grid.py:46-92).
+
+Besides the reference's `density_field` (bool [G,G,G]) the grid keeps `occ_bits`,
+the bit-packed copy (32 KB) the marcher kernels read.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from ... import _lib
+
+
+def get_aabb(vs, scale=1.2):
+    lo, hi = vs.min(dim=0).values, vs.max(dim=0).values
+    c, s = (lo + hi) * 0.5, (hi - lo) * 0.5
+    return torch.stack([c - s * scale, c + s * scale], dim=0)
+
+
+def denormalize(coords, aabb):
+    return coords * (aabb[1] - aabb[0]) + aabb[0]
+
+
+class DensityGrid(torch.nn.Module):
+    def __init__(self, grid_size=64, aabb=None, smpl_init=False) -> None:
+        super().__init__()
+        self.grid_size = grid_size
+        G = grid_size
+        self.register_buffer("density_cached", torch.zeros(G, G, G))
+        self.register_buffer("density_field", torch.zeros(G, G, G, dtype=torch.bool))
+        self.register_buffer("occ_bits", torch.zeros(G * G * G // 32, dtype=torch.int32), persistent=False)
+        self.aabb = aabb
+        self.initialized = False
+        self.smpl_init = smpl_init
+        self._coords = None
+        self._ws = None
+        self._bits_version = None
+
+    # -- helpers ---------------------------------------------------------------
+    @property
+    def coords(self):
+        """cell corners in [0,1)^3, [G,G,G,3] (density_grid.py:22-26)."""
+        dev = self.density_cached.device
+        if self._coords is None or self._coords.device != dev:
+            idx = torch.arange(0, self.grid_size, device=dev)
+            self._coords = torch.stack(torch.meshgrid((idx, idx, idx), indexing="ij"), dim=-1) / self.grid_size
+        return self._coords
+
+    @property
+    def min_corner(self):
+        return self.aabb[0]
+
+    @property
+    def max_corner(self):
+        return self.aabb[1]
+
+    def aabb_tensor(self):
+        """contiguous [6] device tensor (min xyz, max xyz) for the kernels."""
+        a = self.aabb
+        if torch.is_tensor(a) and a.dim() == 2:
+            return a.reshape(6).float().contiguous()
+        return torch.cat([a[0].reshape(3), a[1].reshape(3)]).float().contiguous()
+
+    def _workspace(self, nbytes):
+        dev = self.density_cached.device
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def pack_bits(self):
+        """refresh occ_bits from density_field (after loading a checkpoint / update)."""
+        f8 = self.density_field.to(torch.uint8).contiguous()
+        _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(f8), self.grid_size, _lib.ptr(self.occ_bits), _lib.stream()),
+                   "ia_occupancy_pack")
+
+    def _postprocess(self, density):
+        """density [G,G,G] -> density_field + occ_bits (density_grid.py:104-110)."""
+        G = self.grid_size
+        L = _lib.lib()
+        ws = self._workspace(L.ia_occupancy_workspace_bytes(G))
+        out8 = torch.empty((G, G, G), dtype=torch.uint8, device=density.device)
+        _lib.check(L.ia_occupancy_from_density(_lib.ptr(density.contiguous()), G, _lib.ptr(self.occ_bits), _lib.ptr(out8),
+                                               _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_occupancy_from_density")
+        self.density_field = out8.bool()
+
+    # -- test-time grid (per frame) ----------------------------------------------
+    @torch.no_grad()
+    def initialize(self, deformer, net, iters=5, jitter=None):
+        """density_grid.py:95-110.  `jitter` ([iters,G^3,3] in [0,1)) may be injected
+        for reproducible tests; by default it is drawn like the reference does
+        (torch.rand_like, density_grid.py:100)."""
+        G = self.grid_size
+        bb = deformer.get_bbox_deformed()
+        self.aabb = torch.stack([bb[0], bb[1]])
+        dev = self.density_cached.device
+        if jitter is None:
+            jitter = torch.rand((iters, G * G * G, 3), device=dev)
+        jitter = jitter.to(dev).float().contiguous()
+        from ...deformers.snarf_deformer import SNARFDeformer
+        from ..networks.ngp import NeRFNGPNet
+        if isinstance(deformer, SNARFDeformer) and isinstance(net, NeRFNGPNet):
+            L = _lib.lib()
+            k = len(deformer.deformer.init_bones)
+            ws = self._workspace(L.ia_density_init_workspace_bytes(G, k))
+            density = torch.empty((G, G, G), device=dev)
+            out8 = torch.empty((G, G, G), dtype=torch.uint8, device=dev)
+            tfs = deformer.tfs.detach().float().contiguous()
+            _lib.check(L.ia_density_grid_init(_lib.ptr(jitter), iters, G, _lib.ptr(self.aabb_tensor()),
+                                              _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs),
+                                              deformer.deformer._bones_c, k, C.byref(deformer.deformer.grid_desc()),
+                                              C.byref(net.field_desc()), _lib.ptr(density), _lib.ptr(self.occ_bits),
+                                              _lib.ptr(out8), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                       "ia_density_grid_init")
+            self.density_field = out8.bool()
+            self.density_probe = density
+            return
+        density = torch.zeros_like(self.coords[..., 0])
+        for it in range(iters):
+            pts = denormalize(self.coords + jitter[it].reshape(G, G, G, 3) / G, self.aabb)
+            _, d = deformer(pts.reshape(-1, 3), net)
+            density = torch.maximum(density, d.reshape(density.shape))
+        self.density_probe = density
+        self._postprocess(density)
+
+    # -- training-time grid ---------------------------------------------------------
+    def update(self, deformer, net, step):
+        """density_grid.py:46-92 (smpl_init bootstrap, which needs kaolin, is out of scope)."""
+        G = self.grid_size
+        coords = denormalize(self.coords + torch.rand_like(self.coords) / G, self.aabb)
+        with torch.enable_grad():
+            _, density = deformer(coords.reshape(-1, 3), net, eval_mode=False)
+        density = density.clip(min=0).reshape(coords.shape[:-1])
+        old = self.density_field
+        if step < 500 and self.smpl_init:
+            raise NotImplementedError("smpl_init occupancy bootstrap (kaolin mesh distances) is out of scope")
+        self.density_cached = torch.maximum(self.density_cached * 0.8, density.detach())
+        self._postprocess(self.density_cached)
+        density = 1 - torch.exp(0.01 * -F.relu(density))
+        valid = self.density_field if step < 500 else old
+        return density, valid

@@ -1,0 +1,84 @@
+"""Lightning-free caller of the three plugins: mirrors what DNeRFModel does on the
+hot path (instant_avatar/models/DNeRF.py:61-97 `forward` / `render_image_fast`),
+so benchmarks, smoke tests and parity tests exercise the plugins exactly the way
+train.py / animate.py would, without pytorch_lightning / hydra (absent here).
+"""
+import numpy as np
+import torch
+
+from . import synthetic
+from .deformers.smplx import SMPL
+from .deformers.snarf_deformer import SNARFDeformer
+from .models.networks.ngp import NeRFNGPNet
+from .models.structures.utils import Rays
+from .renderers.raymarcher_acc import Raymarcher
+
+
+class AvatarModel(torch.nn.Module):
+    """net_coarse / deformer / renderer wiring of DNeRFModel.__init__ (DNeRF.py:22-28)."""
+
+    def __init__(self, deformer, net, renderer):
+        super().__init__()
+        self.net_coarse = net
+        self.deformer = deformer
+        self.renderer = renderer
+        self.global_step = 0
+
+    def forward(self, batch, eval_mode=True, noise=0):
+        """DNeRF.py:61-70"""
+        rays = Rays(o=batch["rays_o"], d=batch["rays_d"], near=batch["near"], far=batch["far"])
+        self.deformer.transform_rays_w2s(rays)
+        return self.renderer(rays, lambda x, _: self.deformer(x, self.net_coarse, eval_mode), eval_mode=eval_mode,
+                             noise=noise, bg_color=batch.get("bg_color", None))
+
+    @torch.no_grad()
+    def render_image_fast(self, batch, img_size, jitter=None):
+        """DNeRF.py:72-97: prepare deformer, rebuild the test occupancy grid, render."""
+        self.deformer.prepare_deformer(batch)
+        self.renderer.density_grid_test.initialize(self.deformer, self.net_coarse, jitter=jitter)
+        d = self.forward(batch, eval_mode=True)
+        rgb = d["rgb_coarse"].reshape(-1, *img_size, 3)
+        depth = d["depth_coarse"].reshape(-1, *img_size)
+        alpha = d["alpha_coarse"].reshape(-1, *img_size)
+        counter = d["counter_coarse"].reshape(-1, *img_size)
+        return rgb, depth, alpha, counter
+
+
+def build_synthetic_model(device, resolution=128, n_levels=16, max_samples=256, max_batch=291600, seed=42,
+                          cano_pose="A_pose"):
+    """Synthetic body + field wired into the three plugins.
+    Returns (model, body dict, field dict)."""
+    body = synthetic.make_body(seed)
+    smpl = SMPL.from_dict(body).to(device)
+    opt = dict(softmax_mode="hierarchical", resolution=resolution, cano_pose=cano_pose, precision=32)
+    deformer = SNARFDeformer(None, "neutral", opt, body_model=smpl)
+    betas = torch.zeros(1, 10, device=device)
+    deformer.initialize(betas, device)
+    deformer.initialized = True
+    # canonical joints for the synthetic density (posed with the canonical pose)
+    cano = smpl(betas=betas, body_pose=torch.as_tensor(synthetic.cano_pose(cano_pose), device=device)[None],
+                return_verts=False).joints[0].cpu().numpy()
+    fp = synthetic.make_field(cano, deformer.bbox.cpu().numpy(), seed=seed, n_levels=n_levels)
+    net = NeRFNGPNet(dict(center=[0, -0.3, 0], scale=[2.5, 2.5, 2.5]), n_levels=n_levels).to(device)
+    net.load_field_dict(fp)
+    net.initialize(deformer.bbox)
+    renderer = Raymarcher(max_samples, max_batch).to(device)
+    renderer.initialize(1)
+    model = AvatarModel(deformer, net, renderer).to(device)
+    return model, body, fp
+
+
+def make_batch(device, res, pose72, transl, betas=None):
+    """One animate.py batch (animate.py:60-80): camera rays + SMPL parameters."""
+    o, d = synthetic.make_camera_rays(res)
+    pose72 = np.asarray(pose72, np.float32)
+    transl = np.asarray(transl, np.float32)
+    dist = float(np.sqrt((transl ** 2).sum()))
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+    return {
+        "rays_o": t(o)[None], "rays_d": t(d)[None],
+        "betas": t(np.zeros((1, 10), np.float32) if betas is None else betas).reshape(1, 10),
+        "global_orient": t(pose72[:3])[None], "body_pose": t(pose72[3:])[None], "transl": t(transl)[None],
+        "near": torch.full((1, res * res), dist - 1, device=device),
+        "far": torch.full((1, res * res), dist + 1, device=device),
+    }

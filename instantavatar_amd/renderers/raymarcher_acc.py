@@ -1,0 +1,257 @@
+"""Raymarcher plugin (drop-in for instant_avatar/renderers/raymarcher_acc.py:49).
+
+    Raymarcher(MAX_SAMPLES, MAX_BATCH_SIZE, smpl_init=False)
+    .initialize(N_frames)  .idx  .density_grid_test  .density_grid_train
+    __call__(rays, model, eval_mode, noise, bg_color) -> dict(rgb_coarse, depth_coarse,
+        alpha_coarse, counter_coarse | weight_coarse)
+
+Two test-time routes with identical results:
+  * fused: `ia_render_test` -- the whole wave-front loop of raymarcher_acc.py:83-138
+    (march -> deformer query -> composite -> alive compaction, device-side N_step
+    schedule) enqueued without a single host sync.  Taken when the model closure
+    is recognised as (SNARFDeformer, NeRFNGPNet) or after `bind_fused(deformer, net)`;
+  * closure: the reference's loop structure with `ia_raymarch_test` /
+    `ia_composite_test` replacing the JIT CUDA extension (raymarcher_acc.py:13-16)
+    and an arbitrary `model(pts, _)` callable in between.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from ..models.structures.density_grid import DensityGrid
+
+
+def composite(sigma_vals, dists, thresh=0):
+    """raymarcher_acc.py:25-36 (training compositing, differentiable torch ops)."""
+    tau = torch.relu(sigma_vals) * dists
+    alpha = 1.0 - torch.exp(-tau)
+    if thresh > 0:
+        alpha = torch.where(alpha < thresh, torch.zeros_like(alpha), alpha)
+    trans = torch.cat([torch.ones_like(alpha[..., 0:1]), torch.cumprod(1 - alpha + 1e-10, dim=-1)], dim=-1)
+    return alpha * trans[..., :-1], trans
+
+
+def _find_native_pair(model):
+    """Recognise `lambda x, _: deformer(x, net, eval_mode)` (models/DNeRF.py:66-67)."""
+    from ..deformers.snarf_deformer import SNARFDeformer
+    from ..models.networks.ngp import NeRFNGPNet
+    pair = getattr(model, "ia_native_pair", None)
+    if pair is not None:
+        return pair
+    cells = getattr(model, "__closure__", None) or ()
+    objs = []
+    for c in cells:
+        try:
+            objs.append(c.cell_contents)
+        except ValueError:
+            pass
+    for o in list(objs):
+        objs.extend(v for v in (getattr(o, "deformer", None), getattr(o, "net_coarse", None)) if v is not None)
+    d = next((o for o in objs if isinstance(o, SNARFDeformer)), None)
+    n = next((o for o in objs if isinstance(o, NeRFNGPNet)), None)
+    return (d, n) if d is not None and n is not None else None
+
+
+class Raymarcher(torch.nn.Module):
+    def __init__(self, MAX_SAMPLES: int, MAX_BATCH_SIZE: int, smpl_init: bool = False) -> None:
+        super().__init__()
+        self.MAX_SAMPLES = MAX_SAMPLES
+        self.MAX_BATCH_SIZE = MAX_BATCH_SIZE
+        self.register_buffer("aabb", torch.tensor([[-1.25, -1.55, -1.25], [1.25, 0.95, 1.25]]).float(),
+                             persistent=False)
+        self.density_grid_test = DensityGrid(64)
+        self.smpl_init = smpl_init
+        self.idx = 0
+        self._fused = None
+        self._ws = None
+        self._iters_hint = 8     # loop iterations enqueued per call (even); adapted per frame
+        self._n_alive_host = None
+        self.last_iters = 0
+
+    def initialize(self, N):
+        n = N if self.smpl_init else 1
+        self.density_grid_train_all = torch.nn.ModuleList(
+            [DensityGrid(64, self.aabb, smpl_init=self.smpl_init) for _ in range(n)])
+        self.density_grid_train_all.to(self.aabb.device)
+        for g in self.density_grid_train_all:
+            g.aabb = self.aabb
+
+    def bind_fused(self, deformer, net):
+        self._fused = (deformer, net)
+
+    def __call__(self, rays, model, eval_mode=True, noise=0, bg_color=None):
+        if eval_mode:
+            return self.render_test(rays, model, bg_color)
+        return self.render_train(rays, model, noise, bg_color)
+
+    @property
+    def density_grid_train(self):
+        return self.density_grid_train_all[min(self.idx, len(self.density_grid_train_all) - 1)]
+
+    def _occ_desc(self, grid):
+        o = _lib.OccGrid()
+        o.G = grid.grid_size
+        a = grid.aabb_tensor().cpu().tolist()  # host read (closure path only)
+        o.aabb_min[:] = a[:3]
+        o.aabb_max[:] = a[3:]
+        return o
+
+    # ------------------------------------------------------------------ test
+    @torch.no_grad()
+    def render_test(self, rays, model, bg_color):
+        pair = self._fused or _find_native_pair(model)
+        if pair is not None and rays.o.is_cuda:
+            return self.render_test_fused(rays, pair[0], pair[1], bg_color)
+        return self.render_test_closure(rays, model, bg_color)
+
+    @torch.no_grad()
+    def render_test_fused(self, rays, deformer, net, bg_color=None, sync=True):
+        """raymarcher_acc.py:83-138 as `ia_render_test`.  The loop length is data
+        dependent; `_iters_hint` iterations are enqueued (idle ones cost a few
+        empty launches) and the device-side alive count is checked once at the
+        end -- if rays are still alive the call is resumed.  Results are
+        independent of the hint."""
+        L = _lib.lib()
+        dev = rays.o.device
+        o = rays.o.reshape(-1, 3).float().contiguous()
+        d = rays.d.reshape(-1, 3).float().contiguous()
+        near = rays.near.reshape(-1).float().contiguous()
+        far = rays.far.reshape(-1).float().contiguous()
+        R = o.shape[0]
+        grid = self.density_grid_test
+        k = len(deformer.deformer.init_bones)
+        need = L.ia_render_workspace_bytes(R, self.MAX_BATCH_SIZE, k)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            self._n_alive_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        rgb = torch.empty((R, 3), device=dev)
+        depth, alpha, counter = torch.empty(R, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+        bg = bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None
+        tfs = deformer.tfs.detach().float().contiguous()
+        aabb = grid.aabb_tensor()
+
+        def launch(n_iters, resume):
+            _lib.check(L.ia_render_test(_lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), R, _lib.ptr(bg),
+                                        _lib.ptr(grid.occ_bits), grid.grid_size, _lib.ptr(aabb),
+                                        _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs), deformer.deformer._bones_c,
+                                        k, C.byref(deformer.deformer.grid_desc()), C.byref(net.field_desc()),
+                                        self.MAX_SAMPLES, self.MAX_BATCH_SIZE, n_iters, resume, _lib.ptr(rgb),
+                                        _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(counter),
+                                        _lib.ptr(self._n_alive_dev), _lib.ptr(self._ws), self._ws.numel(),
+                                        _lib.stream()), "ia_render_test")
+
+        total = self._iters_hint
+        launch(total, 0)
+        if sync:
+            # one device->host read per frame (4 bytes) to validate the hint
+            while int(self._n_alive_dev.item()) > 0 and total < 2 * self.MAX_SAMPLES:
+                launch(4, 1)
+                total += 4
+                self._iters_hint = total
+        self.last_iters = total
+        return {
+            "rgb_coarse": rgb.reshape(rays.o.shape),
+            "depth_coarse": depth.reshape(rays.near.shape),
+            "alpha_coarse": alpha.reshape(rays.near.shape),
+            "counter_coarse": counter.reshape(rays.near.shape),
+        }
+
+    @torch.no_grad()
+    def render_test_closure(self, rays, model, bg_color):
+        """Reference loop structure (raymarcher_acc.py:83-138) around an arbitrary model."""
+        L = _lib.lib()
+        dev = rays.o.device
+        _lib.require_cuda(rays.o)
+        rays_o = rays.o.reshape(-1, 3).float().contiguous()
+        rays_d = rays.d.reshape(-1, 3).float().contiguous()
+        near = rays.near.reshape(-1).float().clone()
+        far = rays.far.reshape(-1).float().contiguous()
+        N = rays_o.shape[0]
+        color = torch.zeros(N, 3, device=dev)
+        depth = torch.zeros(N, device=dev)
+        no_hit = torch.ones(N, device=dev)
+        counter = torch.zeros_like(depth)
+        alive = torch.arange(N, device=dev)
+        step_size = ((far - near) / self.MAX_SAMPLES).contiguous()
+        grid = self.density_grid_test
+        occ = self._occ_desc(grid)
+        k = 0
+        while k < self.MAX_SAMPLES:
+            N_alive = len(alive)
+            if N_alive == 0:
+                break
+            N_step = max(min(self.MAX_BATCH_SIZE // N_alive, self.MAX_SAMPLES), 1)
+            pts = torch.empty((N_alive, N_step, 3), device=dev)
+            d_new = torch.empty((N_alive, N_step), device=dev)
+            z_new = torch.empty((N_alive, N_step), device=dev)
+            _lib.check(L.ia_raymarch_test(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(near), _lib.ptr(far),
+                                          _lib.ptr(alive), N_alive, _lib.ptr(grid.occ_bits), C.byref(occ),
+                                          _lib.ptr(step_size), N_step, _lib.ptr(pts), _lib.ptr(d_new), _lib.ptr(z_new),
+                                          _lib.stream()), "ia_raymarch_test")
+            mask = d_new > 0
+            counter[alive] += mask.sum(dim=-1)
+            rgb_vals = torch.zeros_like(pts)
+            sigma_vals = torch.zeros_like(d_new)
+            if mask.any():
+                r, s = model(pts[mask], None)
+                rgb_vals[mask], sigma_vals[mask] = r.float(), s.float()
+            _lib.check(L.ia_composite_test(_lib.ptr(rgb_vals), _lib.ptr(sigma_vals), _lib.ptr(d_new), _lib.ptr(z_new),
+                                           _lib.ptr(alive), N_alive, N_step, _lib.ptr(color), _lib.ptr(depth),
+                                           _lib.ptr(no_hit), 0.01, _lib.stream()), "ia_composite_test")
+            alive = alive[(no_hit[alive] > 1e-4) & (z_new[:, -1] > 0)]
+            k += N_step
+        bg = bg_color.reshape(-1, 3) if bg_color is not None else 1.0
+        color = color + no_hit[..., None] * bg
+        return {
+            "rgb_coarse": color.reshape(rays.o.shape),
+            "depth_coarse": depth.reshape(rays.near.shape),
+            "alpha_coarse": (1 - no_hit).reshape(rays.near.shape),
+            "counter_coarse": counter.reshape(rays.near.shape),
+        }
+
+    # ----------------------------------------------------------------- train
+    def render_train(self, rays, model, noise, bg_color):
+        """raymarcher_acc.py:140-186: fixed MAX_SAMPLES slots per ray from
+        `ia_raymarch_train`, jitter, masked field evaluation, cumprod compositing."""
+        L = _lib.lib()
+        _lib.require_cuda(rays.o)
+        rays_o = rays.o.reshape(-1, 3).float().contiguous()
+        rays_d = rays.d.reshape(-1, 3).float().contiguous()
+        near = rays.near.reshape(-1).float().contiguous()
+        far = rays.far.reshape(-1).float().contiguous()
+        N_step = self.MAX_SAMPLES
+        step_size = ((far - near) / N_step).contiguous()
+        grid = self.density_grid_train
+        occ = self._occ_desc(grid)
+        n_rays = rays_o.shape[0]
+        z_vals = torch.empty((n_rays, N_step), device=rays_o.device)
+        with torch.no_grad():
+            _lib.check(L.ia_raymarch_train(_lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), _lib.ptr(near.detach()),
+                                           _lib.ptr(far.detach()), n_rays, _lib.ptr(grid.occ_bits), C.byref(occ),
+                                           _lib.ptr(step_size.detach()), N_step, _lib.ptr(z_vals), _lib.stream()),
+                       "ia_raymarch_train")
+        mask = z_vals > 0
+        z_vals = z_vals + torch.rand_like(z_vals) * step_size[:, None]
+        pts = z_vals[..., None] * rays_d[:, None] + rays_o[:, None]
+        rgb_vals = torch.zeros_like(pts, dtype=torch.float32)
+        sigma_vals = -torch.ones_like(rgb_vals[..., 0], dtype=torch.float32) * 1e3
+        if mask.sum() > 0:
+            r, s = model(pts[mask], None)
+            rgb_vals = rgb_vals.masked_scatter(mask[..., None].expand_as(rgb_vals), r.float())
+            sigma_vals = sigma_vals.masked_scatter(mask, s.float())
+        if noise > 0:
+            sigma_vals = sigma_vals + noise * torch.randn_like(sigma_vals)
+        dists = torch.ones_like(sigma_vals) * step_size[:, None]
+        weights, transmittance = composite(sigma_vals.reshape(z_vals.shape), dists, thresh=0)
+        no_hit = transmittance[..., -1]
+        color = (weights[..., None] * rgb_vals.reshape(pts.shape)).sum(dim=-2)
+        bg = bg_color.reshape(-1, 3) if bg_color is not None else 1.0
+        color = color + no_hit[..., None] * bg
+        depth = (weights * z_vals).sum(dim=-1)
+        return {
+            "rgb_coarse": color.reshape(rays.o.shape),
+            "depth_coarse": depth.reshape(rays.near.shape),
+            "alpha_coarse": (weights.sum(-1)).reshape(rays.near.shape),
+            "weight_coarse": weights.reshape(*rays.near.shape, -1),
+        }

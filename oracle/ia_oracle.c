@@ -1,0 +1,741 @@
+/*
+ * ia_oracle.c -- CPU restatement of the InstantAvatar rendering hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under instantavatar_amd/ may import, link
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and only as the checker / reported baseline.
+ *
+ * Each function restates one reference kernel in plain C (fp32, same
+ * operation order as the cited lines).  Paths are relative to the reference
+ * tree (tijiang13/InstantAvatar @ 2024-08-07).
+ *
+ * PARITY PINNING
+ *  - In-tree kernels (precompute, broyden, filter, raymarch, composite): the
+ *    reference ships no tests / golden vectors.  They are
+ *    pinned against the reference kernels themselves, compiled unmodified for
+ *    gfx950 by oracle/build_ref.py into oracle/_ref/ and run on the GPU box
+ *    (tests/test_ref_pin.py); outputs frozen under tests/golden/.
+ *  - LBS: pinned against the reference's own python lbs.py (imported in the
+ *    build container, vectors frozen by tests/golden/make_lbs_golden.py).
+ *  - tiny-cuda-nn v1.6 (install.sh:6; NOT in the reference tree, not
+ *    installable here): HashGrid + FullyFusedMLP are restated from the
+ *    published algorithm.  ** parity unpinned ** for those two functions.
+ *    Documented deviation: MLP accumulation is fp32 with fp16 activations
+ *    between layers (tcnn uses tensor-core half accumulators, which are not
+ *    reproducible); the hash-grid interpolation follows tcnn exactly
+ *    (product in fp32, rounded to half, accumulated in half).
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+/* ------------------------------------------------------------------------ */
+/* IEEE binary16 helpers (round-to-nearest-even), no hardware dependency.    */
+/* ------------------------------------------------------------------------ */
+static inline float h2f(uint16_t h) {
+  uint32_t s = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu;
+  uint32_t m = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) {
+      u = s;
+    } else { /* subnormal */
+      int sh = 0;
+      while (!(m & 0x400u)) { m <<= 1; sh++; }
+      m &= 0x3ffu;
+      u = s | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+    }
+  } else if (e == 31) {
+    u = s | 0x7f800000u | (m << 13);
+  } else {
+    u = s | ((e + 127 - 15) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* double -> half, single rounding (RNE).  Used for float inputs too (a float
+ * is exactly a double).                                                      */
+static inline uint16_t d2h(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  uint16_t s = (uint16_t)((u >> 48) & 0x8000u);
+  int64_t e = (int64_t)((u >> 52) & 0x7ff);
+  uint64_t m = u & 0xfffffffffffffull;
+  if (e == 0x7ff) return (uint16_t)(s | 0x7c00u | (m ? 0x200u : 0));
+  if (e == 0) return s; /* double subnormal/zero -> 0 */
+  int64_t he = e - 1023 + 15;
+  if (he >= 31) return (uint16_t)(s | 0x7c00u);
+  uint64_t mant = m | (1ull << 52); /* 53 bits */
+  int shift;
+  if (he <= 0) {
+    if (he < -11) return s;
+    shift = 42 + (int)(1 - he); /* subnormal half */
+    he = 0;
+  } else {
+    shift = 42;
+  }
+  uint64_t q = mant >> shift;
+  uint64_t rem = mant & ((1ull << shift) - 1);
+  uint64_t half = 1ull << (shift - 1);
+  if (rem > half || (rem == half && (q & 1))) q++;
+  /* q may carry into the exponent; encoding handles it naturally */
+  uint32_t out;
+  if (he == 0) out = (uint32_t)q;               /* subnormal (q<=0x400) */
+  else out = (uint32_t)(((uint64_t)(he - 1) << 10) + q); /* q has bit10 */
+  if (out >= 0x7c00u) out = 0x7c00u;
+  return (uint16_t)(s | out);
+}
+static inline uint16_t f2h(float f) { return d2h((double)f); }
+/* half + half with a single rounding (the exact sum fits a double).         */
+static inline uint16_t hadd(uint16_t a, uint16_t b) {
+  return d2h((double)h2f(a) + (double)h2f(b));
+}
+
+void orc_f32_to_f16(const float *x, uint16_t *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = f2h(x[i]);
+}
+void orc_f16_to_f32(const uint16_t *x, float *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = h2f(x[i]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a3  precompute_kernel  (fast_snarf/cuda/precompute/precompute.cu:33-70)   */
+/* voxel_w [24,D,H,W], tfs [24,4,4] -> voxel_J [12,D,H,W], voxel_d [3,D,H,W] */
+/* ------------------------------------------------------------------------ */
+void orc_precompute(const float *voxel_w, const float *tfs, float *voxel_J,
+                    float *voxel_d, const float *offset, const float *scale,
+                    int d, int h, int w) {
+  const long n = (long)d * h * w;
+#pragma omp parallel for schedule(static)
+  for (long index = 0; index < n; index++) {
+    int idx_d = (int)(index / ((long)h * w));
+    int idx_h = (int)(index % ((long)h * w) / w);
+    int idx_w = (int)(index % ((long)h * w) % w);
+    /* precompute.cu:42-47 */
+    float coord_x = (((float)idx_w) / (w - 1) * 2 - 1) / scale[0] - offset[0];
+    float coord_y = (((float)idx_h) / (h - 1) * 2 - 1) / scale[1] - offset[1];
+    float coord_z = (((float)idx_d) / (d - 1) * 2 - 1) / scale[2] - offset[2];
+    float J[12];
+    /* precompute.cu:51-59 */
+    for (int i0 = 0; i0 < 3; i0++)
+      for (int i1 = 0; i1 < 4; i1++) {
+        J[i0 * 4 + i1] = 0;
+        for (int j = 0; j < 24; j++)
+          J[i0 * 4 + i1] += voxel_w[(long)j * n + index] * tfs[j * 16 + i0 * 4 + i1];
+      }
+    for (int c = 0; c < 12; c++) voxel_J[(long)c * n + index] = J[c];
+    /* precompute.cu:66-70 */
+    for (int i0 = 0; i0 < 3; i0++) {
+      float xi = J[i0 * 4 + 0] * coord_x + J[i0 * 4 + 1] * coord_y +
+                 J[i0 * 4 + 2] * coord_z + J[i0 * 4 + 3];
+      voxel_d[(long)i0 * n + index] = xi;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* grid_sampler_3d, bilinear branch, zero padding, align_corners = true      */
+/* (fuse_cuda_kernel_fast.cu:62-108, 110-230).  input [C=12,D,H,W].          */
+/* ------------------------------------------------------------------------ */
+static inline float orc_source_index(float coord, int size) {
+  /* grid_sampler_unnormalize, align_corners: :65-67 */
+  coord = ((coord + 1.f) / 2) * (size - 1);
+  /* compute_coordinates -> safe_downgrade_to_int_range (:82-99); the clip is
+   * commented out at :97 (zero padding).                                     */
+  if (coord > (float)(INT_MAX - 1) || coord < (float)INT_MIN ||
+      !isfinite((double)coord))
+    return -100.0f;
+  return coord;
+}
+static inline int orc_in3(int d, int h, int w, int D, int H, int W) {
+  return d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+}
+static void orc_grid_sample12(const float *inp, int D, int H, int W, float gx,
+                              float gy, float gz, float *out) {
+  float ix = orc_source_index(gx, W);
+  float iy = orc_source_index(gy, H);
+  float iz = orc_source_index(gz, D);
+  int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+  int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  /* :188-195 ("surfaces to each neighbour") */
+  float tnw = (x1 - ix) * (y1 - iy) * (z1 - iz);
+  float tne = (ix - x0) * (y1 - iy) * (z1 - iz);
+  float tsw = (x1 - ix) * (iy - y0) * (z1 - iz);
+  float tse = (ix - x0) * (iy - y0) * (z1 - iz);
+  float bnw = (x1 - ix) * (y1 - iy) * (iz - z0);
+  float bne = (ix - x0) * (y1 - iy) * (iz - z0);
+  float bsw = (x1 - ix) * (iy - y0) * (iz - z0);
+  float bse = (ix - x0) * (iy - y0) * (iz - z0);
+  const long n = (long)D * H * W;
+  for (int c = 0; c < 12; c++) {
+    const float *p = inp + (long)c * n;
+    float o = 0;
+#define AT(z, y, x) p[((long)(z)*H + (y)) * W + (x)]
+    if (orc_in3(z0, y0, x0, D, H, W)) o += AT(z0, y0, x0) * tnw;
+    if (orc_in3(z0, y0, x1, D, H, W)) o += AT(z0, y0, x1) * tne;
+    if (orc_in3(z0, y1, x0, D, H, W)) o += AT(z0, y1, x0) * tsw;
+    if (orc_in3(z0, y1, x1, D, H, W)) o += AT(z0, y1, x1) * tse;
+    if (orc_in3(z1, y0, x0, D, H, W)) o += AT(z1, y0, x0) * bnw;
+    if (orc_in3(z1, y0, x1, D, H, W)) o += AT(z1, y0, x1) * bne;
+    if (orc_in3(z1, y1, x0, D, H, W)) o += AT(z1, y1, x0) * bsw;
+    if (orc_in3(z1, y1, x1, D, H, W)) o += AT(z1, y1, x1) * bse;
+#undef AT
+    out[c] = o;
+  }
+}
+
+/* fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55) */
+static void orc_jinv_update(float *Ji, float x0, float x1, float x2, float g0,
+                            float g1, float g2) {
+  float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2];
+  float J10 = Ji[3], J11 = Ji[4], J12 = Ji[5];
+  float J20 = Ji[6], J21 = Ji[7], J22 = Ji[8];
+  float c0 = J00 * x0 + J10 * x1 + J20 * x2;
+  float c1 = J01 * x0 + J11 * x1 + J21 * x2;
+  float c2 = J02 * x0 + J12 * x1 + J22 * x2;
+  float s = c0 * g0 + c1 * g1 + c2 * g2;
+  float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
+  float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
+  float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
+  Ji[0] += c0 * (r0 + x0) / s;
+  Ji[1] += c1 * (r0 + x0) / s;
+  Ji[2] += c2 * (r0 + x0) / s;
+  Ji[3] += c0 * (r1 + x1) / s;
+  Ji[4] += c1 * (r1 + x1) / s;
+  Ji[5] += c2 * (r1 + x1) / s;
+  Ji[6] += c0 * (r2 + x2) / s;
+  Ji[7] += c1 * (r2 + x2) / s;
+  Ji[8] += c2 * (r2 + x2) / s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a4  broyden_kernel (fuse_cuda_kernel_fast.cu:252-413).                    */
+/* xd [P,3]; voxel_J [12,D,H,W]; tfs [24,4,4]; bone_ids [n_init].            */
+/* x [P,n_init,3], J_inv [P,n_init,3,3], is_valid [P,n_init]: caller-zeroed  */
+/* in the reference (deformer_torch.py:104-106); zeroed here.                */
+/* iters_out (optional) [P,n_init]: number of grid fetches, for traffic      */
+/* accounting in bench/DESIGN.                                               */
+/* ------------------------------------------------------------------------ */
+void orc_broyden(const float *xd, long P, const float *voxel_J, int D, int H,
+                 int W, const float *tfs, const int *bone_ids, int n_init,
+                 const float *offset, const float *scale, float cvg, float dvg,
+                 float *x, float *J_inv, uint8_t *is_valid, uint8_t *iters_out) {
+  memset(x, 0, sizeof(float) * P * n_init * 3);
+  if (J_inv) memset(J_inv, 0, sizeof(float) * P * n_init * 9);
+  memset(is_valid, 0, (size_t)P * n_init);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (long index = 0; index < P * n_init; index++) {
+    long i_point = index / n_init;
+    int i_init = (int)(index % n_init);
+    float gx[3], gxn[3] = {0, 0, 0};
+    float t0 = xd[i_point * 3 + 0], t1 = xd[i_point * 3 + 1], t2 = xd[i_point * 3 + 2];
+    const float *T = tfs + bone_ids[i_init] * 16;
+    /* :287-293  x0 = R^T (xd - t) */
+    float ixd = t0 - T[0 * 4 + 3], iyd = t1 - T[1 * 4 + 3], izd = t2 - T[2 * 4 + 3];
+    float xl[3];
+    xl[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
+    xl[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
+    xl[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+    float Jl[12];
+    int fetches = 1;
+    /* :295-300 */
+    orc_grid_sample12(voxel_J, D, H, W, scale[0] * (xl[0] + offset[0]),
+                      scale[1] * (xl[1] + offset[1]),
+                      scale[2] * (xl[2] + offset[2]), Jl);
+    /* :302-311  J_inv0 = (J_3x3)^T */
+    float Ji[9];
+    Ji[0] = Jl[0]; Ji[3] = Jl[1]; Ji[6] = Jl[2];
+    Ji[1] = Jl[4]; Ji[4] = Jl[5]; Ji[7] = Jl[6];
+    Ji[2] = Jl[8]; Ji[5] = Jl[9]; Ji[8] = Jl[10];
+    for (int i = 0; i < 10; i++) {
+      float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2];
+      float J10 = Ji[3], J11 = Ji[4], J12 = Ji[5];
+      float J20 = Ji[6], J21 = Ji[7], J22 = Ji[8];
+      if (i == 0) { /* :325-332 */
+        gx[0] = Jl[0] * xl[0] + Jl[1] * xl[1] + Jl[2] * xl[2] + Jl[3];
+        gx[1] = Jl[4] * xl[0] + Jl[5] * xl[1] + Jl[6] * xl[2] + Jl[7];
+        gx[2] = Jl[8] * xl[0] + Jl[9] * xl[1] + Jl[10] * xl[2] + Jl[11];
+        gx[0] = gx[0] - t0; gx[1] = gx[1] - t1; gx[2] = gx[2] - t2;
+      } else {
+        gx[0] = gxn[0]; gx[1] = gxn[1]; gx[2] = gxn[2];
+      }
+      /* :340-347 */
+      float u0 = -J00 * gx[0] + -J01 * gx[1] + -J02 * gx[2];
+      float u1 = -J10 * gx[0] + -J11 * gx[1] + -J12 * gx[2];
+      float u2 = -J20 * gx[0] + -J21 * gx[1] + -J22 * gx[2];
+      xl[0] += u0; xl[1] += u1; xl[2] += u2;
+      float ix = scale[0] * (xl[0] + offset[0]);
+      float iy = scale[1] * (xl[1] + offset[1]);
+      float iz = scale[2] * (xl[2] + offset[2]);
+      orc_grid_sample12(voxel_J, D, H, W, ix, iy, iz, Jl);
+      fetches++;
+      /* :356-364 */
+      gxn[0] = Jl[0] * xl[0] + Jl[1] * xl[1] + Jl[2] * xl[2] + Jl[3] - t0;
+      gxn[1] = Jl[4] * xl[0] + Jl[5] * xl[1] + Jl[6] * xl[2] + Jl[7] - t1;
+      gxn[2] = Jl[8] * xl[0] + Jl[9] * xl[1] + Jl[10] * xl[2] + Jl[11] - t2;
+      float norm_gx = gxn[0] * gxn[0] + gxn[1] * gxn[1] + gxn[2] * gxn[2];
+      if (norm_gx < cvg * cvg) { /* :370-392 */
+        int ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+        is_valid[index] = (uint8_t)ok;
+        if (ok) {
+          x[index * 3 + 0] = xl[0]; x[index * 3 + 1] = xl[1]; x[index * 3 + 2] = xl[2];
+          if (J_inv) {
+            float *o = J_inv + index * 9;
+            o[0] = J00; o[1] = J01; o[2] = J02; o[3] = J10; o[4] = J11;
+            o[5] = J12; o[6] = J20; o[7] = J21; o[8] = J22;
+          }
+        }
+        break;
+      } else if (norm_gx > dvg * dvg) { /* :395-398 */
+        is_valid[index] = 0;
+        break;
+      }
+      /* :400-411 */
+      orc_jinv_update(Ji, u0, u1, u2, gxn[0] - gx[0], gxn[1] - gx[1], gxn[2] - gx[2]);
+    }
+    if (iters_out) iters_out[index] = (uint8_t)fetches;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a5  filter (fast_snarf/cuda/filter/filter.cu:19-53), B = 1                */
+/* ------------------------------------------------------------------------ */
+void orc_filter(const float *x, const uint8_t *mask, long P, int n_init,
+                uint8_t *out) {
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < P; p++) {
+    const float *xp = x + p * n_init * 3;
+    const uint8_t *mp = mask + p * n_init;
+    for (int i = 0; i < n_init; i++) {
+      if (!mp[i]) { out[p * n_init + i] = 0; continue; }
+      float xi0 = xp[i * 3], xi1 = xp[i * 3 + 1], xi2 = xp[i * 3 + 2];
+      int flag = 1;
+      for (int j = i + 1; j < n_init; j++) {
+        if (!mp[j]) continue;
+        float d0 = xi0 - xp[j * 3], d1 = xi1 - xp[j * 3 + 1], d2 = xi2 - xp[j * 3 + 2];
+        float dist = d0 * d0 + d1 * d1 + d2 * d2;
+        /* filter.cu:44 compares against the double constant 0.0001*0.0001 */
+        if ((double)dist < 0.0001 * 0.0001) { flag = 0; break; }
+      }
+      out[p * n_init + i] = (uint8_t)flag;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a10  tcnn v1.6 HashGrid (restated; call site models/networks/ngp.py:27-37)*/
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int n_levels;
+  float scale[16];
+  uint32_t res[16];
+  uint32_t offset[17];
+} orc_hash_desc;
+
+/* tcnn grid.h: grid_scale(), grid_resolution(), GridEncodingTemplated ctor. */
+void orc_hash_desc_init(orc_hash_desc *o, int n_levels, int log2_hashmap_size,
+                        int base_resolution, float per_level_scale) {
+  float l2 = log2f(per_level_scale);
+  uint32_t off = 0;
+  o->n_levels = n_levels;
+  for (int l = 0; l < n_levels; l++) {
+    float s = exp2f((float)l * l2) * (float)base_resolution - 1.0f;
+    uint32_t r = (uint32_t)ceilf(s) + 1;
+    uint32_t max_params = 0xffffffffu / 2;
+    uint32_t n = powf((float)r, 3.f) > (float)max_params ? max_params : r * r * r;
+    n = (n + 7u) / 8u * 8u;
+    if (n > (1u << log2_hashmap_size)) n = 1u << log2_hashmap_size;
+    o->scale[l] = s;
+    o->res[l] = r;
+    o->offset[l] = off;
+    off += n;
+  }
+  o->offset[n_levels] = off;
+}
+
+static inline uint32_t orc_grid_index(uint32_t hashmap_size, uint32_t res,
+                                      const uint32_t p[3]) {
+  /* tcnn grid_index<3, CoherentPrime> */
+  uint32_t stride = 1, index = 0;
+  for (int dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
+    index += p[dim] * stride;
+    stride *= res;
+  }
+  if (hashmap_size < stride)
+    index = (p[0] * 1u) ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u);
+  return index % hashmap_size;
+}
+
+/* xn: already normalised to [0,1]^3.  feat: fp16 [32] (level-major).        */
+static void orc_hash_encode1(const orc_hash_desc *hd, const uint16_t *table,
+                             const float xn[3], uint16_t *feat) {
+  for (int l = 0; l < hd->n_levels; l++) {
+    const uint16_t *grid = table + (size_t)hd->offset[l] * 2;
+    uint32_t hsize = hd->offset[l + 1] - hd->offset[l];
+    float scale = hd->scale[l];
+    uint32_t res = hd->res[l];
+    float pos[3];
+    uint32_t pg[3];
+    for (int d = 0; d < 3; d++) { /* pos_fract */
+      pos[d] = xn[d] * scale + 0.5f;
+      float t = floorf(pos[d]);
+      pg[d] = (uint32_t)(int)t;
+      pos[d] -= t;
+    }
+    uint16_t r0 = 0, r1 = 0; /* half accumulators */
+    for (uint32_t idx = 0; idx < 8; idx++) {
+      float wgt = 1;
+      uint32_t pl[3];
+      for (int d = 0; d < 3; d++) {
+        if ((idx & (1u << d)) == 0) { wgt *= 1 - pos[d]; pl[d] = pg[d]; }
+        else { wgt *= pos[d]; pl[d] = pg[d] + 1; }
+      }
+      uint32_t gi = orc_grid_index(hsize, res, pl) * 2;
+      r0 = hadd(r0, f2h(wgt * h2f(grid[gi])));
+      r1 = hadd(r1, f2h(wgt * h2f(grid[gi + 1])));
+    }
+    feat[l * 2] = r0;
+    feat[l * 2 + 1] = r1;
+  }
+}
+
+typedef struct {
+  float center[3];
+  float scale[3];
+  orc_hash_desc hash;
+  const uint16_t *table;
+  const uint16_t *sig_w1, *sig_w2, *col_w1, *col_w2, *col_w3;
+} orc_field;
+
+static inline void orc_normalise(const orc_field *f, const float *x, float *xn) {
+  /* ngp.py:75-77: (x - center)/scale + 0.5, clamp to [0,1] */
+  for (int d = 0; d < 3; d++) {
+    float v = (x[d] - f->center[d]) / f->scale[d] + 0.5f;
+    v = v < 0.f ? 0.f : v;  /* clamp(min=0,max=1); NaN propagates like torch */
+    v = v > 1.f ? 1.f : v;
+    xn[d] = v;
+  }
+}
+
+void orc_hashgrid(const orc_field *f, const float *x, long V, uint16_t *feat) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < V; i++) {
+    float xn[3];
+    orc_normalise(f, x + i * 3, xn);
+    orc_hash_encode1(&f->hash, f->table, xn, feat + i * 32);
+  }
+}
+
+/* a11  FullyFusedMLP layer: y = act(W x), W fp16 [out][in] row-major,        */
+/* x fp16, fp32 accumulate, result rounded to fp16.  act: 0 none, 1 relu.     */
+static void orc_dense(const uint16_t *Wt, int out, int in, const uint16_t *x,
+                      int act, uint16_t *y) {
+  for (int o = 0; o < out; o++) {
+    float acc = 0.f;
+    for (int k = 0; k < in; k++) acc += h2f(Wt[o * in + k]) * h2f(x[k]);
+    if (act == 1 && acc < 0.f) acc = 0.f;
+    y[o] = f2h(acc);
+  }
+}
+
+/* a9 NeRFNGPNet.forward (ngp.py:73-83): rgb [V,3], sigma [V] (fp32 outputs). */
+void orc_field_fwd(const orc_field *f, const float *x, long V, float *rgb,
+                   float *sigma) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < V; i++) {
+    float xn[3];
+    uint16_t feat[32], h1[64], o16[16], cin[16], c1[64], c2[64];
+    orc_normalise(f, x + i * 3, xn);
+    orc_hash_encode1(&f->hash, f->table, xn, feat);
+    orc_dense(f->sig_w1, 64, 32, feat, 1, h1);
+    orc_dense(f->sig_w2, 16, 64, h1, 0, o16);
+    sigma[i] = h2f(o16[0]);                         /* ngp.py:80 */
+    for (int k = 0; k < 15; k++) cin[k] = o16[k + 1]; /* ngp.py:81 x[...,1:] */
+    cin[15] = f2h(1.0f); /* tcnn Identity encoding pads with 1 */
+    orc_dense(f->col_w1, 64, 16, cin, 1, c1);
+    orc_dense(f->col_w2, 64, 64, c1, 1, c2);
+    for (int o = 0; o < 3; o++) {
+      float acc = 0.f;
+      for (int k = 0; k < 64; k++) acc += h2f(f->col_w3[o * 64 + k]) * h2f(c2[k]);
+      float s = 1.0f / (1.0f + expf(-acc)); /* tcnn logistic */
+      rgb[i * 3 + o] = h2f(f2h(s));
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a6 deform_test tail (snarf_deformer.py:130-141): nan_to_num(0,0,0) on the  */
+/* valid candidates, max over candidates (first max wins), gather rgb.        */
+/* cand_rgb [P,C,3], cand_sigma [P,C] hold field values at valid slots; other */
+/* slots are ignored and take `fill` (0 test, -1e5 train :147).               */
+/* ------------------------------------------------------------------------ */
+void orc_candidate_max(const float *cand_rgb, const float *cand_sigma,
+                       const uint8_t *valid, long P, int C, float fill,
+                       int nan_to_num, float *rgb, float *sigma) {
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < P; p++) {
+    float best = 0;
+    int bi = -1;
+    for (int c = 0; c < C; c++) {
+      float s = fill, r[3] = {0, 0, 0};
+      if (valid[p * C + c]) {
+        s = cand_sigma[p * C + c];
+        for (int k = 0; k < 3; k++) r[k] = cand_rgb[(p * C + c) * 3 + k];
+        if (nan_to_num) {
+          if (!isfinite(s)) s = 0;
+          for (int k = 0; k < 3; k++) if (!isfinite(r[k])) r[k] = 0;
+        }
+      }
+      /* torch.max propagates NaN; with nan_to_num there is none.  First
+       * maximum wins (torch semantics on ties).                              */
+      if (bi < 0 || s > best || (isnan(s) && !isnan(best))) {
+        best = s; bi = c;
+        rgb[p * 3] = r[0]; rgb[p * 3 + 1] = r[1]; rgb[p * 3 + 2] = r[2];
+      }
+    }
+    sigma[p] = best;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a13 raymarch_test_kernel (renderers/cuda/raymarcher.cu:29-72)             */
+/* density_grid: uint8 [G,G,G] indexed [x][y][z].  pts/deltas/depths zeroed. */
+/* ------------------------------------------------------------------------ */
+static inline float orc_clampf(float f, float a, float b) {
+  return fmaxf(a, fminf(f, b));
+}
+void orc_raymarch_test(const float *rays_o, const float *rays_d, float *nears,
+                       const float *fars, const int64_t *alive, long n_alive,
+                       const uint8_t *grid, int G, const float *scale,
+                       const float *offset, const float *step_size, int N_steps,
+                       float *pts, float *deltas, float *depths) {
+  memset(pts, 0, sizeof(float) * n_alive * N_steps * 3);
+  memset(deltas, 0, sizeof(float) * n_alive * N_steps);
+  memset(depths, 0, sizeof(float) * n_alive * N_steps);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long i = 0; i < n_alive; i++) {
+    long n = alive[i];
+    float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    float cx = offset[0], cy = offset[1], cz = offset[2];
+    float sx = G / scale[0], sy = G / scale[1], sz = G / scale[2];
+    float far = fars[n], dt = step_size[n];
+    int s = 0;
+    float t = nears[n];
+    while (t < far && s < N_steps) {
+      float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+      int nx = (int)orc_clampf((x - cx) * sx, 0.0f, G - 1.0f);
+      int ny = (int)orc_clampf((y - cy) * sy, 0.0f, G - 1.0f);
+      int nz = (int)orc_clampf((z - cz) * sz, 0.0f, G - 1.0f);
+      if (grid[((long)nx * G + ny) * G + nz]) {
+        pts[(i * N_steps + s) * 3] = x;
+        pts[(i * N_steps + s) * 3 + 1] = y;
+        pts[(i * N_steps + s) * 3 + 2] = z;
+        deltas[i * N_steps + s] = dt;
+        depths[i * N_steps + s] = t;
+        t += dt; s++;
+      } else {
+        t += dt;
+      }
+    }
+    nears[n] = t; /* :72 */
+  }
+}
+
+/* a15 raymarch_train_kernel (raymarcher.cu:130-160) */
+void orc_raymarch_train(const float *rays_o, const float *rays_d,
+                        const float *nears, const float *fars, long n_rays,
+                        const uint8_t *grid, int G, const float *scale,
+                        const float *offset, const float *step_size,
+                        int N_steps, float *depths) {
+  memset(depths, 0, sizeof(float) * n_rays * N_steps);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long n = 0; n < n_rays; n++) {
+    float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    float cx = offset[0], cy = offset[1], cz = offset[2];
+    float sx = G / scale[0], sy = G / scale[1], sz = G / scale[2];
+    float far = fars[n], dt = step_size[n];
+    int s = 0;
+    float t = nears[n];
+    while (t < far && s < N_steps) {
+      float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+      int nx = (int)orc_clampf((x - cx) * sx, 0.0f, G - 1.0f);
+      int ny = (int)orc_clampf((y - cy) * sy, 0.0f, G - 1.0f);
+      int nz = (int)orc_clampf((z - cz) * sz, 0.0f, G - 1.0f);
+      if (grid[((long)nx * G + ny) * G + nz]) {
+        depths[n * N_steps + s] = t;
+        t += dt; s++;
+      } else {
+        t += dt;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a14 composite_test_kernel (raymarcher.cu:211-234).  __expf -> expf.       */
+/* ------------------------------------------------------------------------ */
+void orc_composite_test(const float *rgb, const float *sigma, const float *delta,
+                        const float *depth, const int64_t *alive, long n_alive,
+                        int N_steps, float *color, float *depth_out,
+                        float *nohit, float thresh) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n_alive; i++) {
+    long n = alive[i];
+    float T = nohit[n];
+    int s = 0;
+    /* `T > 1e-4`: float compared with a double literal */
+    while (s < N_steps && (double)T > 1e-4 && delta[i * N_steps + s] > 0) {
+      float tau = expf(-sigma[i * N_steps + s] * delta[i * N_steps + s]);
+      float alpha = 1.0f - tau;
+      if (alpha < thresh) { s++; continue; }
+      float w = alpha * T;
+      color[n * 3] += w * rgb[(i * N_steps + s) * 3];
+      color[n * 3 + 1] += w * rgb[(i * N_steps + s) * 3 + 1];
+      color[n * 3 + 2] += w * rgb[(i * N_steps + s) * 3 + 2];
+      depth_out[n] += w * depth[i * N_steps + s];
+      T *= tau;
+      s++;
+    }
+    nohit[n] = T;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a16/a18 occupancy post-processing (density_grid.py:104-110, 118-125).     */
+/* density [G^3] -> occ uint8 [G^3].  labels_out optional float [G^3].       */
+/* ------------------------------------------------------------------------ */
+static void orc_maxpool3(const float *in, float *out, int G) {
+  /* F.max_pool3d(kernel 3, stride 1, padding 1): -inf padding */
+#pragma omp parallel for schedule(static)
+  for (int x = 0; x < G; x++)
+    for (int y = 0; y < G; y++)
+      for (int z = 0; z < G; z++) {
+        float m = -INFINITY;
+        for (int a = -1; a <= 1; a++)
+          for (int b = -1; b <= 1; b++)
+            for (int c = -1; c <= 1; c++) {
+              int xx = x + a, yy = y + b, zz = z + c;
+              if (xx < 0 || yy < 0 || zz < 0 || xx >= G || yy >= G || zz >= G) continue;
+              float v = in[((long)xx * G + yy) * G + zz];
+              if (v > m || isnan(v)) m = v;
+            }
+        out[((long)x * G + y) * G + z] = m;
+      }
+}
+
+void orc_occupancy_from_density(const float *density, int G, uint8_t *occ,
+                                float *labels_out) {
+  long n = (long)G * G * G;
+  float *f = (float *)malloc(sizeof(float) * n);
+  float *g = (float *)malloc(sizeof(float) * n);
+  /* :104  1 - exp(0.01 * -density) */
+  for (long i = 0; i < n; i++) f[i] = 1.f - expf(0.01f * -density[i]);
+  orc_maxpool3(f, g, G); /* :105 */
+  /* :106  > clamp(mean, max=0.01).  torch.mean over 262144 floats is a
+   * pairwise/vectorised sum; a double accumulation is within 1 ulp of it.   */
+  double acc = 0;
+  for (long i = 0; i < n; i++) acc += g[i];
+  float mean = (float)(acc / (double)n);
+  float thr = mean > 0.01f ? 0.01f : mean;
+  uint8_t *grid = (uint8_t *)malloc(n);
+  for (long i = 0; i < n; i++) grid[i] = g[i] > thr;
+  /* max_connected_component :118-125 -- G*3 rounds of maxpool * grid */
+  for (long i = 0; i < n; i++) f[i] = grid[i] ? (float)(i + 1) : 0.f;
+  for (int it = 0; it < G * 3; it++) {
+    orc_maxpool3(f, g, G);
+    int changed = 0;
+    for (long i = 0; i < n; i++) {
+      float v = g[i] * (float)grid[i];
+      if (v != f[i]) changed = 1;
+      f[i] = v;
+    }
+    if (!changed) break; /* fixed point: further rounds are no-ops */
+  }
+  /* :109 torch.mode(mcc[field]) -- most frequent label, smallest on ties */
+  long *cnt = (long *)calloc(n + 1, sizeof(long));
+  for (long i = 0; i < n; i++) if (grid[i]) cnt[(long)f[i]]++;
+  long best = -1, bestc = 0;
+  for (long l = 1; l <= n; l++) if (cnt[l] > bestc) { bestc = cnt[l]; best = l; }
+  for (long i = 0; i < n; i++) occ[i] = (best > 0) && (f[i] == (float)best);
+  if (labels_out) memcpy(labels_out, f, sizeof(float) * n);
+  free(cnt); free(grid); free(f); free(g);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a20 query_weights_smpl (deformer_torch.py:225-244): KNN(K=30) inverse-     */
+/* distance blend + 30 Laplacian smoothing passes.  pts [N,3] (N = d*h*w in   */
+/* (d,h,w) order), verts [Vn,3], vw [Vn,24] -> weights [24,d,h,w].            */
+/* ------------------------------------------------------------------------ */
+void orc_query_weights_smpl(const float *pts, long N, const float *verts,
+                            int Vn, const float *vw, int d, int h, int w,
+                            int n_smooth, float *weights) {
+  const int K = 30;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (long i = 0; i < N; i++) {
+    float bd[30]; int bi[30]; int nb = 0;
+    float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    for (int v = 0; v < Vn; v++) {
+      float dx = px - verts[v * 3], dy = py - verts[v * 3 + 1], dz = pz - verts[v * 3 + 2];
+      float dist = dx * dx + dy * dy + dz * dz;
+      if (nb < K || dist < bd[nb - 1]) {
+        int j = nb < K ? nb++ : K - 1;
+        while (j > 0 && bd[j - 1] > dist) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; j--; }
+        bd[j] = dist; bi[j] = v;
+      }
+    }
+    float ws[30], sum = 0;
+    for (int k = 0; k < K; k++) { /* :228,231 */
+      float dd = sqrtf(bd[k]);
+      dd = dd < 0.0001f ? 0.0001f : (dd > 1.f ? 1.f : dd);
+      ws[k] = 1.f / dd; sum += ws[k];
+    }
+    for (int j = 0; j < 24; j++) {
+      float acc = 0;
+      for (int k = 0; k < K; k++) acc += (ws[k] / sum) * vw[bi[k] * 24 + j];
+      weights[(long)j * N + i] = acc;
+    }
+  }
+  /* :237-243 */
+  long n = (long)d * h * w;
+  float *mean = (float *)malloc(sizeof(float) * 24 * n);
+  for (int it = 0; it < n_smooth; it++) {
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < 24; c++)
+      for (int z = 1; z < d - 1; z++)
+        for (int y = 1; y < h - 1; y++)
+          for (int x = 1; x < w - 1; x++) {
+            const float *p = weights + (long)c * n;
+#define WAT(zz, yy, xx) p[((long)(zz)*h + (yy)) * w + (xx)]
+            float m = (WAT(z + 1, y, x) + WAT(z - 1, y, x) + WAT(z, y + 1, x) +
+                       WAT(z, y - 1, x) + WAT(z, y, x + 1) + WAT(z, y, x - 1)) / 6.0f;
+#undef WAT
+            mean[(long)c * n + ((long)z * h + y) * w + x] = m;
+          }
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < 24; c++)
+      for (int z = 1; z < d - 1; z++)
+        for (int y = 1; y < h - 1; y++)
+          for (int x = 1; x < w - 1; x++) {
+            long o = (long)c * n + ((long)z * h + y) * w + x;
+            weights[o] = (weights[o] - mean[o]) * 0.7f + mean[o];
+          }
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+      float s = 0;
+      for (int c = 0; c < 24; c++) s += weights[(long)c * n + i];
+      for (int c = 0; c < 24; c++) weights[(long)c * n + i] /= s;
+    }
+  }
+  free(mean);
+}
+
+int orc_version(void) { return 1; }

@@ -1,0 +1,341 @@
+"""Python side of the CPU oracle (TEST INFRASTRUCTURE ONLY -- see the header of
+ia_oracle.c; nothing under instantavatar_amd/ may import this module).
+
+ctypes bindings to libia_oracle.so plus numpy restatements of the reference's
+torch-level glue, each citing the reference lines it follows:
+
+  lbs / SMPL.forward          deformers/smplx/lbs.py:152-250,295-401
+                              deformers/smplx/body_models.py:337-360
+  prepare_deformer            deformers/snarf_deformer.py:41-93
+  switch_to_explicit          deformers/fast_snarf/deformer_torch.py:130-169
+  deform_test                 deformers/snarf_deformer.py:109-141
+  transform_rays_w2s          deformers/snarf_deformer.py:95-103
+  DensityGrid.initialize      models/structures/density_grid.py:95-110
+  Raymarcher.render_test      renderers/raymarcher_acc.py:83-138
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+F32P = C.POINTER(C.c_float)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libia_oracle.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "ia_oracle.c")):
+            build()
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+class HashDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("scale", C.c_float * 16),
+                ("res", C.c_uint32 * 16), ("offset", C.c_uint32 * 17)]
+
+
+class Field(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("scale", C.c_float * 3), ("hash", HashDesc),
+                ("table", C.c_void_p), ("sig_w1", C.c_void_p), ("sig_w2", C.c_void_p),
+                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def hash_desc(n_levels=16, log2_T=19, base=16, pls=1.5):
+    hd = HashDesc()
+    lib().orc_hash_desc_init(C.byref(hd), n_levels, log2_T, base, C.c_float(pls))
+    return hd
+
+
+def make_field(fp):
+    """fp: dict from instantavatar_amd.synthetic.make_field (or a checkpoint).
+    Returns (Field struct, keep-alive list)."""
+    f = Field()
+    keep = []
+    f.center[:] = [float(v) for v in fp["center"]]
+    f.scale[:] = [float(v) for v in fp["scale"]]
+    f.hash = hash_desc(fp.get("n_levels", 16), fp.get("log2_T", 19))
+    for k in ["table", "sig_w1", "sig_w2", "col_w1", "col_w2", "col_w3"]:
+        a = np.ascontiguousarray(fp[k]).view(np.uint16)
+        keep.append(a)
+        setattr(f, k, a.ctypes.data)
+    return f, keep
+
+
+# --------------------------------------------------------------------------
+# a1: LBS joint chain (lbs.py), numpy fp32
+# --------------------------------------------------------------------------
+def batch_rodrigues(rot_vecs):
+    """lbs.py:295-329"""
+    rot_vecs = _f32(rot_vecs)
+    angle = np.linalg.norm(rot_vecs + np.float32(1e-8), axis=1, keepdims=True).astype(np.float32)
+    rot_dir = rot_vecs / angle
+    cos = np.cos(angle)[:, None].astype(np.float32)
+    sin = np.sin(angle)[:, None].astype(np.float32)
+    rx, ry, rz = rot_dir[:, 0:1], rot_dir[:, 1:2], rot_dir[:, 2:3]
+    z = np.zeros_like(rx)
+    K = np.concatenate([z, -rz, ry, rz, z, -rx, -ry, rx, z], axis=1).reshape(-1, 3, 3)
+    ident = np.eye(3, dtype=np.float32)[None]
+    return (ident + sin * K + (1 - cos) * (K @ K)).astype(np.float32)
+
+
+def batch_rigid_transform(rot_mats, joints, parents):
+    """lbs.py:345-401 (single batch element).  rot_mats [24,3,3], joints [24,3]."""
+    joints = _f32(joints)[:, :, None]
+    rel = joints.copy()
+    rel[1:] -= joints[parents[1:]]
+    tm = np.zeros((24, 4, 4), np.float32)
+    tm[:, :3, :3] = rot_mats
+    tm[:, :3, 3:] = rel
+    tm[:, 3, 3] = 1
+    chain = [tm[0]]
+    for i in range(1, 24):
+        chain.append((chain[parents[i]] @ tm[i]).astype(np.float32))
+    transforms = np.stack(chain, 0)
+    posed = transforms[:, :3, 3].copy()
+    jh = np.concatenate([joints, np.zeros((24, 1, 1), np.float32)], 1)
+    corr = np.zeros((24, 4, 4), np.float32)
+    corr[:, :, 3:] = transforms @ jh
+    return posed, (transforms - corr).astype(np.float32)
+
+
+def smpl_forward(body, betas, body_pose, global_orient=None, transl=None, want_verts=True):
+    """SMPL.forward (body_models.py:289-372) + lbs (lbs.py:152-250), B = 1."""
+    betas = _f32(betas).reshape(-1)
+    v_shaped = body["v_template"] + np.einsum("l,mkl->mk", betas, body["shapedirs"]).astype(np.float32)
+    J = (body["J_regressor"] @ v_shaped).astype(np.float32)
+    go = np.zeros(3, np.float32) if global_orient is None else _f32(global_orient).reshape(3)
+    full = np.concatenate([go, _f32(body_pose).reshape(69)])
+    rot = batch_rodrigues(full.reshape(-1, 3))
+    Jt, A = batch_rigid_transform(rot, J, body["parents"])
+    out = dict(A=A, joints=Jt, J_rest=J, rot=rot)
+    if want_verts:
+        pose_feature = (rot[1:] - np.eye(3, dtype=np.float32)).reshape(-1)
+        v_posed = v_shaped + (pose_feature @ body["posedirs"]).reshape(-1, 3).astype(np.float32)
+        T = (body["lbs_weights"] @ A.reshape(24, 16)).reshape(-1, 4, 4)
+        vh = np.concatenate([v_posed, np.ones((len(v_posed), 1), np.float32)], 1)
+        out["vertices"] = np.einsum("vij,vj->vi", T, vh)[:, :3].astype(np.float32)
+    if transl is not None:  # body_models.py:353-360
+        t = _f32(transl).reshape(3)
+        out["A"] = A.copy()
+        out["A"][:, :3, 3] += t
+        out["joints"] = Jt + t
+        if want_verts:
+            out["vertices"] = out["vertices"] + t
+    return out
+
+
+# --------------------------------------------------------------------------
+# a20 + a2: deformer initialisation and per-frame preparation
+# --------------------------------------------------------------------------
+def deformer_initialize(body, betas, cano_pose, resolution=128, n_smooth=30, global_scale=1.2):
+    """SNARFDeformer.initialize (snarf_deformer.py:41-69) +
+    ForwardDeformer.switch_to_explicit (deformer_torch.py:130-186)."""
+    so = smpl_forward(body, betas, cano_pose)
+    tfs_inv_t = np.linalg.inv(so["A"].astype(np.float32)).astype(np.float32)
+    vs = so["vertices"]
+    d, h, w = resolution // 4, resolution, resolution
+    ratio = h / d
+    lin = lambda n: np.linspace(-1, 1, n, dtype=np.float32)
+    gz, gy, gx = np.meshgrid(lin(d), lin(h), lin(w), indexing="ij")
+    grid = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(np.float32)
+    gmin, gmax = vs.min(0), vs.max(0)
+    offset = ((gmin + gmax) * np.float32(0.5)).astype(np.float32)
+    scale = np.float32((gmax - gmin).max() / 2 * global_scale)
+    offset_kernel = -offset
+    scale_kernel = np.full(3, 1.0 / scale, np.float32)
+    scale_kernel[2] *= ratio
+    gd = grid.copy()                      # denormalize :164-169
+    gd[:, 2] /= np.float32(ratio)
+    gd *= scale
+    gd += offset
+    weights = np.empty((24, d, h, w), np.float32)
+    lib().orc_query_weights_smpl(_p(_f32(gd)), C.c_long(len(gd)), _p(_f32(vs)), C.c_int(len(vs)),
+                                 _p(_f32(body["lbs_weights"])), d, h, w, n_smooth, _p(weights))
+    # get_bbox_from_smpl (snarf_deformer.py:20-31)
+    c = (gmax + gmin) / 2
+    s = ((gmax - gmin) / 2).max() * np.float32(1.2)
+    bbox = np.stack([c - s, c + s]).astype(np.float32)
+    return dict(tfs_inv_t=tfs_inv_t, vs_template=vs, lbs_voxel=weights, offset_kernel=offset_kernel,
+                scale_kernel=scale_kernel, bbox=bbox, D=d, H=h, W=w, cano_joints=so["joints"],
+                grid_denorm=gd)
+
+
+def prepare_deformer(body, init, betas, body_pose, global_orient, transl):
+    """snarf_deformer.py:71-93 -> tfs [24,4,4], w2s [4,4] and precompute."""
+    so = smpl_forward(body, betas, body_pose, global_orient, transl, want_verts=False)
+    s2w = so["A"][0].astype(np.float32)
+    w2s = np.linalg.inv(s2w).astype(np.float32)
+    tfs = (w2s[None] @ so["A"] @ init["tfs_inv_t"]).astype(np.float32)
+    return tfs, w2s
+
+
+def precompute(init, tfs):
+    """ForwardDeformer.precompute (deformer_torch.py:77-83).  Returns voxel_J
+    [12,D,H,W] and voxel_d [3,D,H,W] in the REFERENCE layout."""
+    D, H, W = init["D"], init["H"], init["W"]
+    vJ = np.empty((12, D, H, W), np.float32)
+    vd = np.empty((3, D, H, W), np.float32)
+    lib().orc_precompute(_p(init["lbs_voxel"]), _p(_f32(tfs)), _p(vJ), _p(vd), _p(init["offset_kernel"]),
+                         _p(init["scale_kernel"]), D, H, W)
+    return vJ, vd
+
+
+def broyden(xd, voxel_J, tfs, init, bone_ids, cvg=1e-5, dvg=1e-1, want_iters=False):
+    """broyden_cuda (deformer_torch.py:100-116) without the filter."""
+    xd = _f32(xd).reshape(-1, 3)
+    P, n = len(xd), len(bone_ids)
+    x = np.empty((P, n, 3), np.float32)
+    Ji = np.empty((P, n, 3, 3), np.float32)
+    valid = np.empty((P, n), np.uint8)
+    it = np.zeros((P, n), np.uint8)
+    b = np.ascontiguousarray(bone_ids, np.int32)
+    lib().orc_broyden(_p(xd), C.c_long(P), _p(voxel_J), init["D"], init["H"], init["W"], _p(_f32(tfs)),
+                      _p(b), n, _p(init["offset_kernel"]), _p(init["scale_kernel"]), C.c_float(cvg),
+                      C.c_float(dvg), _p(x), _p(Ji), _p(valid), _p(it))
+    return (x, Ji, valid, it) if want_iters else (x, Ji, valid)
+
+
+def filter_dup(x, mask):
+    out = np.empty_like(mask)
+    lib().orc_filter(_p(x), _p(mask), C.c_long(x.shape[0]), x.shape[1], _p(out))
+    return out
+
+
+def search(xd, voxel_J, tfs, init, bone_ids):
+    x, Ji, valid = broyden(xd, voxel_J, tfs, init, bone_ids)
+    return x, filter_dup(x, valid), Ji, valid
+
+
+def field_fwd(field, x):
+    x = _f32(x).reshape(-1, 3)
+    rgb = np.empty((len(x), 3), np.float32)
+    sig = np.empty(len(x), np.float32)
+    lib().orc_field_fwd(C.byref(field), _p(x), C.c_long(len(x)), _p(rgb), _p(sig))
+    return rgb, sig
+
+
+def hashgrid(field, x):
+    x = _f32(x).reshape(-1, 3)
+    feat = np.empty((len(x), 32), np.uint16)
+    lib().orc_hashgrid(C.byref(field), _p(x), C.c_long(len(x)), _p(feat))
+    return feat.view(np.float16)
+
+
+def deform_query(pts, world, eval_mode=True):
+    """SNARFDeformer.__call__ (snarf_deformer.py:127-165): returns rgb, sigma."""
+    pts = _f32(pts).reshape(-1, 3)
+    x, valid, _, _ = search(pts, world["voxel_J"], world["tfs"], world["init"], world["bone_ids"])
+    P, Cn = valid.shape
+    rgb_c = np.zeros((P, Cn, 3), np.float32)
+    sig_c = np.zeros((P, Cn), np.float32)
+    m = valid.astype(bool)
+    if m.any():
+        r, s = field_fwd(world["field"], x[m])
+        rgb_c[m], sig_c[m] = r, s
+    rgb = np.empty((P, 3), np.float32)
+    sig = np.empty(P, np.float32)
+    lib().orc_candidate_max(_p(rgb_c), _p(sig_c), _p(valid), C.c_long(P), Cn,
+                            C.c_float(0.0 if eval_mode else -1e5), 1 if eval_mode else 0, _p(rgb), _p(sig))
+    return rgb, sig
+
+
+def transform_rays_w2s(o, d, w2s):
+    """snarf_deformer.py:95-103"""
+    o2 = (_f32(o) @ w2s[:3, :3].T + w2s[:3, 3]).astype(np.float32)
+    d2 = (_f32(d) @ w2s[:3, :3].T).astype(np.float32)
+    dist = np.linalg.norm(o2, axis=-1).astype(np.float32)
+    return o2, d2, dist - 1, dist + 1
+
+
+def occupancy_from_density(density, G=64):
+    occ = np.empty(G ** 3, np.uint8)
+    lib().orc_occupancy_from_density(_p(_f32(density).reshape(-1)), G, _p(occ), None)
+    return occ.reshape(G, G, G)
+
+
+def density_grid_initialize(world, jitter, G=64):
+    """DensityGrid.initialize (density_grid.py:95-110).  jitter [iters,G^3,3]
+    replaces torch.rand_like (:100).  Returns (aabb [2,3], density, occ)."""
+    vd = world["voxel_d"].reshape(3, -1)
+    aabb = np.stack([vd.min(1), vd.max(1)]).astype(np.float32)   # get_bbox_deformed
+    idx = np.arange(G, dtype=np.float32)
+    cx, cy, cz = np.meshgrid(idx, idx, idx, indexing="ij")
+    coords0 = (np.stack([cx, cy, cz], -1).reshape(-1, 3) / np.float32(G)).astype(np.float32)
+    density = np.zeros(G ** 3, np.float32)
+    for it in range(len(jitter)):
+        coords = (coords0 + _f32(jitter[it]) / np.float32(G)) * (aabb[1] - aabb[0]) + aabb[0]
+        _, d = deform_query(coords.astype(np.float32), world, eval_mode=True)
+        density = np.maximum(density, d)
+    return aabb, density, occupancy_from_density(density, G)
+
+
+def render_test(o, d, near, far, occ, aabb, model, MAX_SAMPLES=256, MAX_BATCH_SIZE=291600, bg=None):
+    """Raymarcher.render_test (raymarcher_acc.py:83-138).  model(pts)->(rgb,sigma)."""
+    L = lib()
+    o = _f32(o).reshape(-1, 3); d = _f32(d).reshape(-1, 3)
+    near = _f32(near).reshape(-1).copy(); far = _f32(far).reshape(-1)
+    N = len(o)
+    color = np.zeros((N, 3), np.float32); depth = np.zeros(N, np.float32)
+    no_hit = np.ones(N, np.float32); counter = np.zeros(N, np.float32)
+    alive = np.arange(N, dtype=np.int64)
+    step = ((far - near) / np.float32(MAX_SAMPLES)).astype(np.float32)
+    offset = _f32(aabb[0]); scale = _f32(aabb[1] - aabb[0])
+    G = occ.shape[0]
+    occ8 = np.ascontiguousarray(occ, np.uint8)
+    k = 0
+    n_field = 0
+    while k < MAX_SAMPLES:
+        Na = len(alive)
+        if Na == 0:
+            break
+        Ns = max(min(MAX_BATCH_SIZE // Na, MAX_SAMPLES), 1)
+        pts = np.empty((Na, Ns, 3), np.float32); dn = np.empty((Na, Ns), np.float32); zn = np.empty((Na, Ns), np.float32)
+        L.orc_raymarch_test(_p(o), _p(d), _p(near), _p(far), _p(alive), C.c_long(Na), _p(occ8), G, _p(scale),
+                            _p(offset), _p(step), Ns, _p(pts), _p(dn), _p(zn))
+        counter[alive] += (dn > 0).sum(-1)
+        mask = dn > 0
+        rgb = np.zeros_like(pts); sig = np.zeros((Na, Ns), np.float32)
+        if mask.any():
+            r, s = model(pts[mask])
+            rgb[mask], sig[mask] = r, s
+            n_field += int(mask.sum())
+        L.orc_composite_test(_p(rgb), _p(sig), _p(dn), _p(zn), _p(alive), C.c_long(Na), Ns, _p(color), _p(depth),
+                             _p(no_hit), C.c_float(0.01))
+        alive = alive[(no_hit[alive] > 1e-4) & (zn[:, -1] > 0)]
+        k += Ns
+    color = color + no_hit[:, None] * (1.0 if bg is None else _f32(bg).reshape(-1, 3))
+    return dict(rgb=color.astype(np.float32), depth=depth, alpha=1 - no_hit, counter=counter, n_field=n_field)
+
+
+def make_world(body, init, field_params, betas, body_pose, global_orient, transl, bone_ids):
+    tfs, w2s = prepare_deformer(body, init, betas, body_pose, global_orient, transl)
+    vJ, vd = precompute(init, tfs)
+    field, keep = make_field(field_params)
+    return dict(init=init, tfs=tfs, w2s=w2s, voxel_J=vJ, voxel_d=vd, field=field, _keep=keep,
+                bone_ids=np.asarray(bone_ids, np.int32))
+
+
+def render_image_fast(world, rays_o, rays_d, jitter, G=64, **kw):
+    """DNeRFModel.render_image_fast (models/DNeRF.py:72-97) for one frame."""
+    aabb, density, occ = density_grid_initialize(world, jitter, G)
+    o, d, near, far = transform_rays_w2s(rays_o, rays_d, world["w2s"])
+    out = render_test(o, d, near, far, occ, aabb, lambda p: deform_query(p, world, True), **kw)
+    out.update(occ=occ, aabb=aabb, density=density)
+    return out

@@ -1,0 +1,197 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors, host logic,
+and that the C-ABI library loads and exports every declared symbol."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from instantavatar_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+# ---------------------------------------------------------------- C ABI / build
+def test_cabi_exports_every_declared_symbol():
+    from instantavatar_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "instantavatar_hip.h")).read()
+    declared = set(re.findall(r"\b(ia_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    l = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(l, s)]
+    assert not missing, "symbols declared in include/*.h but not exported: %s" % missing
+    assert set(_lib.EXPORTED) <= declared
+    assert _lib.lib().ia_version() >= 100
+
+
+def test_no_cpu_fallback_fails_loudly():
+    from instantavatar_amd import _lib
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    net = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), n_levels=8, log2_hashmap_size=12)
+    with pytest.raises(_lib.IAError):
+        with torch.no_grad():
+            net(torch.zeros(4, 3), None)  # CPU tensor: must raise, not fall back
+
+
+def test_product_does_not_import_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "instantavatar_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|libia_oracle|orc_[a-z_]+\(", src, re.M):
+                    bad.append(f)
+    assert not bad, "product files reference the oracle: %s" % bad
+
+
+# ---------------------------------------------------------------- half helpers
+def test_half_conversion_matches_ieee(oracle):
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.randn(20000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 7e4)])
+    x = np.concatenate([x, np.array([0, -0.0, np.inf, -np.inf, 65504, 65520, 65519.99, 5.96e-8, 2.98e-8, 2.99e-8], np.float32)])
+    y = np.empty(len(x), np.uint16)
+    oracle.lib().orc_f32_to_f16(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_long(len(x)))
+    ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(y, ref)
+    allh = np.arange(65536, dtype=np.uint16)
+    back = np.empty(65536, np.float32)
+    oracle.lib().orc_f16_to_f32(allh.ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p), C.c_long(65536))
+    ref = allh.view(np.float16).astype(np.float32)
+    ok = (back == ref) | (np.isnan(back) & np.isnan(ref))
+    assert ok.all()
+
+
+# ---------------------------------------------------------------- tcnn level table
+def test_hash_level_table_pinned(oracle):
+    """tcnn-v1.6 level table with glibc float32 arithmetic (parity unpinned vs tcnn itself;
+    this pins OUR three implementations to each other and to the frozen numbers)."""
+    from instantavatar_amd import _lib
+    hd_o = oracle.hash_desc()
+    hd_p = _lib.make_hash_desc()
+    sc, res, off = syn.hash_level_table()
+    expect_res = [16, 24, 36, 54, 81, 122, 183, 274, 411, 616, 923, 1384, 2076, 3114, 4671, 7007]
+    assert list(hd_o.res) == expect_res == list(hd_p.res) == list(res)
+    assert list(hd_o.offset) == list(hd_p.offset) == list(off)
+    assert hd_o.offset[16] == 6513496  # => encoder.params = 3072 + 13026992
+    assert np.allclose(np.array(hd_o.scale[:]), sc, rtol=0, atol=0)
+    assert list(hd_o.offset[:5]) == [0, 4096, 17920, 64576, 222040]
+
+
+# ---------------------------------------------------------------- LBS golden (reference lbs.py)
+def test_lbs_oracle_matches_reference_golden(oracle):
+    g = np.load(os.path.join(HERE, "golden", "lbs_golden.npz"))
+    body = dict(v_template=g["v_template"], shapedirs=g["shapedirs"], posedirs=g["posedirs"],
+                J_regressor=g["J_regressor"], lbs_weights=g["lbs_weights"], parents=g["parents"])
+    for i in range(int(g["n_cases"])):
+        pose = g["pose%d" % i][0]
+        out = oracle.smpl_forward(body, g["betas%d" % i], pose[3:], pose[:3], g["transl%d" % i])
+        assert np.abs(out["A"] - g["A%d" % i][0]).max() < 2e-5
+        assert np.abs(out["vertices"] - g["verts%d" % i][0]).max() < 2e-5
+        assert np.abs(out["joints"] - g["joints%d" % i][0]).max() < 2e-5
+        assert np.abs(oracle.batch_rodrigues(pose.reshape(-1, 3)) - g["rot%d" % i]).max() < 1e-6
+
+
+def test_lbs_product_torch_matches_reference_golden():
+    from instantavatar_amd.deformers.smplx import SMPL
+    g = np.load(os.path.join(HERE, "golden", "lbs_golden.npz"))
+    smpl = SMPL.from_dict(dict(v_template=g["v_template"], shapedirs=g["shapedirs"], posedirs=g["posedirs"],
+                               J_regressor=g["J_regressor"], lbs_weights=g["lbs_weights"], parents=g["parents"]))
+    for i in range(int(g["n_cases"])):
+        pose = torch.as_tensor(g["pose%d" % i])
+        out = smpl(torch.as_tensor(g["betas%d" % i]), pose[:, 3:], pose[:, :3], torch.as_tensor(g["transl%d" % i]))
+        assert (out.A - torch.as_tensor(g["A%d" % i])).abs().max() < 2e-5
+        assert (out.vertices - torch.as_tensor(g["verts%d" % i])).abs().max() < 2e-5
+
+
+# ---------------------------------------------------------------- oracle self-consistency
+@pytest.fixture(scope="module")
+def small_world(oracle):
+    body = syn.make_body()
+    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
+    fp = syn.make_field(init["cano_joints"], init["bbox"])
+    poses, tr = syn.procedural_pose_track(8)
+    world = oracle.make_world(body, init, fp, np.zeros(10, np.float32), poses[1, 3:], poses[1, :3], tr[1], syn.INIT_BONES)
+    return body, init, fp, world
+
+
+def test_weight_voxels_are_a_partition_of_unity(small_world):
+    _, init, _, _ = small_world
+    w = init["lbs_voxel"]
+    assert w.shape == (24, 8, 32, 32)
+    assert np.abs(w.sum(0) - 1).max() < 1e-5 and w.min() >= 0
+
+
+def test_broyden_roots_satisfy_forward_skinning(oracle, small_world):
+    """Converged roots x_c must map back to x_d under d(x) = J(x) [x,1] within cvg."""
+    body, init, fp, world = small_world
+    rng = np.random.RandomState(1)
+    vd = world["voxel_d"].reshape(3, -1)
+    pts = (vd[:, rng.randint(0, vd.shape[1], 4000)].T + rng.randn(4000, 3).astype(np.float32) * 0.01).astype(np.float32)
+    x, Ji, valid, iters = oracle.broyden(pts, world["voxel_J"], world["tfs"], init, world["bone_ids"], want_iters=True)
+    assert valid.any() and iters.min() >= 2 and iters.max() <= 11
+    # identity pose: every valid root equals the query point
+    w_id = oracle.make_world(body, init, fp, np.zeros(10, np.float32), syn.cano_pose("A_pose"), np.zeros(3, np.float32),
+                             np.zeros(3, np.float32), syn.INIT_BONES)
+    assert np.abs(w_id["tfs"] - np.eye(4)).max() < 1e-5
+    x2, _, v2 = oracle.broyden(pts, w_id["voxel_J"], w_id["tfs"], init, w_id["bone_ids"])
+    m = v2.astype(bool)
+    assert m.any()
+    assert np.abs(x2[m] - np.repeat(pts[:, None], 13, 1)[m]).max() < 1e-4
+    # filter: at most one survivor per cluster; survivors are a subset of valid
+    keep = oracle.filter_dup(x2, v2)
+    assert (keep <= v2).all() and (keep.sum(1) <= 1 + 0 * keep.sum(1)).all()
+
+
+def test_filter_keeps_last_duplicate(oracle):
+    x = np.zeros((1, 13, 3), np.float32)
+    mask = np.zeros((1, 13), np.uint8)
+    x[0, 2] = [0.1, 0.2, 0.3]; x[0, 7] = [0.1, 0.2, 0.30005]; x[0, 9] = [0.5, 0, 0]
+    mask[0, [2, 7, 9]] = 1
+    out = oracle.filter_dup(x, mask)
+    assert out[0].tolist() == [0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0]  # Q6: the LAST of a cluster survives
+
+
+def test_occupancy_keeps_largest_component(oracle):
+    G = 16
+    dens = np.zeros((G, G, G), np.float32)
+    dens[2:6, 2:6, 2:6] = 500.0     # big blob
+    dens[12:13, 12:13, 12:13] = 500.0  # small blob, not 26-connected to the big one after max-pool
+    occ = oracle.occupancy_from_density(dens, G)
+    assert occ[3, 3, 3] and not occ[12, 12, 12]
+    assert occ.sum() == 6 ** 3  # 4^3 dilated by the 3^3 max-pool
+    assert oracle.occupancy_from_density(np.zeros((G, G, G), np.float32), G).sum() == 0
+
+
+def test_composite_threshold_and_early_stop(oracle):
+    n, S = 1, 6
+    rgb = np.ones((n, S, 3), np.float32)
+    sigma = np.array([[0.5, 100, 1e4, 50, 50, 50]], np.float32)
+    delta = np.full((n, S), 2 / 256, np.float32); delta[0, 5] = 0
+    depth = np.arange(S, dtype=np.float32)[None] + 1
+    alive = np.zeros(1, np.int64)
+    color = np.zeros((1, 3), np.float32); dep = np.zeros(1, np.float32); nohit = np.ones(1, np.float32)
+    oracle.lib().orc_composite_test(*[a.ctypes.data_as(C.c_void_p) for a in (rgb, sigma, delta, depth, alive)],
+                                    C.c_long(1), S, color.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p),
+                                    nohit.ctypes.data_as(C.c_void_p), C.c_float(0.01))
+    a1 = 1 - np.exp(-100 * 2 / 256)          # sample 0 (alpha<0.01) skipped without attenuation
+    T = (1 - a1) * np.exp(-1e4 * 2 / 256)    # sample 2 drives T below 1e-4 -> loop stops
+    assert abs(nohit[0] - T) < 1e-7 and T < 1e-4
+    assert abs(color[0, 0] - (a1 + (1 - a1) * (1 - np.exp(-1e4 * 2 / 256)))) < 1e-6
+
+
+def test_render_frame_small(oracle, small_world):
+    body, init, fp, world = small_world
+    ro, rd = syn.make_camera_rays(32)
+    jit = np.random.RandomState(3).rand(2, 64 ** 3, 3).astype(np.float32)
+    out = oracle.render_image_fast(world, ro, rd, jit)
+    cov = (out["alpha"] > 0.5).mean()
+    assert 0.02 < cov < 0.5 and out["occ"].sum() > 100
+    assert np.isfinite(out["rgb"]).all() and out["rgb"].min() >= 0 and out["rgb"].max() <= 1 + 1e-5
+    # linearity of the background term (Q12): rgb(bg) - rgb(white) = T * (bg - 1)
+    o, d, near, far = oracle.transform_rays_w2s(ro, rd, world["w2s"])
+    bg = np.zeros((len(ro), 3), np.float32)
+    out2 = oracle.render_test(o, d, near, far, out["occ"], out["aabb"], lambda p: oracle.deform_query(p, world, True), bg=bg)
+    assert np.abs((out["rgb"] - out2["rgb"]) - (1 - out["alpha"])[:, None]).max() < 1e-6

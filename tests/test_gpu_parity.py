@@ -1,0 +1,302 @@
+"""GPU parity suite (-m gpu): every HIP kernel, called through the C ABI, against
+the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star: RGB/alpha within 1e-3 abs, fp32):
+  * integer / index / byte results (validity masks, occupancy bits, hash-grid
+    features in fp16, ray-march sample depths)             -> bit exact
+  * fp32 chains whose only difference is FMA contraction    -> 1e-5 .. 1e-4
+  * rendered rgb / alpha                                    -> 1e-3
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from instantavatar_amd import _lib, synthetic as syn
+from instantavatar_amd.models.structures.utils import Rays
+from instantavatar_amd.pipeline import make_batch
+
+import world as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gpu_world(oracle):
+    model, body, fp, init = W.build(DEV, 64, 16)
+    poses, tr = W.poses()
+    return model, body, fp, init, poses, tr
+
+
+def _prepare(model, poses, tr, i, res=64):
+    batch = make_batch(DEV, res, poses[i], tr[i])
+    model.deformer.prepare_deformer(batch)
+    return batch
+
+
+def test_native_library_is_loaded():
+    import os
+    maps = open("/proc/self/maps").read()
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libinstantavatar_hip.so" in maps
+    assert torch.cuda.is_available() and "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_smpl_tfs_kernel(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    for i in (0, 3, 5):
+        _prepare(model, poses, tr, i)
+        tfs, w2s = oracle.prepare_deformer(body, init, np.zeros(10, np.float32), poses[i, 3:], poses[i, :3], tr[i])
+        assert np.abs(model.deformer.tfs[0].cpu().numpy() - tfs).max() < 2e-5
+        assert np.abs(model.deformer.w2s[0].cpu().numpy() - w2s).max() < 2e-5
+
+
+def test_precompute_kernel(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    _prepare(model, poses, tr, 2)
+    tfs = model.deformer.tfs[0].cpu().numpy()
+    vJ, vd = oracle.precompute(init, tfs)
+    fd = model.deformer.deformer
+    assert np.abs(fd.voxel_J[0].cpu().numpy() - vJ).max() < 1e-5
+    assert np.abs(fd.voxel_d[0].cpu().numpy() - vd).max() < 1e-5
+    bb = torch.cat(model.deformer.get_bbox_deformed()).cpu().numpy()
+    vdg = fd.voxel_d[0].reshape(3, -1)
+    assert np.array_equal(bb[:3], vdg.min(1).values.cpu().numpy()) and np.array_equal(bb[3:], vdg.max(1).values.cpu().numpy())
+
+
+def _query_points(model, n, seed):
+    rng = np.random.RandomState(seed)
+    vd = model.deformer.deformer.voxel_d[0].reshape(3, -1).cpu().numpy()
+    pts = vd[:, rng.randint(0, vd.shape[1], n)].T + rng.randn(n, 3).astype(np.float32) * 0.02
+    return np.ascontiguousarray(pts, np.float32)
+
+
+def test_broyden_search_and_filter(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    _prepare(model, poses, tr, 4)
+    fd = model.deformer.deformer
+    tfs = model.deformer.tfs[0].cpu().numpy()
+    vJ = np.ascontiguousarray(fd.voxel_J[0].cpu().numpy())
+    pts = _query_points(model, 20011, 7)  # ragged: not a multiple of 64
+    x_o, Ji_o, raw_o = oracle.broyden(pts, vJ, tfs, init, syn.INIT_BONES)
+    keep_o = oracle.filter_dup(x_o, raw_o)
+    out = fd.broyden_cuda(torch.as_tensor(pts, device=DEV)[None], None, fd.voxel_J_cl, model.deformer.tfs)
+    x_g, keep_g = out["result"][0].cpu().numpy(), out["valid_ids"][0].cpu().numpy()
+    Ji_g = out["J_inv"][0].cpu().numpy()
+    # convergence flags are branchy: allow a vanishing fraction of flips (FMA contraction)
+    flips = (keep_g != keep_o.astype(bool)).mean()
+    assert flips < 2e-4, flips
+    both = keep_g & keep_o.astype(bool)
+    assert both.sum() > 1000
+    assert np.abs(x_g[both] - x_o[both]).max() < 2e-5
+    assert np.abs(Ji_g[both] - Ji_o[both]).max() < 5e-3
+    # Q1: non-converged / invalid slots stay exactly zero
+    raw_g = np.abs(x_g).sum(-1) > 0
+    assert (x_g[~raw_g] == 0).all()
+    # empty input is fine
+    e = fd.broyden_cuda(torch.zeros((1, 0, 3), device=DEV), None, fd.voxel_J_cl, model.deformer.tfs)
+    assert e["result"].shape == (1, 0, 13, 3)
+
+
+def test_hashgrid_features_bit_exact(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    field, keep = oracle.make_field(fp)
+    rng = np.random.RandomState(11)
+    bb = init["bbox"]
+    x = (rng.rand(50003, 3) * (bb[1] - bb[0]) * 1.1 + bb[0] - 0.05 * (bb[1] - bb[0])).astype(np.float32)  # incl. clamped
+    x[:3] = [bb[0], bb[1], (bb[0] + bb[1]) / 2]
+    ref = oracle.hashgrid(field, x).view(np.uint16)
+    got = model.net_coarse.encode(torch.as_tensor(x, device=DEV)).cpu().numpy().view(np.uint16)
+    mism = (ref != got).any(1).mean()
+    # pos = x*scale+0.5 is an FMA on the GPU and mul+add on the host: a cell flip at an
+    # exact cell boundary is continuous in value but not bitwise -> allow 1e-4 of samples
+    assert mism < 1e-4, mism
+    d = np.abs(ref.view(np.float16).astype(np.float32) - got.view(np.float16).astype(np.float32)).max()
+    assert d < 2e-3, d
+
+
+def test_field_forward(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    field, keep = oracle.make_field(fp)
+    rng = np.random.RandomState(12)
+    bb = init["bbox"]
+    for n in (1, 63, 64, 65, 40007):
+        x = (rng.rand(n, 3) * (bb[1] - bb[0]) + bb[0]).astype(np.float32)
+        rgb_o, sig_o = oracle.field_fwd(field, x)
+        with torch.no_grad():
+            rgb_g, sig_g = model.net_coarse(torch.as_tensor(x, device=DEV), None)
+        rgb_g, sig_g = rgb_g.cpu().numpy(), sig_g.cpu().numpy()
+        # fp16-rounded outputs: equal except where the fp32 sum order flips a rounding
+        assert np.abs(rgb_g - rgb_o).max() < 2e-3
+        tol = 2e-3 * np.maximum(1.0, np.abs(sig_o))
+        assert (np.abs(sig_g - sig_o) <= tol).all()
+        if n > 1000:
+            assert (sig_g == sig_o).mean() > 0.97 and (rgb_g == rgb_o).mean() > 0.97
+            assert sig_o.max() > 50 and sig_o.min() < -50  # the synthetic field is not trivial
+
+
+def test_deform_query_fused_vs_oracle(oracle, gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    _prepare(model, poses, tr, 1)
+    ow = W.oracle_world(oracle, body, fp, init, poses[1], tr[1])
+    # feed the oracle the GPU's transforms so that only the stage under test differs
+    ow["tfs"] = model.deformer.tfs[0].cpu().numpy()
+    ow["voxel_J"] = np.ascontiguousarray(model.deformer.deformer.voxel_J[0].cpu().numpy())
+    pts = _query_points(model, 30001, 5)
+    rgb_o, sig_o = oracle.deform_query(pts, ow, True)
+    rgb_g, sig_g = model.deformer(torch.as_tensor(pts, device=DEV), model.net_coarse, True)
+    rgb_g, sig_g = rgb_g.cpu().numpy(), sig_g.cpu().numpy()
+    bad = np.abs(sig_g - sig_o) > 2e-3 * np.maximum(1, np.abs(sig_o))
+    assert bad.mean() < 5e-4, bad.mean()
+    ok = ~bad & (sig_o > 0)
+    assert np.abs(rgb_g[ok] - rgb_o[ok]).max() < 2e-3
+    assert (sig_g >= 0).all()  # Q11: invalid candidates contribute 0 at test time
+    # closure route == fused route
+    rgb_c, sig_c = model.deformer(torch.as_tensor(pts, device=DEV), lambda x, d: model.net_coarse(x, d), True)
+    assert torch.equal(torch.as_tensor(sig_g), sig_c.cpu())
+
+
+def test_occupancy_postprocess_bit_exact(oracle, gpu_world):
+    model = gpu_world[0]
+    G = 64
+    rng = np.random.RandomState(2)
+    dens = np.zeros((G, G, G), np.float32)
+    dens[10:30, 20:40, 5:50] = rng.rand(20, 20, 45) * 300
+    dens[40:44, 40:44, 40:44] = 200           # separate small component
+    dens[50, 50, 50] = 1e-3                     # below threshold
+    ref = oracle.occupancy_from_density(dens, G)
+    grid = model.renderer.density_grid_test
+    grid._postprocess(torch.as_tensor(dens, device=DEV))
+    got = grid.density_field.cpu().numpy()
+    assert np.array_equal(got, ref.astype(bool))
+    bits = grid.occ_bits.cpu().numpy().view(np.uint32)
+    unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(G, G, G).astype(bool)
+    assert np.array_equal(unpacked, got)
+    grid._postprocess(torch.zeros((G, G, G), device=DEV))   # empty grid edge case
+    assert grid.density_field.sum().item() == 0
+
+
+def test_raymarch_and_composite_kernels(oracle, gpu_world):
+    model = gpu_world[0]
+    G = 64
+    rng = np.random.RandomState(4)
+    occ = np.zeros((G, G, G), np.uint8)
+    occ[20:44, 10:54, 24:40] = 1
+    occ[rng.rand(G, G, G) > 0.97] = 1
+    aabb = np.array([[-1.0, -1.2, -0.6], [1.0, 0.9, 0.7]], np.float32)
+    N = 3001
+    o = np.tile(np.array([[0.0, 0.0, -4.0]], np.float32), (N, 1)) + rng.randn(N, 3).astype(np.float32) * 0.01
+    d = rng.randn(N, 3).astype(np.float32) * 0.15 + np.array([0, 0, 1], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = np.linalg.norm(o, axis=1).astype(np.float32)
+    near, far = dist - 1, dist + 1
+    step = ((far - near) / 256).astype(np.float32)
+    alive = np.sort(rng.choice(N, 2000, replace=False)).astype(np.int64)
+    for Ns in (1, 7, 256):
+        near_o = near.copy()
+        pts = np.empty((len(alive), Ns, 3), np.float32); dn = np.empty((len(alive), Ns), np.float32); zn = np.empty_like(dn)
+        oracle.lib().orc_raymarch_test(*[a.ctypes.data_as(C.c_void_p) for a in (o, d, near_o, far, alive)], C.c_long(len(alive)),
+                                       occ.ctypes.data_as(C.c_void_p), G, (aabb[1] - aabb[0]).ctypes.data_as(C.c_void_p),
+                                       aabb[0].ctypes.data_as(C.c_void_p), step.ctypes.data_as(C.c_void_p), Ns,
+                                       pts.ctypes.data_as(C.c_void_p), dn.ctypes.data_as(C.c_void_p), zn.ctypes.data_as(C.c_void_p))
+        t = lambda a: torch.as_tensor(a, device=DEV)
+        bits = torch.zeros(G ** 3 // 32, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(t(occ)), G, _lib.ptr(bits), _lib.stream()))
+        og = _lib.OccGrid(); og.G = G; og.aabb_min[:] = aabb[0].tolist(); og.aabb_max[:] = aabb[1].tolist()
+        near_g = t(near.copy()); pg = torch.empty((len(alive), Ns, 3), device=DEV); dg = torch.empty((len(alive), Ns), device=DEV); zg = torch.empty_like(dg)
+        to, td, tf, ta, ts = t(o), t(d), t(far), t(alive), t(step)
+        _lib.check(_lib.lib().ia_raymarch_test(_lib.ptr(to), _lib.ptr(td), _lib.ptr(near_g), _lib.ptr(tf), _lib.ptr(ta), len(alive),
+                                               _lib.ptr(bits), C.byref(og), _lib.ptr(ts), Ns, _lib.ptr(pg), _lib.ptr(dg), _lib.ptr(zg),
+                                               _lib.stream()))
+        # depths are produced by the same sequence of float adds -> bit exact; positions differ by FMA only
+        assert np.array_equal(zg.cpu().numpy(), zn) and np.array_equal(dg.cpu().numpy(), dn)
+        assert np.array_equal(near_g.cpu().numpy(), near_o)
+        assert np.abs(pg.cpu().numpy() - pts).max() < 1e-6
+        # composite on random field values
+        rgbv = rng.rand(len(alive), Ns, 3).astype(np.float32); sig = (rng.randn(len(alive), Ns) * 60).astype(np.float32)
+        col = np.zeros((N, 3), np.float32); dep = np.zeros(N, np.float32); nh = np.ones(N, np.float32)
+        oracle.lib().orc_composite_test(*[a.ctypes.data_as(C.c_void_p) for a in (rgbv, sig, dn, zn, alive)], C.c_long(len(alive)), Ns,
+                                        col.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), nh.ctypes.data_as(C.c_void_p), C.c_float(0.01))
+        cg = torch.zeros((N, 3), device=DEV); dpg = torch.zeros(N, device=DEV); nhg = torch.ones(N, device=DEV)
+        _lib.check(_lib.lib().ia_composite_test(_lib.ptr(t(rgbv)), _lib.ptr(t(sig)), _lib.ptr(dg), _lib.ptr(zg), _lib.ptr(ta), len(alive), Ns,
+                                                _lib.ptr(cg), _lib.ptr(dpg), _lib.ptr(nhg), 0.01, _lib.stream()))
+        assert np.abs(cg.cpu().numpy() - col).max() < 2e-5 and np.abs(nhg.cpu().numpy() - nh).max() < 2e-5
+        assert np.abs(dpg.cpu().numpy() - dep).max() < 2e-4
+
+
+def _frame_parity(oracle, model, body, fp, init, pose, transl, res, jit_seed, iters=2):
+    G = 64
+    jit = np.random.RandomState(jit_seed).rand(iters, G ** 3, 3).astype(np.float32)
+    batch = make_batch(DEV, res, pose, transl)
+    rgb, depth, alpha, counter = model.render_image_fast(batch, (res, res), jitter=torch.as_tensor(jit, device=DEV))
+    ow = W.oracle_world(oracle, body, fp, init, pose, transl)
+    ro, rd = syn.make_camera_rays(res)
+    ref = oracle.render_image_fast(ow, ro, rd, jit)
+    rgb, alpha = rgb.reshape(-1, 3).cpu().numpy(), alpha.reshape(-1).cpu().numpy()
+    occ_g = model.renderer.density_grid_test.density_field.cpu().numpy()
+    return rgb, alpha, depth.reshape(-1).cpu().numpy(), counter.reshape(-1).cpu().numpy(), occ_g, ref
+
+
+def test_render_frame_parity_full_pipeline(oracle, gpu_world):
+    """DNeRFModel.render_image_fast end to end (SMPL chain -> precompute -> occupancy
+    build -> fused render loop) vs the oracle: rgb / alpha within 1e-3."""
+    model, body, fp, init, poses, tr = gpu_world
+    for i, res in ((2, 64), (6, 96)):
+        rgb, alpha, depth, counter, occ_g, ref = _frame_parity(oracle, model, body, fp, init, poses[i], tr[i], res, 100 + i)
+        occ_mism = (occ_g != ref["occ"].astype(bool)).mean()
+        assert occ_mism < 2e-4, occ_mism
+        cov = (ref["alpha"] > 0.5).mean()
+        assert cov > 0.02
+        err_rgb = np.abs(rgb - ref["rgb"]).max(1)
+        err_a = np.abs(alpha - ref["alpha"])
+        # discontinuities (occupancy cell flips, alpha<0.01 skips) may move single rays
+        assert (err_rgb > 1e-3).mean() < 2e-3 and (err_a > 1e-3).mean() < 2e-3, ((err_rgb > 1e-3).mean(), err_rgb.max())
+        assert np.median(err_rgb[ref["alpha"] > 0.5]) < 1e-4
+        assert abs(counter.mean() - ref["counter"].mean()) < 0.02 * max(1.0, ref["counter"].mean())
+
+
+def test_render_closure_route_equals_fused_route(gpu_world):
+    model, body, fp, init, poses, tr = gpu_world
+    res = 64
+    batch = make_batch(DEV, res, poses[3], tr[3])
+    jit = torch.rand((2, 64 ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    rgb_f, depth_f, alpha_f, cnt_f = model.render_image_fast(batch, (res, res), jitter=jit)
+    rays = Rays(o=batch["rays_o"], d=batch["rays_d"], near=batch["near"], far=batch["far"])
+    model.deformer.transform_rays_w2s(rays)
+    out = model.renderer.render_test_closure(rays, lambda x, _: model.deformer(x, lambda p, d: model.net_coarse(p, d), True), None)
+    assert torch.allclose(out["rgb_coarse"].reshape(-1, 3), rgb_f.reshape(-1, 3), atol=1e-6)
+    assert torch.allclose(out["alpha_coarse"].reshape(-1), alpha_f.reshape(-1), atol=1e-6)
+    assert torch.equal(out["counter_coarse"].reshape(-1), cnt_f.reshape(-1))
+
+
+def test_config0_identity_pose_8_levels(oracle):
+    """BASELINE configs[0]: 128x128, canonical pose (identity deformer), 8-level grid."""
+    model, body, fp, init = W.build(DEV, 64, 8)
+    pose = np.concatenate([np.zeros(3, np.float32), syn.cano_pose("A_pose")])
+    pose[0] = np.pi  # face the camera
+    transl = np.array([0, 0.15, 5], np.float32)
+    rgb, alpha, depth, counter, occ_g, ref = _frame_parity(oracle, model, body, fp, init, pose, transl, 128, 9)
+    assert (np.abs(rgb - ref["rgb"]).max(1) > 1e-3).mean() < 2e-3
+    assert (np.abs(alpha - ref["alpha"]) > 1e-3).mean() < 2e-3
+    assert (ref["alpha"] > 0.5).mean() > 0.03
+
+
+def test_render_is_idempotent_and_background_linear(gpu_world):
+    """Size-independent properties at the full 512x512 bench size."""
+    model, body, fp, init, poses, tr = gpu_world
+    res = 512
+    batch = make_batch(DEV, res, poses[0], tr[0])
+    jit = torch.rand((5, 64 ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    a = model.render_image_fast(batch, (res, res), jitter=jit)
+    b = model.render_image_fast(make_batch(DEV, res, poses[0], tr[0]), (res, res), jitter=jit)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    batch2 = make_batch(DEV, res, poses[0], tr[0])
+    batch2["bg_color"] = torch.zeros((1, res * res, 3), device=DEV)
+    c = model.render_image_fast(batch2, (res, res), jitter=jit)
+    T = (1 - a[2]).reshape(-1, 1)
+    assert torch.allclose(a[0].reshape(-1, 3) - c[0].reshape(-1, 3), T.expand(-1, 3), atol=1e-6)
+    assert 0.03 < (a[2] > 0.5).float().mean().item() < 0.5
+    assert (a[0] >= 0).all() and (a[0] <= 1 + 1e-5).all()
