@@ -32,7 +32,10 @@ def build(force=False, verbose=False):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "ia_common.h")),
                 os.path.getmtime(os.path.join(HERE, "..", "include", "instantavatar_hip.h"))):
-            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj]
+            # -ffp-contract=off: fused multiply-adds appear only where the sources spell them
+            # (IA_DOT3 / __builtin_fmaf), the same sequence the CPU checker uses
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip", "-c", src,
+                   "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -74,6 +74,12 @@ unsigned long long *ia_prof_units(int id);
 void ia_prof_begin(int id, hipStream_t s);
 void ia_prof_end(int id, hipStream_t s);
 
+// ---- explicit FMA convention --------------------------------------------------
+// Branchy fp32 chains (Broyden root finder, trilinear fetch, marcher) use ONE fixed
+// operation sequence shared with the CPU checker: contraction is switched off in
+// those functions and every `sum + x*y` is an explicit fma into the running sum.
+#define IA_DOT3(a0, b0, a1, b1, a2, b2) __builtin_fmaf((a2), (b2), __builtin_fmaf((a1), (b1), (a0) * (b0)))
+
 // ---- wave helpers -----------------------------------------------------------
 __device__ __forceinline__ int ia_lane() { return threadIdx.x & 63; }
 

@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t *__restrict__ ta
   uint32_t g[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {  // tcnn pos_fract
-    const float pos = xn[d] * scale + 0.5f;
+    const float pos = __builtin_fmaf(xn[d], scale, 0.5f);  // nvcc contracts tcnn's `input * scale + 0.5f`
     const float fl = floorf(pos);
     g[d] = (uint32_t)(int)fl;
     w[d] = pos - fl;

@@ -24,7 +24,7 @@ struct MarchRay {
 
 __device__ __forceinline__ bool march_occupied(const MarchRay &r, const uint32_t *__restrict__ bits, int G,
                                                float t, float &x, float &y, float &z) {
-  x = r.ox + t * r.dx; y = r.oy + t * r.dy; z = r.oz + t * r.dz;
+  x = __builtin_fmaf(t, r.dx, r.ox); y = __builtin_fmaf(t, r.dy, r.oy); z = __builtin_fmaf(t, r.dz, r.oz);
   const int nx = (int)clampf((x - r.cx) * r.sx, 0.0f, G - 1.0f);  // raymarcher.cu:49-51
   const int ny = (int)clampf((y - r.cy) * r.sy, 0.0f, G - 1.0f);
   const int nz = (int)clampf((z - r.cz) * r.sz, 0.0f, G - 1.0f);

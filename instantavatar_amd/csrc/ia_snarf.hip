@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
     for (int j = 0; j < 24; j++) {
       const float w = voxel_w[(size_t)j * n + index];
 #pragma unroll
-      for (int c = 0; c < 12; c++) J[c] += w * tfs[j * 16 + c];
+      for (int c = 0; c < 12; c++) J[c] = __builtin_fmaf(w, tfs[j * 16 + c], J[c]);
     }
     float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index * 12);
     o[0] = make_float4(J[0], J[1], J[2], J[3]);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
     // precompute.cu:66-70
 #pragma unroll
     for (int i0 = 0; i0 < 3; i0++) {
-      const float xi = J[i0 * 4 + 0] * cx + J[i0 * 4 + 1] * cy + J[i0 * 4 + 2] * cz + J[i0 * 4 + 3];
+      const float xi = IA_DOT3(J[i0 * 4 + 0], cx, J[i0 * 4 + 1], cy, J[i0 * 4 + 2], cz) + J[i0 * 4 + 3];
       if (voxel_d) voxel_d[(size_t)i0 * n + index] = xi;
       mn[i0] = fminf(mn[i0], xi);
       mx[i0] = fmaxf(mx[i0], xi);
@@ -199,9 +199,9 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
       const float4 *p = reinterpret_cast<const float4 *>(vJ + ((size_t)(zz * g.H + yy) * g.W + xx) * 12);
       const float4 a = p[0], b = p[1], c = p[2];
       const float w = wgt[k];
-      out[0] += a.x * w; out[1] += a.y * w; out[2] += a.z * w; out[3] += a.w * w;
-      out[4] += b.x * w; out[5] += b.y * w; out[6] += b.z * w; out[7] += b.w * w;
-      out[8] += c.x * w; out[9] += c.y * w; out[10] += c.z * w; out[11] += c.w * w;
+      const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int q = 0; q < 12; q++) out[q] = __builtin_fmaf(v[q], w, out[q]);
     }
   }
 }
@@ -211,13 +211,13 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
                                             float g2) {
   const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
               J21 = Ji[7], J22 = Ji[8];
-  const float c0 = J00 * x0 + J10 * x1 + J20 * x2;
-  const float c1 = J01 * x0 + J11 * x1 + J21 * x2;
-  const float c2 = J02 * x0 + J12 * x1 + J22 * x2;
-  const float s = c0 * g0 + c1 * g1 + c2 * g2;
-  const float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
-  const float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
-  const float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
+  const float c0 = IA_DOT3(J00, x0, J10, x1, J20, x2);
+  const float c1 = IA_DOT3(J01, x0, J11, x1, J21, x2);
+  const float c2 = IA_DOT3(J02, x0, J12, x1, J22, x2);
+  const float s = IA_DOT3(c0, g0, c1, g1, c2, g2);
+  const float r0 = IA_DOT3(-J00, g0, -J01, g1, -J02, g2);
+  const float r1 = IA_DOT3(-J10, g0, -J11, g1, -J12, g2);
+  const float r2 = IA_DOT3(-J20, g0, -J21, g1, -J22, g2);
   Ji[0] += c0 * (r0 + x0) / s; Ji[1] += c1 * (r0 + x0) / s; Ji[2] += c2 * (r0 + x0) / s;
   Ji[3] += c0 * (r1 + x1) / s; Ji[4] += c1 * (r1 + x1) / s; Ji[5] += c2 * (r1 + x1) / s;
   Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
@@ -233,15 +233,15 @@ __device__ __forceinline__ bool broyden_solve(const float *__restrict__ vJ, cons
                                               int &fetches) {
   // :287-293  x0 = R^T (xd - t)
   const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
-  float xl0 = ixd * T[0] + iyd * T[4] + izd * T[8];
-  float xl1 = ixd * T[1] + iyd * T[5] + izd * T[9];
-  float xl2 = ixd * T[2] + iyd * T[6] + izd * T[10];
+  float xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
+  float xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
+  float xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
   float Jl[12];
   fetch_J(vJ, g, g.scl[0] * (xl0 + g.off[0]), g.scl[1] * (xl1 + g.off[1]), g.scl[2] * (xl2 + g.off[2]), Jl);
   float Ji[9] = {Jl[0], Jl[4], Jl[8], Jl[1], Jl[5], Jl[9], Jl[2], Jl[6], Jl[10]};  // transpose :302-311
-  float gx0 = Jl[0] * xl0 + Jl[1] * xl1 + Jl[2] * xl2 + Jl[3];
-  float gx1 = Jl[4] * xl0 + Jl[5] * xl1 + Jl[6] * xl2 + Jl[7];
-  float gx2 = Jl[8] * xl0 + Jl[9] * xl1 + Jl[10] * xl2 + Jl[11];
+  float gx0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3];
+  float gx1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7];
+  float gx2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11];
   gx0 = gx0 - t0; gx1 = gx1 - t1; gx2 = gx2 - t2;
   bool valid = false;
   fetches = 1;
@@ -249,18 +249,18 @@ __device__ __forceinline__ bool broyden_solve(const float *__restrict__ vJ, cons
     fetches++;
     const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
                 J21 = Ji[7], J22 = Ji[8];
-    const float u0 = -J00 * gx0 + -J01 * gx1 + -J02 * gx2;
-    const float u1 = -J10 * gx0 + -J11 * gx1 + -J12 * gx2;
-    const float u2 = -J20 * gx0 + -J21 * gx1 + -J22 * gx2;
+    const float u0 = IA_DOT3(-J00, gx0, -J01, gx1, -J02, gx2);
+    const float u1 = IA_DOT3(-J10, gx0, -J11, gx1, -J12, gx2);
+    const float u2 = IA_DOT3(-J20, gx0, -J21, gx1, -J22, gx2);
     xl0 += u0; xl1 += u1; xl2 += u2;
     const float ix = g.scl[0] * (xl0 + g.off[0]);
     const float iy = g.scl[1] * (xl1 + g.off[1]);
     const float iz = g.scl[2] * (xl2 + g.off[2]);
     fetch_J(vJ, g, ix, iy, iz, Jl);
-    const float n0 = Jl[0] * xl0 + Jl[1] * xl1 + Jl[2] * xl2 + Jl[3] - t0;
-    const float n1 = Jl[4] * xl0 + Jl[5] * xl1 + Jl[6] * xl2 + Jl[7] - t1;
-    const float n2 = Jl[8] * xl0 + Jl[9] * xl1 + Jl[10] * xl2 + Jl[11] - t2;
-    const float norm = n0 * n0 + n1 * n1 + n2 * n2;
+    const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
+    const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
+    const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
+    const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
     if (norm < cvg2) {
       valid = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
       if (valid) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_search(
     for (int j = init + 1; j < n_init; j++) {
       if (!s_valid[j][lane]) continue;
       const float d0 = x[0] - s_x[j][lane][0], d1 = x[1] - s_x[j][lane][1], d2 = x[2] - s_x[j][lane][2];
-      const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+      const float dist = IA_DOT3(d0, d0, d1, d1, d2, d2);
       if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
     }
   }

