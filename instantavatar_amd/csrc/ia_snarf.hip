@@ -3,9 +3,9 @@
 //   k_smpl_tfs      a1/a2  SMPL joint chain -> bone transforms (one wave)
 //   k_precompute    a3     blended 3x4 transforms per skinning voxel, written
 //                          channel-LAST so a trilinear corner is 48 contiguous B
-//   k_search        a4+a5  Broyden root finding (one wave = 64 points x one init
-//                          bone, n_init waves per workgroup), duplicate filter and
-//                          ballot/prefix-sum compaction of the surviving roots
+//   k_search        a4+a5  Broyden root finding with lane refill (a workgroup owns
+//                          128 points x n_init solves as an LDS queue), duplicate
+//                          filter and ballot/prefix-sum compaction of the roots
 //
 // Reference semantics: fast_snarf/cuda/precompute/precompute.cu:24-71,
 // fuse_kernel/fuse_cuda_kernel_fast.cu:23-55,62-108,110-248,252-413,
@@ -225,67 +225,26 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 
 struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
 
-// One (point, init) solve.  Returns validity; x_out = root, Ji_out = J_inv before
-// the last rank-1 update (what the reference stores, :383-391).
-__device__ __forceinline__ bool broyden_solve(const float *__restrict__ vJ, const float *__restrict__ T,
-                                              const SnarfGridDev &g, float t0, float t1, float t2,
-                                              float cvg2, float dvg2, float *x_out, float *Ji_out,
-                                              int &fetches) {
-  // :287-293  x0 = R^T (xd - t)
-  const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
-  float xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
-  float xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
-  float xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
-  float Jl[12];
-  fetch_J(vJ, g, g.scl[0] * (xl0 + g.off[0]), g.scl[1] * (xl1 + g.off[1]), g.scl[2] * (xl2 + g.off[2]), Jl);
-  float Ji[9] = {Jl[0], Jl[4], Jl[8], Jl[1], Jl[5], Jl[9], Jl[2], Jl[6], Jl[10]};  // transpose :302-311
-  float gx0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3];
-  float gx1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7];
-  float gx2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11];
-  gx0 = gx0 - t0; gx1 = gx1 - t1; gx2 = gx2 - t2;
-  bool valid = false;
-  fetches = 1;
-  for (int i = 0; i < 10; i++) {
-    fetches++;
-    const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
-                J21 = Ji[7], J22 = Ji[8];
-    const float u0 = IA_DOT3(-J00, gx0, -J01, gx1, -J02, gx2);
-    const float u1 = IA_DOT3(-J10, gx0, -J11, gx1, -J12, gx2);
-    const float u2 = IA_DOT3(-J20, gx0, -J21, gx1, -J22, gx2);
-    xl0 += u0; xl1 += u1; xl2 += u2;
-    const float ix = g.scl[0] * (xl0 + g.off[0]);
-    const float iy = g.scl[1] * (xl1 + g.off[1]);
-    const float iz = g.scl[2] * (xl2 + g.off[2]);
-    fetch_J(vJ, g, ix, iy, iz, Jl);
-    const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
-    const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
-    const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
-    const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
-    if (norm < cvg2) {
-      valid = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
-      if (valid) {
-        x_out[0] = xl0; x_out[1] = xl1; x_out[2] = xl2;
-        if (Ji_out) {
-          Ji_out[0] = J00; Ji_out[1] = J01; Ji_out[2] = J02; Ji_out[3] = J10; Ji_out[4] = J11;
-          Ji_out[5] = J12; Ji_out[6] = J20; Ji_out[7] = J21; Ji_out[8] = J22;
-        }
-      }
-      break;
-    } else if (norm > dvg2) {
-      break;
-    }
-    jinv_update(Ji, u0, u1, u2, n0 - gx0, n1 - gx1, n2 - gx2);
-    gx0 = n0; gx1 = n1; gx2 = n2;
-  }
-  return valid;
-}
+// ---------------------------------------------------------------------------
+// a4 + a5 search kernel with LANE REFILL.
+//
+// Broyden trip counts are very uneven (most (point, init) pairs diverge at the
+// first check after 2 grid fetches, roots need 3..11), so a lane-per-solve
+// mapping leaves most of a wave idle while its slowest lane iterates.  Here a
+// workgroup owns NP points x n_init solves as a queue in LDS; every lane runs a
+// small state machine whose loop body is ONE trilinear fetch, and a lane whose
+// solve terminated pulls the next item (wave ballot + one LDS atomic per wave).
+// Items are ordered init-major / point-minor, so lanes refilled together start
+// from neighbouring canonical positions.  Each solve executes exactly the
+// arithmetic sequence of the reference kernel (fuse_cuda_kernel_fast.cu:268-412).
+// Afterwards the workgroup runs the duplicate filter and either writes the dense
+// reference layout (MODE 0) or compacts the surviving roots (MODE 1).
+// ---------------------------------------------------------------------------
+#define IA_SEARCH_NP 128       // points per workgroup
+#define IA_SEARCH_THREADS 256  // 4 waves
 
-// Workgroup = 64 points x n_init waves (blockDim = (64, n_init)).  Every wave
-// runs one init bone for 64 consecutive points, so the lanes of a wave start
-// from neighbouring canonical positions and gather neighbouring voxels.
-// MODE 0: dense outputs (reference layout).  MODE 1: compacted candidates.
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_search(
+__global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
     const float *__restrict__ xd, int P, const int32_t *__restrict__ n_pts_dev,
     const float *__restrict__ vJ, const float *__restrict__ tfs, BoneIds bones, int n_init, SnarfGridDev g,
     float cvg2, float dvg2,
@@ -295,74 +254,172 @@ __global__ __launch_bounds__(1024) void k_search(
     // MODE 1
     float *__restrict__ cand_xc, int cand_cap, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
     int32_t *__restrict__ n_cand, unsigned long long *prof) {
-  __shared__ float s_x[IA_N_INIT_MAX][64][3];
-  __shared__ uint8_t s_valid[IA_N_INIT_MAX][64];
-  __shared__ uint8_t s_keep[IA_N_INIT_MAX][64];
-  __shared__ int s_base[64];
+  constexpr int NP = IA_SEARCH_NP;
+  __shared__ float s_x[IA_N_INIT_MAX][NP][3];
+  __shared__ float s_xd[NP][3];
+  __shared__ uint8_t s_valid[IA_N_INIT_MAX][NP];
+  __shared__ uint8_t s_keep[IA_N_INIT_MAX][NP];
+  __shared__ int s_base[NP];
+  __shared__ int s_wtot[IA_SEARCH_THREADS / 64];
+  __shared__ int s_next;
+  __shared__ int s_blockbase;
   if (n_pts_dev) P = min(P, *n_pts_dev);
-  const int lane = threadIdx.x, init = threadIdx.y;
-  const int p0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int p0 = blockIdx.x * NP;
   if (p0 >= P) return;  // uniform per workgroup
-  const int p = p0 + lane;
-  const bool live = p < P;
-  float x[3] = {0.f, 0.f, 0.f};
+  const int np = min(NP, P - p0);
+  const int n_items = np * n_init;
+  if (tid == 0) s_next = 0;
+  for (int e = tid; e < np * 3; e += IA_SEARCH_THREADS) (&s_xd[0][0])[e] = xd[(size_t)p0 * 3 + e];
+  __syncthreads();
+
+  // ---- lane state machine ----
+  bool active = false, first = false;
+  int item = 0, iter = 0, fetches = 0, solves = 0;
+  float t0 = 0, t1 = 0, t2 = 0, xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
   float Ji[9];
-  bool ok = false;
-  int fetches = 0;
-  if (live) {
-    const float t0 = xd[(size_t)p * 3], t1 = xd[(size_t)p * 3 + 1], t2 = xd[(size_t)p * 3 + 2];
-    const float *T = tfs + bones.id[init] * 16;
-    ok = broyden_solve(vJ, T, g, t0, t1, t2, cvg2, dvg2, x, (MODE == 0 && J_inv) ? Ji : nullptr, fetches);
+#pragma unroll
+  for (int k = 0; k < 9; k++) Ji[k] = 0.f;
+  bool queue_empty = false;
+  while (true) {
+    if (!queue_empty) {
+      const unsigned long long need = __ballot(!active);
+      if (need) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_next, __popcll(need));
+        base = __shfl(base, 0, 64);
+        if (base >= n_items) queue_empty = true;
+        const int my = base + __popcll(need & ((1ull << lane) - 1ull));
+        if (!active && my < n_items) {
+          item = my;
+          const int init = my / np, pt = my - init * np;
+          t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
+          const float *T = tfs + bones.id[init] * 16;
+          // :287-293  x0 = R^T (xd - t)
+          const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
+          xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
+          xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
+          xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
+          active = true; first = true; iter = 0; solves++;
+        }
+      }
+    }
+    if (!__any(active)) break;
+    if (active) {
+      const float ix = g.scl[0] * (xl0 + g.off[0]);
+      const float iy = g.scl[1] * (xl1 + g.off[1]);
+      const float iz = g.scl[2] * (xl2 + g.off[2]);
+      float Jl[12];
+      fetch_J(vJ, g, ix, iy, iz, Jl);
+      fetches++;
+      bool done = false, ok = false;
+      if (first) {
+        // :302-311 J_inv0 = (J_3x3)^T ; :325-332 g(x0)
+        Ji[0] = Jl[0]; Ji[1] = Jl[4]; Ji[2] = Jl[8]; Ji[3] = Jl[1]; Ji[4] = Jl[5]; Ji[5] = Jl[9];
+        Ji[6] = Jl[2]; Ji[7] = Jl[6]; Ji[8] = Jl[10];
+        gx0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3];
+        gx1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7];
+        gx2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11];
+        gx0 = gx0 - t0; gx1 = gx1 - t1; gx2 = gx2 - t2;
+        first = false;
+      } else {
+        // :356-398 residual at the updated point, convergence / divergence tests
+        const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
+        const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
+        const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
+        const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
+        if (norm < cvg2) {
+          done = true;
+          ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+        } else if (norm > dvg2) {
+          done = true;
+        } else {
+          jinv_update(Ji, u0, u1, u2, n0 - gx0, n1 - gx1, n2 - gx2);  // :400-411
+          gx0 = n0; gx1 = n1; gx2 = n2;
+          if (++iter == 10) done = true;  // Q1: not converged after 10 iterations -> invalid
+        }
+      }
+      if (done) {
+        const int init = item / np, pt = item - init * np;
+        s_x[init][pt][0] = ok ? xl0 : 0.f; s_x[init][pt][1] = ok ? xl1 : 0.f; s_x[init][pt][2] = ok ? xl2 : 0.f;
+        s_valid[init][pt] = ok;
+        if (MODE == 0 && J_inv) {
+          // Q4: the stored J_inv is the matrix BEFORE the last rank-1 update (:383-391)
+          const size_t o = ((size_t)(p0 + pt) * n_init + init) * 9;
+#pragma unroll
+          for (int k = 0; k < 9; k++) J_inv[o + k] = ok ? Ji[k] : 0.f;
+        }
+        active = false;
+      } else {
+        // :340-351 update = -J_inv g ; x += update (start of the next iteration)
+        u0 = IA_DOT3(-Ji[0], gx0, -Ji[1], gx1, -Ji[2], gx2);
+        u1 = IA_DOT3(-Ji[3], gx0, -Ji[4], gx1, -Ji[5], gx2);
+        u2 = IA_DOT3(-Ji[6], gx0, -Ji[7], gx1, -Ji[8], gx2);
+        xl0 += u0; xl1 += u1; xl2 += u2;
+      }
+    }
   }
-  if (prof) {  // bench-only accounting: solves and trilinear fetches per wave
-    int f = fetches, n = live ? 1 : 0;
+  if (prof) {  // bench-only accounting: solves and trilinear fetches
+    int f = fetches, n = solves;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); }
     if (lane == 0) { atomicAdd(prof, (unsigned long long)n); atomicAdd(prof + 1, (unsigned long long)f); }
   }
-  s_x[init][lane][0] = x[0]; s_x[init][lane][1] = x[1]; s_x[init][lane][2] = x[2];
-  s_valid[init][lane] = ok;
   __syncthreads();
-  // a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4
-  bool keep = ok;
-  if (ok) {
-    for (int j = init + 1; j < n_init; j++) {
-      if (!s_valid[j][lane]) continue;
-      const float d0 = x[0] - s_x[j][lane][0], d1 = x[1] - s_x[j][lane][1], d2 = x[2] - s_x[j][lane][2];
-      const float dist = IA_DOT3(d0, d0, d1, d1, d2, d2);
-      if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
+  // ---- a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4 ----
+  for (int q = tid; q < n_items; q += IA_SEARCH_THREADS) {
+    const int init = q / np, pt = q - init * np;
+    bool keep = s_valid[init][pt];
+    if (keep) {
+      const float x0 = s_x[init][pt][0], x1 = s_x[init][pt][1], x2 = s_x[init][pt][2];
+      for (int j = init + 1; j < n_init; j++) {
+        if (!s_valid[j][pt]) continue;
+        const float d0 = x0 - s_x[j][pt][0], d1 = x1 - s_x[j][pt][1], d2 = x2 - s_x[j][pt][2];
+        const float dist = IA_DOT3(d0, d0, d1, d1, d2, d2);
+        if ((double)dist < 0.0001 * 0.0001) { keep = false; break; }
+      }
     }
-  }
-  if (MODE == 0) {
-    if (live) {
-      const size_t o = (size_t)p * n_init + init;
-      // the reference leaves x zero unless converged AND inside the grid (:376-392)
-      xc[o * 3] = ok ? x[0] : 0.f; xc[o * 3 + 1] = ok ? x[1] : 0.f; xc[o * 3 + 2] = ok ? x[2] : 0.f;
+    s_keep[init][pt] = keep;
+    if (MODE == 0) {
+      const size_t o = (size_t)(p0 + pt) * n_init + init;
+      xc[o * 3] = s_x[init][pt][0]; xc[o * 3 + 1] = s_x[init][pt][1]; xc[o * 3 + 2] = s_x[init][pt][2];
       valid_out[o] = keep;
-      if (valid_raw) valid_raw[o] = ok;
-      if (J_inv) for (int k = 0; k < 9; k++) J_inv[o * 9 + k] = ok ? Ji[k] : 0.f;
+      if (valid_raw) valid_raw[o] = s_valid[init][pt];
     }
-    return;
   }
-  s_keep[init][lane] = keep;
+  if (MODE == 0) return;
   __syncthreads();
-  if (init == 0) {  // wave 0: per-point counts, wave scan, one atomic per wave
-    int cnt = 0;
-    for (int j = 0; j < n_init; j++) cnt += s_keep[j][lane];
-    int total;
-    const int excl = ia_wave_excl_scan(cnt, total);
-    int base = 0;
-    if (lane == 0 && total > 0) base = atomicAdd(n_cand, total);
-    base = __shfl(base, 0, 64);
-    s_base[lane] = base + excl;
-    if (live) { pt_off[p] = base + excl; pt_cnt[p] = (uint8_t)cnt; }
+  // ---- compaction: per-point counts, workgroup scan, ONE global atomic ----
+  int cnt = 0;
+  if (tid < np)
+    for (int j = 0; j < n_init; j++) cnt += s_keep[j][tid];
+  int wtot;
+  const int excl = ia_wave_excl_scan(cnt, wtot);
+  if (lane == 0) s_wtot[tid >> 6] = wtot;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < IA_SEARCH_THREADS / 64; w++) { const int c = s_wtot[w]; s_wtot[w] = tot; tot += c; }
+    s_blockbase = tot > 0 ? atomicAdd(n_cand, tot) : 0;
   }
   __syncthreads();
-  if (keep) {
+  if (tid < np) {
+    const int b = s_blockbase + s_wtot[tid >> 6] + excl;
+    s_base[tid] = b;
+    pt_off[p0 + tid] = b;
+    pt_cnt[p0 + tid] = (uint8_t)cnt;
+  }
+  __syncthreads();
+  for (int q = tid; q < n_items; q += IA_SEARCH_THREADS) {
+    const int init = q / np, pt = q - init * np;
+    if (!s_keep[init][pt]) continue;
     int rank = 0;
-    for (int j = 0; j < init; j++) rank += s_keep[j][lane];
-    const int o = s_base[lane] + rank;
-    if (o < cand_cap) { cand_xc[(size_t)o * 3] = x[0]; cand_xc[(size_t)o * 3 + 1] = x[1]; cand_xc[(size_t)o * 3 + 2] = x[2]; }
+    for (int j = 0; j < init; j++) rank += s_keep[j][pt];
+    const int o = s_base[pt] + rank;
+    if (o < cand_cap) {
+      cand_xc[(size_t)o * 3] = s_x[init][pt][0]; cand_xc[(size_t)o * 3 + 1] = s_x[init][pt][1];
+      cand_xc[(size_t)o * 3 + 2] = s_x[init][pt][2];
+    }
   }
 }
 
@@ -414,7 +471,7 @@ extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, con
   IA_CHECK_ARG(xd && voxel_J && tfs && grid && xc && valid, "ia_snarf_search: null pointer");
   BoneIds b;
   IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search: bad bone ids / n_init=%d", n_init);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, 64)), dim3(64, n_init), 0,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0,
                      (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
                      ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
                      valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
@@ -437,7 +494,7 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
   BoneIds b;
   IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search_compact: bad bone ids / n_init=%d", n_init);
   ia_prof_begin(IA_PROF_SEARCH, s);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), dim3(ia_div_up(P, 64)), dim3(64, n_init), 0, s, xd, P,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0, s, xd, P,
                      n_pts_dev, voxel_J, tfs, b, n_init, ia_make_grid_dev(grid), cvg_thresh * cvg_thresh,
                      dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr,
                      (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand, ia_prof_units(IA_PROF_SEARCH));
