@@ -66,6 +66,10 @@ typedef struct ia_field {
   const uint16_t *table;
   const uint16_t *sig_w1, *sig_w2;
   const uint16_t *col_w1, *col_w2, *col_w3;
+  /* optional: MFMA weight-fragment image built by ia_field_prepare from the five
+   * matrices above (ia_field_frags_bytes() bytes); NULL = built inside every
+   * field kernel launch (slower).  Must be rebuilt whenever the weights change. */
+  const uint16_t *mlp_frags;
 } ia_field;
 
 /* Occupancy grid (models/structures/density_grid.py): G^3 cells over aabb.   */
@@ -150,6 +154,8 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
 int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
                  const ia_field *field, float *rgb, float *sigma,
                  void *stream);
+size_t ia_field_frags_bytes(void);
+int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream);
 /* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */
 int ia_hashgrid_fwd(const float *x, int V, const ia_field *field,
                     uint16_t *feat, void *stream);

@@ -28,7 +28,7 @@ class HashDesc(C.Structure):
 class Field(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("scale", C.c_float * 3), ("hash", HashDesc),
                 ("table", C.c_void_p), ("sig_w1", C.c_void_p), ("sig_w2", C.c_void_p),
-                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p)]
+                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p), ("mlp_frags", C.c_void_p)]
 
 
 class OccGrid(C.Structure):
@@ -50,6 +50,8 @@ _SIGS = {
                                           C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, C.c_int32, _VP, _VP,
                                           _VP, C.c_int, _VP]),
     "ia_field_fwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP]),
+    "ia_field_frags_bytes": (C.c_size_t, []),
+    "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
     "ia_hashgrid_fwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP]),
     "ia_candidate_max": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_float, C.c_int, _VP, _VP, _VP]),
     "ia_raymarch_test": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), _VP, C.c_int,

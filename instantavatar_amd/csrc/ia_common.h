@@ -57,6 +57,7 @@ struct FieldDev {
   HashLevelsDev lv;
   const uint32_t *table;  // half2 per entry
   const uint16_t *sig_w1, *sig_w2, *col_w1, *col_w2, *col_w3;
+  const uint16_t *frags;  // prebuilt MFMA A-fragment image or null
 };
 int ia_make_field_dev(const ia_field *f, FieldDev *out);
 

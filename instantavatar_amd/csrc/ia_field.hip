@@ -58,6 +58,7 @@ int ia_make_field_dev(const ia_field *f, FieldDev *o) {
   o->table = reinterpret_cast<const uint32_t *>(f->table);
   o->sig_w1 = f->sig_w1; o->sig_w2 = f->sig_w2;
   o->col_w1 = f->col_w1; o->col_w2 = f->col_w2; o->col_w3 = f->col_w3;
+  o->frags = f->mlp_frags;
   return 0;
 }
 
@@ -177,10 +178,17 @@ __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int 
   const int waves_total = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
   if (blockIdx.x * 4 >= n_tiles) return;  // whole workgroup idle
-  // build the A fragments once per workgroup
-  for (int e = threadIdx.x; e < N_FRAG * 64 * 8; e += 256) {
-    const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
-    reinterpret_cast<_Float16 *>(&s_frag[f][l])[p] = frag_value<L>(F, f, l & 31, l >> 5, p);
+  // A fragments: copy the prebuilt image (ia_field_prepare) or build it here
+  if (F.frags) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(F.frags);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_frag[0][0]);
+#pragma unroll
+    for (int e = threadIdx.x; e < N_FRAG * 64; e += 256) dst[e] = src[e];
+  } else {
+    for (int e = threadIdx.x; e < N_FRAG * 64 * 8; e += 256) {
+      const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
+      reinterpret_cast<_Float16 *>(&s_frag[f][l])[p] = frag_value<L>(F, f, l & 31, l >> 5, p);
+    }
   }
   __syncthreads();
   const int h = lane >> 5, j = lane & 31;
@@ -250,6 +258,33 @@ __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int 
       }
     }
   }
+}
+
+// Builds the MFMA A-fragment image [N_FRAG][64 lanes][8 halves] once per weight update.
+template <int L>
+__global__ __launch_bounds__(256) void k_build_frags(FieldDev F, uint16_t *__restrict__ out) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N_FRAG * 64 * 8; e += gridDim.x * blockDim.x) {
+    const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
+    union { uint16_t u; _Float16 h; } c;
+    c.h = frag_value<L>(F, f, l & 31, l >> 5, p);
+    out[e] = c.u;
+  }
+}
+
+extern "C" size_t ia_field_frags_bytes(void) { return (size_t)N_FRAG * 64 * 8 * 2; }
+
+extern "C" int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream) {
+  IA_CHECK_ARG(frags_out, "ia_field_prepare: null output");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_field_prepare: bad field descriptor (%d)", rc);
+  F.frags = nullptr;
+  if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<16>), dim3(44), dim3(256), 0, (hipStream_t)stream, F, frags_out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<8>), dim3(44), dim3(256), 0, (hipStream_t)stream, F, frags_out);
+  IA_LAUNCH_CHECK("k_build_frags");
+  return IA_OK;
 }
 
 // Encoding only: feat fp16 [V,32] level-major (tcnn output order).

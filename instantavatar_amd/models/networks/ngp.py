@@ -118,6 +118,12 @@ class NeRFNGPNet(nn.Module):
             f.col_w1 = c
             f.col_w2 = c + 2 * COL_W1
             f.col_w3 = c + 2 * (COL_W1 + COL_W2)
+            f.mlp_frags = None
+            # MFMA weight fragments: rebuilt only when the fp16 shadow changed
+            L = _lib.lib()
+            self._frags = torch.empty(L.ia_field_frags_bytes() // 2, dtype=torch.float16, device=enc.device)
+            _lib.check(L.ia_field_prepare(C.byref(f), _lib.ptr(self._frags), _lib.stream()), "ia_field_prepare")
+            f.mlp_frags = self._frags.data_ptr()
             self._desc = f
         return self._desc
 
