@@ -8,6 +8,8 @@ The fixture pins oracle.smpl_forward / batch_rodrigues / batch_rigid_transform
 ("LBS: call lbs.py directly").
 """
 import importlib.util
+import sys as _sys
+_sys.dont_write_bytecode = True  # never write into /root/reference
 import os
 import sys
 
