@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
+    ap.add_argument("--train-steps", type=int, default=30, help="training iterations timed after the render loop (0 = skip)")
     return ap.parse_args()
 
 
@@ -66,6 +67,63 @@ def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
     return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d full %dx%d frames (occupancy build + render) through oracle/ (C + OpenMP, fp32)" % (n_frames, res, res),
             "seconds": dt}
+
+
+def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, n_rays=4096):
+    """train.py analogue (configs 2/4): one frame + 4096 rays per step and rank
+    (confs/sampler/patch.yaml: 4 x 32 x 32), targets rendered from the synthetic field,
+    Adam(lr 1e-2), occupancy update every 20 steps, gradient all-reduce over RCCL."""
+    from instantavatar_amd.pipeline import build_synthetic_model, make_batch
+    from instantavatar_amd.training import NeRFLoss, configure_optimizer, training_step
+    n_frames = 4
+    targets = []
+    with torch.no_grad():
+        for f in range(n_frames):
+            b = make_batch(dev, res, poses[f], tr[f])
+            rgb, _, alpha, _ = model.render_image_fast(b, (res, res))
+            targets.append((b, rgb.reshape(1, -1, 3), alpha.reshape(1, -1)))
+    trainee, _, _ = build_synthetic_model(dev, resolution=128, n_levels=16)
+    trainee.net_coarse.reset_parameters()   # identical seed on every rank -> identical replicas
+    trainee.train()
+    opt = configure_optimizer(trainee)
+    loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def step(i):
+        b, rgb, alpha = targets[(i + rank) % n_frames]
+        sel = torch.randint(0, res * res, (n_rays,), device=dev, generator=g)
+        batch = dict(b)
+        for k in ("rays_o", "rays_d"):
+            batch[k] = b[k][:, sel]
+        for k in ("near", "far"):
+            batch[k] = b[k][:, sel]
+        batch["rgb"], batch["alpha"] = rgb[:, sel], alpha[:, sel]
+        batch["bg_color"] = torch.ones_like(batch["rgb"])
+        return training_step(trainee, batch, opt, loss_fn, world_size=world_size)
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    if world_size > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    first = last = None
+    for i in range(n_steps):
+        out = step(3 + i)
+        if i == 0:
+            first = out["mse_loss"].detach()
+        last = out["mse_loss"].detach()
+    torch.cuda.synchronize()
+    if world_size > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"it_per_sec": n_steps / dt, "rays_per_sec": n_steps * n_rays * world_size / dt, "steps": n_steps,
+            "rays_per_step_per_gpu": n_rays, "mse_first": float(first), "mse_last": float(last),
+            "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
 def main():
@@ -179,6 +237,8 @@ def main():
     }
     if roof is not None:
         result["roofline"] = roof
+    if args.train_steps > 0:
+        result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res)
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:
         result["cpu_baseline"] = cpu_baseline(body, fp, model, poses, tr, res, args.cpu_frames)
     if rank == 0:

@@ -154,6 +154,18 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
 int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
                  const ia_field *field, float *rgb, float *sigma,
                  void *stream);
+/* Training-mode forward (what tcnn does under autograd, ngp.py:78,81): same
+ * outputs plus the fp16 activation record per sample, ia_field_act_stride()
+ * halves: [features 2L | h1 64 | sigma-net out 16 | c1 64 | c2 64].          */
+int ia_field_act_stride(int n_levels);
+int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb,
+                       float *sigma, uint16_t *acts, void *stream);
+/* Hash-grid backward (tcnn kernel_grid_backward): dtable fp32 [n_entries,2]
+ * += interpolation weight * dfeat [V,2L] (fp32 atomics; caller zero-fills).
+ * dx: optional [V,3] gradient w.r.t. the (un-normalised) input positions
+ * (tcnn kernel_grid_backward_input), needed when SMPL poses are optimised.   */
+int ia_hashgrid_bwd(const float *x, int V, const ia_field *field, const float *dfeat,
+                    float *dtable, float *dx, void *stream);
 size_t ia_field_frags_bytes(void);
 int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream);
 /* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */

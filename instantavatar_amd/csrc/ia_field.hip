@@ -165,11 +165,30 @@ __device__ __forceinline__ half8 pack_slab(const floatx16 &acc, int sub) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
-template <int L>
+// activation record written in training mode (fp16, IA_ACT_STRIDE halves per sample):
+//   [0,2L) hash features | h1 (64) | sigma-net output (16) | c1 (64) | c2 (64)
+template <int G8>
+__device__ __forceinline__ void save_rows(uint16_t *__restrict__ dst, const floatx16 &acc, int h, bool relu) {
+  // C/D rows (r&3)+8(r>>2)+4h: four consecutive rows per register group -> one 8-byte store
+#pragma unroll
+  for (int g = 0; g < G8; g++) {
+    union { _Float16 hh[4]; uint2 u; } c;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float v = acc[4 * g + q];
+      if (relu) v = v < 0.f ? 0.f : v;
+      c.hh[q] = (_Float16)v;
+    }
+    *reinterpret_cast<uint2 *>(dst + 8 * g + 4 * h) = c.u;
+  }
+}
+
+template <int L, bool SAVE>
 __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int V,
                                                const int32_t *__restrict__ n_dev, FieldDev F,
                                                float *__restrict__ rgb, float *__restrict__ sigma,
-                                               unsigned long long *prof) {
+                                               unsigned long long *prof, uint16_t *__restrict__ acts) {
+  constexpr int ACT_STRIDE = 2 * L + 64 + 16 + 64 + 64;
   __shared__ __attribute__((aligned(16))) half8 s_frag[N_FRAG][64];
   if (n_dev) V = min(V, *n_dev);
   if (prof && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(prof, (unsigned long long)V);
@@ -201,6 +220,11 @@ __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int 
     for (int l = 0; l < L; l++)
       feat[l] = encode_level(F.table + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l],
                              F.lv.hashed[l] != 0, xn);
+    if (SAVE && i < V) {
+      uint4 *o = reinterpret_cast<uint4 *>(acts + (size_t)i * ACT_STRIDE);
+#pragma unroll
+      for (int q = 0; q < L / 4; q++) o[q] = make_uint4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
+    }
     // exchange: lane j gives its upper-half levels to lane j+32 and receives that
     // lane's lower-half levels (see header)
 #pragma unroll
@@ -224,17 +248,22 @@ __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int 
           a1[rb] = MFMA(s_frag[F_SIG1 + rb * 2 + s][lane], b.v, a1[rb]);
         }
       }
+      const int o = tile * 64 + cb * 32 + j;
+      uint16_t *arow = SAVE ? acts + (size_t)o * ACT_STRIDE + 2 * L : nullptr;
+      if (SAVE && o < V) { save_rows<4>(arow, a1[0], h, true); save_rows<4>(arow + 32, a1[1], h, true); }
       // ---- sigma net layer 2: [16 x 64] ----
       a2 = (floatx16){0.f};
 #pragma unroll
       for (int s = 0; s < 4; s++)
         a2 = MFMA(s_frag[F_SIG2 + s][lane], (s & 1) ? pack_slab<true>(a1[s >> 1], 1) : pack_slab<true>(a1[s >> 1], 0), a2);
+      if (SAVE && o < V) save_rows<2>(arow + 64, a2, h, false);
       half8 cin = pack_slab<false>(a2, 0);  // out[kk], kk = C/D rows 0..15
       const float sig = (float)cin[0];      // row 0 lives in lanes h == 0
       if (h == 0) cin[0] = (_Float16)1.0f;  // identity-encoding padding constant
       // ---- colour net ----
 #pragma unroll
       for (int rb = 0; rb < 2; rb++) a3[rb] = MFMA(s_frag[F_COL1 + rb][lane], cin, (floatx16){0.f});
+      if (SAVE && o < V) { save_rows<4>(arow + 80, a3[0], h, true); save_rows<4>(arow + 112, a3[1], h, true); }
 #pragma unroll
       for (int rb = 0; rb < 2; rb++) {
         a4[rb] = (floatx16){0.f};
@@ -243,11 +272,11 @@ __global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int 
           a4[rb] = MFMA(s_frag[F_COL2 + rb * 4 + s][lane],
                         (s & 1) ? pack_slab<true>(a3[s >> 1], 1) : pack_slab<true>(a3[s >> 1], 0), a4[rb]);
       }
+      if (SAVE && o < V) { save_rows<4>(arow + 144, a4[0], h, true); save_rows<4>(arow + 176, a4[1], h, true); }
       a5 = (floatx16){0.f};
 #pragma unroll
       for (int s = 0; s < 4; s++)
         a5 = MFMA(s_frag[F_COL3 + s][lane], (s & 1) ? pack_slab<true>(a4[s >> 1], 1) : pack_slab<true>(a4[s >> 1], 0), a5);
-      const int o = tile * 64 + cb * 32 + j;
       if (h == 0 && o < V) {
         sigma[o] = sig;
 #pragma unroll
@@ -306,17 +335,23 @@ __global__ __launch_bounds__(256) void k_hashgrid(const float *__restrict__ x, i
 }
 
 int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb,
-                    float *sigma, hipStream_t s) {
+                    float *sigma, hipStream_t s, uint16_t *acts) {
   if (V <= 0) return IA_OK;
   const int tiles = (V + 63) / 64;
   int blocks = (tiles + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   unsigned long long *prof = ia_prof_units(IA_PROF_FIELD);
   ia_prof_begin(IA_PROF_FIELD, s);
-  if (F.lv.n_levels == 16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof);
+  uint16_t *na = nullptr;
+  if (acts) {
+    if (F.lv.n_levels == 16)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16, true>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, acts);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8, true>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, acts);
+  } else if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16, false>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, na);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8, false>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, na);
   ia_prof_end(IA_PROF_FIELD, s);
   IA_LAUNCH_CHECK("k_field");
   return IA_OK;
@@ -330,7 +365,107 @@ extern "C" int ia_field_fwd(const float *x, int V, const int32_t *n_dev, const i
   FieldDev F;
   int rc = ia_make_field_dev(field, &F);
   IA_CHECK_ARG(rc == 0, "ia_field_fwd: bad field descriptor (%d)", rc);
-  return ia_launch_field(x, V, n_dev, F, rgb, sigma, (hipStream_t)stream);
+  return ia_launch_field(x, V, n_dev, F, rgb, sigma, (hipStream_t)stream, nullptr);
+}
+
+// Training-mode forward: additionally writes the fp16 activation record per sample.
+extern "C" int ia_field_act_stride(int n_levels) { return 2 * n_levels + 64 + 16 + 64 + 64; }
+
+extern "C" int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb, float *sigma,
+                                  uint16_t *acts, void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_field_fwd_train: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(x && rgb && sigma && acts, "ia_field_fwd_train: null pointer");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_field_fwd_train: bad field descriptor (%d)", rc);
+  return ia_launch_field(x, V, nullptr, F, rgb, sigma, (hipStream_t)stream, acts);
+}
+
+// ---------------------------------------------------------------------------
+// Hash-grid backward (tcnn kernel_grid_backward / kernel_grid_backward_input):
+// dL/dtable[entry][f] += w_corner * dL/dfeat[level][f]   (fp32 atomics)
+// dL/dx (optional)     = sum_levels scale_l * sum_corners dw/dpos * <val, dfeat>
+// One lane = one sample; the level loop is wave-uniform.
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ x, int V, FieldDev F,
+                                                      const float *__restrict__ dfeat,
+                                                      float *__restrict__ dtable, float *__restrict__ dx) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    float xn[3];
+    normalise(F, x, (size_t)i, xn);
+    float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < L; l++) {
+      const float scale = F.lv.scale[l];
+      const uint32_t res = F.lv.res[l], size = F.lv.size[l];
+      const bool hashed = F.lv.hashed[l] != 0;
+      const uint32_t *tab = F.table + F.lv.offset[l];
+      float *dtab = dtable + (size_t)F.lv.offset[l] * 2;
+      const float d0 = dfeat[(size_t)i * (2 * L) + 2 * l], d1 = dfeat[(size_t)i * (2 * L) + 2 * l + 1];
+      float w[3];
+      uint32_t g[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const float pos = __builtin_fmaf(xn[d], scale, 0.5f);
+        const float fl = floorf(pos);
+        g[d] = (uint32_t)(int)fl;
+        w[d] = pos - fl;
+      }
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++) {
+        const uint32_t cx = g[0] + (idx & 1), cy = g[1] + ((idx >> 1) & 1), cz = g[2] + ((idx >> 2) & 1);
+        uint32_t index;
+        if (hashed) {
+          index = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1);
+        } else {
+          index = cx + cy * res + cz * res * res;
+          if (index >= size) index -= size;
+          index = min(index, size - 1);
+        }
+        const float wx = (idx & 1) ? w[0] : 1.f - w[0], wy = (idx & 2) ? w[1] : 1.f - w[1], wz = (idx & 4) ? w[2] : 1.f - w[2];
+        const float wt = wx * wy * wz;
+        if (d0 != 0.f) unsafeAtomicAdd(dtab + (size_t)index * 2, wt * d0);
+        if (d1 != 0.f) unsafeAtomicAdd(dtab + (size_t)index * 2 + 1, wt * d1);
+        if (dx) {
+          union { uint32_t u; half2v h; } c;
+          c.u = tab[index];
+          const float dot = (float)c.h.x * d0 + (float)c.h.y * d1;
+          const float sx = (idx & 1) ? 1.f : -1.f, sy = (idx & 2) ? 1.f : -1.f, sz = (idx & 4) ? 1.f : -1.f;
+          gx[0] += scale * sx * wy * wz * dot;
+          gx[1] += scale * wx * sy * wz * dot;
+          gx[2] += scale * wx * wy * sz * dot;
+        }
+      }
+    }
+    if (dx) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        // d xn / d x = 1/scale inside the unit cube, 0 where the clamp is active (ngp.py:75-77)
+        const float raw = (x[(size_t)i * 3 + d] - F.center[d]) / F.scale[d] + 0.5f;
+        dx[(size_t)i * 3 + d] = (raw > 0.f && raw < 1.f) ? gx[d] / F.scale[d] : 0.f;
+      }
+    }
+  }
+}
+
+extern "C" int ia_hashgrid_bwd(const float *x, int V, const ia_field *field, const float *dfeat, float *dtable,
+                               float *dx, void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_hashgrid_bwd: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(x && dfeat && dtable, "ia_hashgrid_bwd: null pointer");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_hashgrid_bwd: bad field descriptor (%d)", rc);
+  int blocks = (V + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F, dfeat, dtable, dx);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F, dfeat, dtable, dx);
+  IA_LAUNCH_CHECK("k_hashgrid_bwd");
+  return IA_OK;
 }
 
 extern "C" int ia_hashgrid_fwd(const float *x, int V, const ia_field *field, uint16_t *feat, void *stream) {

@@ -9,7 +9,7 @@
 #include "ia_common.h"
 
 int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb,
-                    float *sigma, hipStream_t s);
+                    float *sigma, hipStream_t s, uint16_t *acts);
 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
 
@@ -687,7 +687,7 @@ static int query_impl(const float *pts, int P, const int32_t *n_pts_dev, const f
   int rc = ia_snarf_search_compact(pts, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, 1e-5f, 1e-1f,
                                    q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, 1, s);
   if (rc) return rc;
-  return ia_launch_field(q.cand_xc, q.cand_cap, q.n_cand, F, q.cand_rgb, q.cand_sigma, s);
+  return ia_launch_field(q.cand_xc, q.cand_cap, q.n_cand, F, q.cand_rgb, q.cand_sigma, s, nullptr);
 }
 
 extern "C" int ia_deform_query(const float *pts, int P, const int32_t *n_pts_dev, const float *voxel_J,

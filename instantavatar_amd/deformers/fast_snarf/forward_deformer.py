@@ -125,7 +125,7 @@ class ForwardDeformer(torch.nn.Module):
         Training adds the implicit-differentiation term of deformer_torch.py:50-67
         (version 1) or the closed-form inverse skinning of :68-75 (version 2)."""
         need_grad = (not eval_mode) and tfs.requires_grad
-        xc, others = self.search(xd, cond, tfs, eval_mode=True, want_J_inv=need_grad or not eval_mode)
+        xc, others = self.search(xd, cond, tfs, eval_mode=True, want_J_inv=need_grad)
         if eval_mode:
             return xc, others
         mask = others["valid_ids"]

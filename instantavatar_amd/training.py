@@ -1,0 +1,165 @@
+"""Training-side glue of the hot path (rows a7/a8/a15/a17 of SURVEY.md section 8).
+
+* `field_autograd`: NeRFNGPNet under autograd (what tcnn's torch binding does at
+  ngp.py:78,81).  Forward = the fused HIP kernel in training mode
+  (`ia_field_fwd_train`, identical outputs + fp16 activation record); backward =
+  MLP weight/input gradients as plain GEMMs over the saved activations (rocBLAS
+  via torch.matmul, fp32) and the hash-table scatter-add as the HIP kernel
+  `ia_hashgrid_bwd` (fp32 atomics; tcnn accumulates in fp16 under a 1024x loss
+  scale, DNeRF.py:58 -- fp32 needs no scaling, the GradScaler stays functional).
+* `NeRFLoss`: instant_avatar/utils/loss.py:53-77.
+* `training_step`: DNeRFModel.training_step (models/DNeRF.py:112-161) without
+  Lightning; `all_reduce_grads` is the data-parallel extension (RCCL over xGMI,
+  one flat bucket per parameter tensor: 52 MB hash-table gradient + 2 small ones).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .deformers import _opt
+
+
+class _FieldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, enc_params, col_params, net):
+        L = _lib.lib()
+        xc = x.detach().reshape(-1, 3).float().contiguous()
+        V = xc.shape[0]
+        stride = L.ia_field_act_stride(net.n_levels)
+        acts = torch.empty((V, stride), device=x.device, dtype=torch.float16)
+        rgb = torch.empty((V, 3), device=x.device)
+        sigma = torch.empty(V, device=x.device)
+        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, C.byref(net.field_desc()), _lib.ptr(rgb), _lib.ptr(sigma),
+                                        _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
+        ctx.net = net
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(xc, acts, rgb)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        net = ctx.net
+        xc, acts, rgb = ctx.saved_tensors
+        V = xc.shape[0]
+        nf = 2 * net.n_levels
+        enc_h, col_h = net._half_params()
+        W1 = enc_h[:net.sig_w1_size].float().view(64, nf)
+        W2 = enc_h[net.sig_w1_size:net.sig_w1_size + 1024].float().view(16, 64)
+        Wc1 = col_h[:1024].float().view(64, 16)
+        Wc2 = col_h[1024:5120].float().view(64, 64)
+        Wc3 = col_h[5120:6144].float().view(16, 64)
+        a = acts.float()
+        feat, h1, o16 = a[:, :nf], a[:, nf:nf + 64], a[:, nf + 64:nf + 80]
+        c1, c2 = a[:, nf + 80:nf + 144], a[:, nf + 144:nf + 208]
+        cin = torch.cat([o16[:, 1:], torch.ones_like(o16[:, :1])], dim=1)  # colour input: out[1:16] + padding 1
+        d_rgb = d_rgb.reshape(V, 3).float()
+        d_sigma = d_sigma.reshape(V).float()
+        dY = torch.zeros((V, 16), device=xc.device)
+        dY[:, :3] = d_rgb * rgb * (1 - rgb)  # sigmoid'
+        dWc3 = dY.t() @ c2
+        dC2 = (dY @ Wc3) * (c2 > 0)
+        dWc2 = dC2.t() @ c1
+        dC1 = (dC2 @ Wc2) * (c1 > 0)
+        dWc1 = dC1.t() @ cin
+        dcin = dC1 @ Wc1
+        dO = torch.cat([d_sigma[:, None], dcin[:, :15]], dim=1)
+        dW2 = dO.t() @ h1
+        dH1 = (dO @ W2) * (h1 > 0)
+        dW1 = dH1.t() @ feat
+        dfeat = (dH1 @ W1).contiguous()
+        g_enc = torch.zeros_like(net.encoder.params)
+        g_enc[:net.sig_w1_size] = dW1.reshape(-1)
+        g_enc[net.sig_w1_size:net.sig_w1_size + 1024] = dW2.reshape(-1)
+        dtable = g_enc[net.sig_w1_size + 1024:]
+        dx = torch.empty((V, 3), device=xc.device) if ctx.need_dx else None
+        _lib.check(_lib.lib().ia_hashgrid_bwd(_lib.ptr(xc), V, C.byref(net.field_desc()), _lib.ptr(dfeat),
+                                              dtable.data_ptr(), _lib.ptr(dx), _lib.stream()), "ia_hashgrid_bwd")
+        g_col = torch.cat([dWc1.reshape(-1), dWc2.reshape(-1), dWc3.reshape(-1)])
+        return dx, g_enc, g_col, None
+
+
+def field_autograd(net, x):
+    return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net)
+
+
+class NeRFLoss(torch.nn.Module):
+    """instant_avatar/utils/loss.py:53-77"""
+
+    def __init__(self, opt=None):
+        super().__init__()
+        self.w_rgb = _opt.get(opt, "w_rgb", 1.0)
+        self.w_alpha = _opt.get(opt, "w_alpha", 0.1)
+        self.w_reg = _opt.get(opt, "w_reg", 0.1)
+
+    def forward(self, predicts, targets):
+        OFFSET = 0.313262
+        ent = lambda v: (-torch.log(torch.exp(-v) + torch.exp(v - 1))).mean() + OFFSET
+        losses = {"mse_loss": F.mse_loss(predicts["rgb_coarse"], targets["rgb"], reduction="mean"),
+                  "loss_alpha_coarse": F.mse_loss(predicts["alpha_coarse"], targets["alpha"]),
+                  "reg_alpha": ent(predicts["alpha_coarse"]), "reg_density": ent(predicts["weight_coarse"])}
+        losses["loss"] = (self.w_rgb * losses["mse_loss"] + self.w_alpha * losses["loss_alpha_coarse"] +
+                          self.w_reg * losses["reg_alpha"] + self.w_reg * losses["reg_density"])
+        return losses
+
+
+def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
+    """DNeRFModel.configure_optimizers (DNeRF.py:32-59): one Adam, hash encoding and
+    the rest in separate groups, GradScaler(1024) kept for interface parity."""
+    enc, rest = [], []
+    for name, p in model.named_parameters():
+        (enc if "encoder" in name else rest).append(p)
+    opt = torch.optim.Adam([{"params": enc}, {"params": rest}], lr=lr, betas=betas, eps=eps)
+    return opt
+
+
+def all_reduce_grads(model, world_size):
+    """Data-parallel gradient averaging: one RCCL all-reduce per parameter tensor
+    (the 52 MB hash-table gradient is ONE flat bucket; xGMI is point-to-point, so
+    few large collectives beat many small ones)."""
+    if world_size <= 1:
+        return
+    import torch.distributed as dist
+    for p in model.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            p.grad.div_(world_size)
+
+
+def update_density_grid(model, world_size=1):
+    """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the
+    cached densities are MAX-reduced so that every rank thresholds the same field."""
+    N = 20
+    if model.global_step % N != 0:
+        return None
+    grid = model.renderer.density_grid_train
+    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step)
+    if world_size > 1:
+        from .parallel import reduce_density_cache
+        reduce_density_cache(grid.density_cached, world_size)
+        grid._postprocess(grid.density_cached)
+    reg = N * density[~valid].mean()
+    if model.global_step < 500:
+        reg = reg + 0.5 * density.mean()
+    return reg
+
+
+def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False):
+    """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs."""
+    model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
+    model.deformer.prepare_deformer(batch)
+    reg = update_density_grid(model, world_size)
+    model.net_coarse.initialize(model.deformer.bbox)
+    use_noise = model.global_step < 1000 and not is_refine
+    predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
+    losses = loss_fn(predicts, batch)
+    if reg is not None and not is_refine:
+        losses["reg"] = reg
+        losses["loss"] = losses["loss"] + reg
+    optimizer.zero_grad(set_to_none=True)
+    losses["loss"].backward()
+    all_reduce_grads(model, world_size)
+    optimizer.step()
+    model.global_step += 1
+    return losses
