@@ -58,6 +58,9 @@ struct FieldDev {
   const uint32_t *table;  // half2 per entry
   const uint16_t *sig_w1, *sig_w2, *col_w1, *col_w2, *col_w3;
   const uint16_t *frags;  // prebuilt MFMA A-fragment image or null
+  // set when all hashed levels have the same size and follow each other (tcnn default):
+  // level l >= n_dense lives at table + hash_base + (l - n_dense) * hash_size
+  uint32_t n_dense, hash_base, hash_size;
 };
 int ia_make_field_dev(const ia_field *f, FieldDev *out);
 

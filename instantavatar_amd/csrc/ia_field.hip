@@ -59,6 +59,15 @@ int ia_make_field_dev(const ia_field *f, FieldDev *o) {
   o->sig_w1 = f->sig_w1; o->sig_w2 = f->sig_w2;
   o->col_w1 = f->col_w1; o->col_w2 = f->col_w2; o->col_w3 = f->col_w3;
   o->frags = f->mlp_frags;
+  // uniform-hash pattern (lets the kernel derive per-level pointers instead of holding 16 of them)
+  uint32_t nd = 0;
+  while ((int)nd < L && !o->lv.hashed[nd]) nd++;
+  bool uni = (int)nd < L;
+  for (int l = nd; l < L && uni; l++)
+    uni = o->lv.hashed[l] && o->lv.size[l] == o->lv.size[nd] && o->lv.offset[l] == o->lv.offset[nd] + (l - nd) * o->lv.size[nd];
+  o->n_dense = nd;
+  o->hash_base = uni ? o->lv.offset[nd] : 0;
+  o->hash_size = uni ? o->lv.size[nd] : 0;
   return 0;
 }
 
@@ -107,11 +116,28 @@ __device__ __forceinline__ void normalise(const FieldDev &F, const float *__rest
   }
 }
 
+// ---------------------------------------------------------------------------
 // One level of the hash grid for one sample -> packed (f0,f1) half2.
-__device__ __forceinline__ uint32_t encode_level(const uint32_t *__restrict__ tab, float scale,
-                                                 uint32_t res, uint32_t size, bool hashed,
-                                                 const float xn[3]) {
-  float w[3];
+//
+// The cost of the encoding on gfx950 is the number of L1 (TCP) accesses: a 64-lane
+// gather of 4-byte entries is served at ~1 lane per clock per CU, so the 16 x 8
+// corner reads of a sample set the kernel's roofline.  Three access paths keep the
+// reference arithmetic (same corner order, same half accumulation) while cutting
+// the access count from 128 to ~80 per sample:
+//   KIND 0  level table staged in LDS (the two coarsest dense levels, 70 KB);
+//   KIND 1  dense level in global memory: the x-neighbours (cx, cx+1) are adjacent
+//           entries -> ONE 8-byte load per corner pair;
+//   KIND 2  hashed level: for even cx the pair differs only in index bit 0 -> one
+//           aligned 8-byte load; odd cx adds a 4-byte load for the second corner.
+// ---------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) U2A4 { uint32_t x, y; };
+
+// Raw corner data of one level: v[8] (+ ext[4], meta for hashed levels), resolved later by
+// level_reduce so that no load result is consumed inside the issue phase.
+template <int KIND>
+__device__ __forceinline__ void level_loads(const uint32_t *__restrict__ tab, float scale, uint32_t res,
+                                            uint32_t size, const float xn[3], float w[3], uint32_t lo[4],
+                                            uint32_t hi[4], uint32_t ext[4], uint32_t &meta) {
   uint32_t g[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {  // tcnn pos_fract
@@ -120,20 +146,48 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t *__restrict__ ta
     g[d] = (uint32_t)(int)fl;
     w[d] = pos - fl;
   }
-  uint32_t v[8];
+  meta = 0;
+  if (KIND == 2) {
+    // hashed level (coherent prime hash, 2^k entries): eight independent 4-byte gathers.
+    // (Merging the (cx, cx+1) pair of even cx into one aligned 8-byte slot saves 25 % of the
+    // L1 accesses but needs a predicated second load; the register cost of deferring its
+    // select spilled the 16-level kernel -- measured slower, see DESIGN.md.)
 #pragma unroll
-  for (int idx = 0; idx < 8; idx++) {
-    const uint32_t cx = g[0] + (idx & 1), cy = g[1] + ((idx >> 1) & 1), cz = g[2] + ((idx >> 2) & 1);
-    uint32_t index;
-    if (hashed) {
-      index = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1);
-    } else {
-      index = cx + cy * res + cz * res * res;  // < 2*size for clamped inputs
-      if (index >= size) index -= size;
-      index = min(index, size - 1);  // memory safety for non-finite inputs
+    for (int pr = 0; pr < 4; pr++) {
+      const uint32_t cy = g[1] + (pr & 1), cz = g[2] + (pr >> 1);
+      const uint32_t hsh = (cy * 2654435761u) ^ (cz * 805459861u);
+      lo[pr] = tab[(g[0] ^ hsh) & (size - 1)];
+      hi[pr] = tab[((g[0] + 1) ^ hsh) & (size - 1)];
+      ext[pr] = 0u;
     }
-    v[idx] = tab[index];
+    return;
   }
+  const uint32_t tab0 = (KIND == 1) ? tab[0] : 0u;  // wave-uniform: entry 0 (wrap target of the last entry)
+#pragma unroll
+  for (int pr = 0; pr < 4; pr++) {  // corner pairs (cx, cx+1) at fixed (cy, cz): idx = 2*pr, 2*pr+1
+    const uint32_t cy = g[1] + (pr & 1), cz = g[2] + (pr >> 1);
+    uint32_t i0 = g[0] + cy * res + cz * res * res;  // < 2*size for clamped inputs (tcnn: index % size)
+    if (i0 >= size) i0 -= size;
+    i0 = min(i0, size - 1);  // memory safety for non-finite inputs
+    ext[pr] = 0u;
+    if (KIND == 0) {         // LDS-resident level
+      uint32_t i1 = i0 + 1;
+      if (i1 >= size) i1 -= size;
+      lo[pr] = tab[i0];
+      hi[pr] = tab[i1];
+    } else {                 // dense level in global memory: ONE 8-byte load per x-neighbour pair
+      const bool last = i0 == size - 1;  // only at the clamped border: i1 wraps to entry 0
+      const U2A4 pair = *reinterpret_cast<const U2A4 *>(tab + (last ? size - 2 : i0));
+      lo[pr] = pair.x;
+      hi[pr] = pair.y;
+      if (last) { meta |= 1u << pr; ext[pr] = tab0; meta |= 32u; }
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t level_reduce(const float w[3], const uint32_t lo[4], const uint32_t hi[4],
+                                                 const uint32_t ext[4], uint32_t meta) {
   _Float16 r0 = (_Float16)0.f, r1 = (_Float16)0.f;
 #pragma unroll
   for (int idx = 0; idx < 8; idx++) {
@@ -141,14 +195,82 @@ __device__ __forceinline__ uint32_t encode_level(const uint32_t *__restrict__ ta
     wt *= (idx & 1) ? w[0] : 1.f - w[0];
     wt *= (idx & 2) ? w[1] : 1.f - w[1];
     wt *= (idx & 4) ? w[2] : 1.f - w[2];
+    const int pr = idx >> 1;
+    uint32_t raw;
+    if (KIND != 1) {
+      raw = (idx & 1) ? hi[pr] : lo[pr];
+    } else {
+      // (lo/hi are separate arrays on purpose: `sel ? a[1] : a[0]` would be turned into a
+      // dynamically indexed -- i.e. scratch -- access)
+      const bool sel = (meta >> pr) & 1u;  // dense: pair wrapped around the end of the level
+      const uint32_t c0 = sel ? hi[pr] : lo[pr];
+      const uint32_t c1 = sel ? ext[pr] : hi[pr];
+      raw = (idx & 1) ? c1 : c0;
+    }
     union { uint32_t u; half2v h; } c;
-    c.u = v[idx];
+    c.u = raw;
     r0 = r0 + (_Float16)(wt * (float)c.h.x);
     r1 = r1 + (_Float16)(wt * (float)c.h.y);
   }
   union { uint32_t u; half2v h; } o;
   o.h.x = r0; o.h.y = r1;
   return o.u;
+}
+
+// Encodes levels [L0, L0+N) of one sample.  All corner loads of the group are issued
+// before the first use (straight-line code, no data-dependent control flow), so the
+// group's gathers overlap.  NLDS: leading levels resident in LDS; NDENSE: number of
+// dense (non-hashed) levels; NDENSE < 0: decide per level at run time (generic tables).
+template <int L0, int N, int NLDS, int NDENSE>
+__device__ __forceinline__ void encode_group(const FieldDev &F, const uint32_t *__restrict__ lds_tab,
+                                             const float xn[3], uint32_t *__restrict__ feat) {
+  float w[N][3];
+  uint32_t lo[N][4], hi[N][4], ext[N][4], meta[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int l = L0 + k;
+    const uint32_t *gt = F.table + F.lv.offset[(NDENSE >= 0 && l >= NDENSE) ? 0 : l];
+    if (l < NLDS) level_loads<0>(lds_tab + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l], xn, w[k], lo[k], hi[k], ext[k], meta[k]);
+    else if (NDENSE >= 0 ? (l < NDENSE) : !F.lv.hashed[l]) level_loads<1>(gt, F.lv.scale[l], F.lv.res[l], F.lv.size[l], xn, w[k], lo[k], hi[k], ext[k], meta[k]);
+    else if (NDENSE >= 0)  // uniform hashed levels: pointer and size derived, not stored per level
+      level_loads<2>(F.table + F.hash_base + (uint32_t)(l - NDENSE) * F.hash_size, F.lv.scale[l], 0u, F.hash_size, xn,
+                     w[k], lo[k], hi[k], ext[k], meta[k]);
+    else level_loads<2>(gt, F.lv.scale[l], F.lv.res[l], F.lv.size[l], xn, w[k], lo[k], hi[k], ext[k], meta[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int l = L0 + k;
+    if (l < NLDS) feat[l] = level_reduce<0>(w[k], lo[k], hi[k], ext[k], meta[k]);
+    else if (NDENSE >= 0 ? (l < NDENSE) : !F.lv.hashed[l]) feat[l] = level_reduce<1>(w[k], lo[k], hi[k], ext[k], meta[k]);
+    else feat[l] = level_reduce<2>(w[k], lo[k], hi[k], ext[k], meta[k]);
+  }
+}
+
+template <int L, int NLDS, int NDENSE>
+__device__ __forceinline__ void encode_all(const FieldDev &F, const uint32_t *__restrict__ lds_tab,
+                                           const float xn[3], uint32_t *__restrict__ feat) {
+  // groups of IA_ENC_GROUP levels: all gathers of a group are in flight together; the group
+  // size is bounded by the register file (each level holds 12 raw words until it is reduced).
+  // sched_barrier keeps the compiler from hoisting the next group's loads above this group's
+  // reduction (which would spill).
+#ifndef IA_ENC_GROUP
+#define IA_ENC_GROUP 8
+#endif
+#pragma unroll
+  for (int g0 = 0; g0 < L; g0 += IA_ENC_GROUP) {
+    switch (g0) {  // compile-time after unrolling
+      case 0: encode_group<0, IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 2: encode_group<2, IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 4: encode_group<4, IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 6: encode_group<6, IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 8: encode_group<(L > 8 ? 8 : 0), IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 10: encode_group<(L > 8 ? 10 : 0), IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 12: encode_group<(L > 8 ? 12 : 0), IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+      case 14: encode_group<(L > 8 ? 14 : 0), IA_ENC_GROUP, NLDS, NDENSE>(F, lds_tab, xn, feat); break;
+    }
+    asm volatile("" ::: "memory");  // loads of the next group stay below this group's reduction
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <bool RELU>
@@ -183,43 +305,57 @@ __device__ __forceinline__ void save_rows(uint16_t *__restrict__ dst, const floa
   }
 }
 
-template <int L, bool SAVE>
-__global__ __launch_bounds__(256) void k_field(const float *__restrict__ x, int V,
+#ifndef IA_FIELD_THREADS
+#define IA_FIELD_THREADS 768
+#endif
+#define IA_FIELD_WAVES (IA_FIELD_THREADS / 64)
+
+template <int L, bool SAVE, int NLDS, int NDENSE>
+__global__ __launch_bounds__(IA_FIELD_THREADS) void k_field(const float *__restrict__ x, int V,
                                                const int32_t *__restrict__ n_dev, FieldDev F,
                                                float *__restrict__ rgb, float *__restrict__ sigma,
-                                               unsigned long long *prof, uint16_t *__restrict__ acts) {
+                                               unsigned long long *prof, uint16_t *__restrict__ acts,
+                                               int lds_entries) {
   constexpr int ACT_STRIDE = 2 * L + 64 + 16 + 64 + 64;
-  __shared__ __attribute__((aligned(16))) half8 s_frag[N_FRAG][64];
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  half8 (*s_frag)[64] = reinterpret_cast<half8 (*)[64]>(s_dyn);
+  const uint32_t *s_tab = reinterpret_cast<const uint32_t *>(s_dyn + N_FRAG * 64 * 16);
   if (n_dev) V = min(V, *n_dev);
   if (prof && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(prof, (unsigned long long)V);
   const int n_tiles = (V + 63) >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int waves_total = gridDim.x * 4;
-  int tile = blockIdx.x * 4 + wave;
-  if (blockIdx.x * 4 >= n_tiles) return;  // whole workgroup idle
+  // tiles go round-robin over workgroups first (one workgroup per CU), then over its waves:
+  // a small launch still spreads over all 256 CUs
+  const int tile_stride = gridDim.x * IA_FIELD_WAVES;
+  int tile = blockIdx.x + wave * gridDim.x;
+  if ((int)blockIdx.x >= n_tiles) return;  // whole workgroup idle
+  // stage the coarsest dense levels (entries [0, lds_entries) of the table) in LDS
+  {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_dyn + N_FRAG * 64 * 16);
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(F.table);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+    for (int e = threadIdx.x; e < lds_entries / 4; e += IA_FIELD_THREADS) dst4[e] = src4[e];
+  }
   // A fragments: copy the prebuilt image (ia_field_prepare) or build it here
   if (F.frags) {
     const uint4 *src = reinterpret_cast<const uint4 *>(F.frags);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_frag[0][0]);
 #pragma unroll
-    for (int e = threadIdx.x; e < N_FRAG * 64; e += 256) dst[e] = src[e];
+    for (int e = threadIdx.x; e < N_FRAG * 64; e += IA_FIELD_THREADS) dst[e] = src[e];
   } else {
-    for (int e = threadIdx.x; e < N_FRAG * 64 * 8; e += 256) {
+    for (int e = threadIdx.x; e < N_FRAG * 64 * 8; e += IA_FIELD_THREADS) {
       const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
       reinterpret_cast<_Float16 *>(&s_frag[f][l])[p] = frag_value<L>(F, f, l & 31, l >> 5, p);
     }
   }
   __syncthreads();
   const int h = lane >> 5, j = lane & 31;
-  for (; tile < n_tiles; tile += waves_total) {
+  for (; tile < n_tiles; tile += tile_stride) {
     const int i = tile * 64 + lane;
     float xn[3] = {0.f, 0.f, 0.f};
     if (i < V) normalise(F, x, (size_t)i, xn);
     uint32_t feat[L];
-#pragma unroll
-    for (int l = 0; l < L; l++)
-      feat[l] = encode_level(F.table + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l],
-                             F.lv.hashed[l] != 0, xn);
+    encode_all<L, NLDS, NDENSE>(F, s_tab, xn, feat);
     if (SAVE && i < V) {
       uint4 *o = reinterpret_cast<uint4 *>(acts + (size_t)i * ACT_STRIDE);
 #pragma unroll
@@ -324,10 +460,7 @@ __global__ __launch_bounds__(256) void k_hashgrid(const float *__restrict__ x, i
     float xn[3];
     normalise(F, x, (size_t)i, xn);
     uint32_t f[L];
-#pragma unroll
-    for (int l = 0; l < L; l++)
-      f[l] = encode_level(F.table + F.lv.offset[l], F.lv.scale[l], F.lv.res[l], F.lv.size[l],
-                          F.lv.hashed[l] != 0, xn);
+    encode_all<L, 0, -1>(F, nullptr, xn, f);
     uint4 *o = reinterpret_cast<uint4 *>(feat + (size_t)i * L);
 #pragma unroll
     for (int q = 0; q < L / 4; q++) o[q] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
@@ -338,20 +471,37 @@ int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev 
                     float *sigma, hipStream_t s, uint16_t *acts) {
   if (V <= 0) return IA_OK;
   const int tiles = (V + 63) / 64;
-  int blocks = (tiles + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  int blocks = tiles < 256 ? tiles : 256;  // one workgroup per CU; waves loop over tiles
+  // specialisation: leading dense levels (tcnn default: 4), the first two of them staged in LDS
+  int n_dense = 0;
+  while (n_dense < F.lv.n_levels && !F.lv.hashed[n_dense]) n_dense++;
+  bool pattern = n_dense == 4 && F.hash_size != 0 && (int)F.n_dense == n_dense;
+  const int lds_entries = pattern ? (int)((F.lv.offset[2] + 3) / 4 * 4) : 0;
+  pattern = pattern && (size_t)lds_entries * 4 <= 72 * 1024 && F.lv.offset[0] == 0;
+  const size_t shmem = (size_t)N_FRAG * 64 * 16 + (pattern ? (size_t)lds_entries * 4 : 0);
+  static bool attr_done = false;
+  if (!attr_done) {  // > 64 KB of dynamic LDS must be opted into once per kernel
+    const int lim = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field<16, true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field<8, true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field<16, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field<8, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    attr_done = true;
+  }
   unsigned long long *prof = ia_prof_units(IA_PROF_FIELD);
   ia_prof_begin(IA_PROF_FIELD, s);
-  uint16_t *na = nullptr;
-  if (acts) {
-    if (F.lv.n_levels == 16)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16, true>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, acts);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8, true>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, acts);
-  } else if (F.lv.n_levels == 16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<16, false>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, na);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<8, false>), dim3(blocks), dim3(256), 0, s, x, V, n_dev, F, rgb, sigma, prof, na);
+  const dim3 g(blocks), b(IA_FIELD_THREADS);
+  const int L16 = F.lv.n_levels == 16;
+#define IA_LF(LV, SV, NL, ND) \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<LV, SV, NL, ND>), g, b, shmem, s, x, V, n_dev, F, rgb, sigma, prof, acts, pattern ? lds_entries : 0)
+  if (pattern) {
+    if (acts) { if (L16) IA_LF(16, true, 2, 4); else IA_LF(8, true, 2, 4); }
+    else { if (L16) IA_LF(16, false, 2, 4); else IA_LF(8, false, 2, 4); }
+  } else {
+    if (acts) { if (L16) IA_LF(16, true, 0, -1); else IA_LF(8, true, 0, -1); }
+    else { if (L16) IA_LF(16, false, 0, -1); else IA_LF(8, false, 0, -1); }
+  }
+#undef IA_LF
   ia_prof_end(IA_PROF_FIELD, s);
   IA_LAUNCH_CHECK("k_field");
   return IA_OK;
