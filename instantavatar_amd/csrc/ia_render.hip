@@ -330,9 +330,10 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, int n) {
 // coords = (idx/G + rand/G) * (aabb1 - aabb0) + aabb0
 __global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G,
                                                       const float *__restrict__ aabb,
-                                                      float *__restrict__ pts) {
+                                                      float *__restrict__ pts, int32_t *__restrict__ n_cand) {
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_cand = 0;  // candidate counter of the following search
   if (i >= n) return;
   const int idx[3] = {i / (G * G), i / G % G, i % G};
 #pragma unroll
@@ -683,9 +684,9 @@ extern "C" size_t ia_query_workspace_bytes(int P, int n_init) { return query_ws_
 
 static int query_impl(const float *pts, int P, const int32_t *n_pts_dev, const float *voxel_J, const float *tfs,
                       const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid, const FieldDev &F,
-                      const QueryWs &q, hipStream_t s) {
+                      const QueryWs &q, hipStream_t s, int zero_counter = 1) {
   int rc = ia_snarf_search_compact(pts, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, 1e-5f, 1e-1f,
-                                   q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, 1, s);
+                                   q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, zero_counter, s);
   if (rc) return rc;
   return ia_launch_field(q.cand_xc, q.cand_cap, q.n_cand, F, q.cand_rgb, q.cand_sigma, s, nullptr);
 }
@@ -737,8 +738,8 @@ extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const
   const dim3 grd(ia_div_up(n, 256)), blk(256);
   hipLaunchKernelGGL(k_fill_f32, grd, blk, 0, s, density, 0.f, n);  // density_grid.py:98
   for (int it = 0; it < iters; it++) {
-    hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, aabb, pts);
-    rc = query_impl(pts, n, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s);
+    hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, aabb, pts, q.n_cand);
+    rc = query_impl(pts, n, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_candidate_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n,
                        (const int32_t *)nullptr, n_init, 0.f, 1, (float *)nullptr, (float *)nullptr, density);
@@ -784,6 +785,7 @@ extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const fl
   rw.alive_a = w.take<int32_t>(R); rw.alive_b = w.take<int32_t>(R); rw.ray_off = w.take<int32_t>(R); rw.ray_cnt = w.take<int32_t>(R);
   rw.s_pts = w.take<float>((size_t)cap * 3); rw.s_t = w.take<float>(cap);
   rw.q = carve_query(w, cap, n_init);
+  rw.q.n_cand = &rw.st->n_cand;  // zeroed by k_iter_begin: no separate zero-fill launch per iteration
   rw.sample_cap = cap;
   const dim3 blk(256), gR(ia_div_up(R, 256));
   if (!resume) {
@@ -802,7 +804,7 @@ extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const fl
     // ones never more than the first compaction leaves; keep R (idle waves exit).
     hipLaunchKernelGGL(k_march_compact, gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, rw.st, occ_bits,
                        G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap);
-    rc = query_impl(rw.s_pts, cap, &rw.st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s);
+    rc = query_impl(rw.s_pts, cap, &rw.st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_composite_compact, gR, blk, 0, s, cur, nxt, rw.st, rw.ray_off, rw.ray_cnt, rw.s_t, rw.step,
                        rw.q.pt_off, rw.q.pt_cnt, rw.q.cand_rgb, rw.q.cand_sigma, n_init, rw.color, rw.depth, rw.nohit,

@@ -123,38 +123,57 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
                                                     float *__restrict__ voxel_J,
                                                     float *__restrict__ voxel_d,
                                                     float *__restrict__ bbox, SnarfGridDev g) {
+  // 4 consecutive voxels (along W) per thread: one 16-byte load per joint plane and
+  // 192 contiguous bytes of output per thread.  W % 4 == 0 is checked by the host.
   const int n = g.D * g.H * g.W;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < n; index += gridDim.x * blockDim.x) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += gridDim.x * blockDim.x) {
+    const int index0 = q * 4;
+    float J[4][12];
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+#pragma unroll
+      for (int c = 0; c < 12; c++) J[v][c] = 0.f;
+    // precompute.cu:51-59: J[c] accumulates over j in joint order
+#pragma unroll 2
+    for (int j = 0; j < 24; j++) {
+      const float4 w4 = *reinterpret_cast<const float4 *>(voxel_w + (size_t)j * n + index0);
+      const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        const float t = tfs[j * 16 + c];
+#pragma unroll
+        for (int v = 0; v < 4; v++) J[v][c] = __builtin_fmaf(w[v], t, J[v][c]);
+      }
+    }
+    float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index0 * 12);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      o[3 * v + 0] = make_float4(J[v][0], J[v][1], J[v][2], J[v][3]);
+      o[3 * v + 1] = make_float4(J[v][4], J[v][5], J[v][6], J[v][7]);
+      o[3 * v + 2] = make_float4(J[v][8], J[v][9], J[v][10], J[v][11]);
+    }
     const int hw = g.H * g.W;
-    const int idx_d = index / hw;
-    const int idx_h = index % hw / g.W;
-    const int idx_w = index % hw % g.W;
+    const int idx_d = index0 / hw, idx_h = index0 % hw / g.W, idx_w0 = index0 % hw % g.W;
     // precompute.cu:42-47
-    const float cx = (((float)idx_w) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];
     const float cy = (((float)idx_h) / (g.H - 1) * 2 - 1) / g.scl[1] - g.off[1];
     const float cz = (((float)idx_d) / (g.D - 1) * 2 - 1) / g.scl[2] - g.off[2];
-    float J[12];
+    float xi[3][4];
 #pragma unroll
-    for (int c = 0; c < 12; c++) J[c] = 0.f;
-    // precompute.cu:51-59: J[c] accumulates over j in joint order
-#pragma unroll 4
-    for (int j = 0; j < 24; j++) {
-      const float w = voxel_w[(size_t)j * n + index];
+    for (int v = 0; v < 4; v++) {
+      const float cx = (((float)(idx_w0 + v)) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];
+      // precompute.cu:66-70
 #pragma unroll
-      for (int c = 0; c < 12; c++) J[c] = __builtin_fmaf(w, tfs[j * 16 + c], J[c]);
+      for (int i0 = 0; i0 < 3; i0++) {
+        xi[i0][v] = IA_DOT3(J[v][i0 * 4 + 0], cx, J[v][i0 * 4 + 1], cy, J[v][i0 * 4 + 2], cz) + J[v][i0 * 4 + 3];
+        mn[i0] = fminf(mn[i0], xi[i0][v]);
+        mx[i0] = fmaxf(mx[i0], xi[i0][v]);
+      }
     }
-    float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index * 12);
-    o[0] = make_float4(J[0], J[1], J[2], J[3]);
-    o[1] = make_float4(J[4], J[5], J[6], J[7]);
-    o[2] = make_float4(J[8], J[9], J[10], J[11]);
-    // precompute.cu:66-70
+    if (voxel_d) {
 #pragma unroll
-    for (int i0 = 0; i0 < 3; i0++) {
-      const float xi = IA_DOT3(J[i0 * 4 + 0], cx, J[i0 * 4 + 1], cy, J[i0 * 4 + 2], cz) + J[i0 * 4 + 3];
-      if (voxel_d) voxel_d[(size_t)i0 * n + index] = xi;
-      mn[i0] = fminf(mn[i0], xi);
-      mx[i0] = fmaxf(mx[i0], xi);
+      for (int i0 = 0; i0 < 3; i0++)
+        *reinterpret_cast<float4 *>(voxel_d + (size_t)i0 * n + index0) = make_float4(xi[i0][0], xi[i0][1], xi[i0][2], xi[i0][3]);
     }
   }
   if (bbox) {
@@ -444,11 +463,11 @@ extern "C" int ia_smpl_tfs(const float *joints_rest, const int32_t *parents, con
 extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxel_J, float *voxel_d,
                              float *bbox, const ia_snarf_grid *grid, void *stream) {
   IA_CHECK_ARG(voxel_w && tfs && voxel_J && grid, "ia_precompute: null pointer");
-  IA_CHECK_ARG(grid->D > 1 && grid->H > 1 && grid->W > 1, "ia_precompute: bad grid %d %d %d", grid->D, grid->H, grid->W);
+  IA_CHECK_ARG(grid->D > 1 && grid->H > 1 && grid->W > 1 && grid->W % 4 == 0, "ia_precompute: bad grid %d %d %d (W must be a multiple of 4)", grid->D, grid->H, grid->W);
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)grid->D * grid->H * grid->W;
   if (bbox) { hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox); IA_LAUNCH_CHECK("k_bbox_init"); }
-  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_precompute, dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
                      ia_make_grid_dev(grid));
   IA_LAUNCH_CHECK("k_precompute");
