@@ -282,6 +282,43 @@ int ia_transform_rays_w2s(const float *rays_o, const float *rays_d,
                           const float *w2s, int R, float *o_out, float *d_out,
                           float *near, float *far, void *stream);
 
+/* ---- a15 + a8 fused: Raymarcher.render_train over compact samples ----------
+ * (raymarcher_acc.py:140-186, composite :25-36, snarf_deformer.py:143-159).
+ * ia_march_train_compact: raymarch_train + jitter (z = t + jitter*dt, jitter
+ *   [n_rays,max_samples] as torch.rand_like draws it at :156, NULL = 0.5) + compaction:
+ *   s_pts [cap,3], s_z [cap], s_slot [cap] (slot in the dense layout), ray_off/ray_cnt
+ *   [n_rays], n_samples (device int32, zeroed inside).
+ * ia_composite_train_fwd: per sample max over its candidates (invalid = -1e5),
+ *   optional sigma noise, alpha = 1-exp(-relu(sigma)*dt), T = cumprod(1-alpha+1e-10);
+ *   outputs color [n,3] (+T*bg), depth, alpha (= sum w), weights_dense [n,max_samples];
+ *   saves s_arg (winning candidate or -1), s_sigma, s_alpha, s_T for the backward.
+ * ia_composite_train_bwd: gradients w.r.t. the candidates' rgb [n_cand,3] / sigma
+ *   [n_cand] (buffers zero-filled by the caller).                              */
+int ia_march_train_compact(const float *rays_o, const float *rays_d, const float *nears,
+                           const float *fars, int n_rays, const uint32_t *occ_bits,
+                           const ia_occ_grid *occ, int max_samples, const float *jitter,
+                           float *s_pts, float *s_z, int32_t *s_slot, int32_t *ray_off,
+                           int32_t *ray_cnt, int32_t *n_samples, int sample_cap, void *stream);
+int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *pt_off,
+                           const uint8_t *pt_cnt, int n_init, const int32_t *ray_off,
+                           const int32_t *ray_cnt, const float *s_z, const float *nears,
+                           const float *fars, int n_rays, int max_samples, const float *noise,
+                           float noise_scale, const float *bg, float *color, float *depth,
+                           float *alpha, float *weights_dense, const int32_t *s_slot,
+                           int32_t *s_arg, float *s_sigma, float *s_alpha, float *s_T, void *stream);
+int ia_composite_train_bwd(const float *d_color, const float *d_depth, const float *d_alpha,
+                           const float *d_weights, const float *cand_rgb, const int32_t *ray_off,
+                           const int32_t *ray_cnt, const float *s_z, const float *nears,
+                           const float *fars, int n_rays, int max_samples, const float *bg,
+                           const int32_t *s_slot, const int32_t *s_arg, const float *s_sigma,
+                           const float *s_alpha, const float *s_T, float *d_cand_rgb,
+                           float *d_cand_sigma, void *stream);
+
+/* deform_train's max over candidates (snarf_deformer.py:147-158): index of the
+ * winning candidate per point, -1 when an invalid slot (sigma = -1e5) wins.    */
+int ia_candidate_argmax(const float *cand_sigma, const int32_t *pt_off, const uint8_t *pt_cnt,
+                        int P, int n_init, int32_t *arg, void *stream);
+
 /* ---- measurement hooks (bench.py only) --------------------------------------
  * When enabled, every launch of the Broyden-search kernel (id 0) and of the
  * field kernel (id 1) is bracketed by HIP events on the caller's stream and the

@@ -75,6 +75,13 @@ _SIGS = {
                                  C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid), C.POINTER(Field), C.c_int,
                                  C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_transform_rays_w2s": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "ia_march_train_compact": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), C.c_int, _VP, _VP, _VP,
+                                         _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    "ia_composite_train_fwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP,
+                                         C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ia_composite_train_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP,
+                                         _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ia_candidate_argmax": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
     "ia_profile_enable": (C.c_int, [C.c_int]),
     "ia_profile_reset": (C.c_int, []),
     "ia_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),

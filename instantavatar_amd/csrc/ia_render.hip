@@ -827,3 +827,227 @@ extern "C" int ia_transform_rays_w2s(const float *rays_o, const float *rays_d, c
   IA_LAUNCH_CHECK("k_transform_rays");
   return IA_OK;
 }
+
+// ===========================================================================
+// Training-side renderer (rows a15 / a8 of SURVEY.md section 8)
+// ===========================================================================
+// raymarch_train + jitter + sample compaction (raymarcher_acc.py:153-159):
+// every ray marches all `max_samples` slots; occupied slots become compact samples
+// (contiguous per ray, in slot order) with z = t + jitter * dt and p = z * d + o.
+__global__ __launch_bounds__(256) void k_march_train_compact(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
+    const float *__restrict__ fars, int n_rays, const uint32_t *__restrict__ bits, OccDev occ, int max_samples,
+    const float *__restrict__ jitter, float *__restrict__ s_pts, float *__restrict__ s_z,
+    int32_t *__restrict__ s_slot, int32_t *__restrict__ ray_off, int32_t *__restrict__ ray_cnt,
+    int32_t *__restrict__ n_samples, int sample_cap) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((n - ia_lane()) >= n_rays) return;
+  const bool live = n < n_rays;
+  MarchRay r;
+  int cnt = 0;
+  float t0 = 0.f, dt = 0.f;
+  if (live) {
+    t0 = nears[n];
+    dt = (fars[n] - t0) / max_samples;  // step_size (raymarcher_acc.py:147)
+    r.ox = rays_o[(size_t)n * 3]; r.oy = rays_o[(size_t)n * 3 + 1]; r.oz = rays_o[(size_t)n * 3 + 2];
+    r.dx = rays_d[(size_t)n * 3]; r.dy = rays_d[(size_t)n * 3 + 1]; r.dz = rays_d[(size_t)n * 3 + 2];
+    r.cx = occ.mn[0]; r.cy = occ.mn[1]; r.cz = occ.mn[2];
+    r.sx = occ.G / (occ.mx[0] - occ.mn[0]); r.sy = occ.G / (occ.mx[1] - occ.mn[1]); r.sz = occ.G / (occ.mx[2] - occ.mn[2]);
+    r.far = fars[n]; r.dt = dt;
+    float t = t0;
+    while (t < r.far && cnt < max_samples) {
+      float x, y, z;
+      if (march_occupied(r, bits, occ.G, t, x, y, z)) cnt++;  // a slot is consumed even if its depth is <= 0
+      t += dt;
+    }
+  }
+  int total;
+  const int excl = ia_wave_excl_scan(cnt, total);
+  int base = 0;
+  if (ia_lane() == 0 && total > 0) base = atomicAdd(n_samples, total);
+  base = __shfl(base, 0, 64) + excl;
+  if (!live) return;
+  ray_off[n] = base;
+  int s = 0, kept = 0;
+  float t = t0;
+  while (t < r.far && s < cnt) {
+    float x, y, z;
+    if (march_occupied(r, bits, occ.G, t, x, y, z)) {
+      if (t > 0.f) {  // slots with depth <= 0 are masked out by the reference (z_vals > 0)
+        const int o = base + kept;
+        if (o < sample_cap) {
+          const float zj = t + (jitter ? jitter[(size_t)n * max_samples + s] : 0.5f) * dt;
+          s_z[o] = zj;
+          s_slot[o] = s;  // position in the reference's dense [n_rays, max_samples] layout
+          s_pts[(size_t)o * 3] = zj * r.dx + r.ox; s_pts[(size_t)o * 3 + 1] = zj * r.dy + r.oy; s_pts[(size_t)o * 3 + 2] = zj * r.dz + r.oz;
+        }
+        kept++;
+      }
+      s++;
+    }
+    t += dt;
+  }
+  ray_cnt[n] = kept;
+}
+
+// candidate max for training: invalid slots carry -1e5 (snarf_deformer.py:147), no
+// nan_to_num; returns sigma and the index of the winning candidate (-1: an invalid slot won)
+__device__ __forceinline__ void cand_max_train(const float *__restrict__ cand_sigma, int off, int cnt, int n_init,
+                                               float &sg, int &arg) {
+  float best = cnt < n_init ? -1e5f : -INFINITY;
+  arg = -1;
+  for (int c = 0; c < cnt; c++) {
+    const float s = cand_sigma[off + c];
+    if (s > best || (arg < 0 && cnt >= n_init && c == 0)) { best = s; arg = off + c; }
+  }
+  sg = best;
+}
+
+// composite() of raymarcher_acc.py:25-36 + render_train tail (:161-186) over compact samples.
+__global__ __launch_bounds__(256) void k_composite_train_fwd(
+    const float *__restrict__ cand_rgb, const float *__restrict__ cand_sigma, const int32_t *__restrict__ pt_off,
+    const uint8_t *__restrict__ pt_cnt, int n_init, const int32_t *__restrict__ ray_off,
+    const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z, const float *__restrict__ nears,
+    const float *__restrict__ fars, int n_rays, int max_samples, const float *__restrict__ noise, float noise_scale,
+    const float *__restrict__ bg, float *__restrict__ color, float *__restrict__ depth, float *__restrict__ alpha_out,
+    float *__restrict__ weights_dense, const int32_t *__restrict__ s_slot, int32_t *__restrict__ s_arg,
+    float *__restrict__ s_sigma, float *__restrict__ s_alpha, float *__restrict__ s_T) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rays) return;
+  const int off = ray_off[n], cnt = ray_cnt[n];
+  const float dt = (fars[n] - nears[n]) / max_samples;
+  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, asum = 0.f;
+  for (int k = 0; k < max_samples; k++) weights_dense[(size_t)n * max_samples + k] = 0.f;
+  for (int k = 0; k < cnt; k++) {
+    const int s = off + k;
+    float sg; int arg;
+    cand_max_train(cand_sigma, pt_off[s], pt_cnt[s], n_init, sg, arg);
+    if (noise) sg += noise_scale * noise[s];               // raymarcher_acc.py:166-167
+    const float tau = fmaxf(sg, 0.f) * dt;                 // relu(sigma) * dists
+    const float a = 1.0f - expf(-tau);
+    const float w = a * T;
+    s_arg[s] = arg; s_sigma[s] = sg; s_alpha[s] = a; s_T[s] = T;
+    if (arg >= 0) { c0 += w * cand_rgb[(size_t)arg * 3]; c1 += w * cand_rgb[(size_t)arg * 3 + 1]; c2 += w * cand_rgb[(size_t)arg * 3 + 2]; }
+    dep += w * s_z[s];
+    asum += w;
+    weights_dense[(size_t)n * max_samples + s_slot[s]] = w;
+    T = T * (1.0f - a + 1e-10f);                           // cumprod(1 - alpha + 1e-10)
+  }
+  const float b0 = bg ? bg[(size_t)n * 3] : 1.f, b1 = bg ? bg[(size_t)n * 3 + 1] : 1.f, b2 = bg ? bg[(size_t)n * 3 + 2] : 1.f;
+  color[(size_t)n * 3] = c0 + T * b0; color[(size_t)n * 3 + 1] = c1 + T * b1; color[(size_t)n * 3 + 2] = c2 + T * b2;
+  depth[n] = dep;
+  alpha_out[n] = asum;   // alpha_coarse = weights.sum(-1) (:184)
+}
+
+__global__ __launch_bounds__(256) void k_composite_train_bwd(
+    const float *__restrict__ d_color, const float *__restrict__ d_depth, const float *__restrict__ d_alpha,
+    const float *__restrict__ d_weights, const float *__restrict__ cand_rgb, const int32_t *__restrict__ ray_off,
+    const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z, const float *__restrict__ nears,
+    const float *__restrict__ fars, int n_rays, int max_samples, const float *__restrict__ bg,
+    const int32_t *__restrict__ s_slot, const int32_t *__restrict__ s_arg, const float *__restrict__ s_sigma,
+    const float *__restrict__ s_alpha, const float *__restrict__ s_T, float *__restrict__ d_cand_rgb,
+    float *__restrict__ d_cand_sigma) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rays) return;
+  const int off = ray_off[n], cnt = ray_cnt[n];
+  if (cnt == 0) return;
+  const float dt = (fars[n] - nears[n]) / max_samples;
+  const float dc0 = d_color ? d_color[(size_t)n * 3] : 0.f, dc1 = d_color ? d_color[(size_t)n * 3 + 1] : 0.f,
+              dc2 = d_color ? d_color[(size_t)n * 3 + 2] : 0.f;
+  const float dd = d_depth ? d_depth[n] : 0.f, da = d_alpha ? d_alpha[n] : 0.f;
+  const float b0 = bg ? bg[(size_t)n * 3] : 1.f, b1 = bg ? bg[(size_t)n * 3 + 1] : 1.f, b2 = bg ? bg[(size_t)n * 3 + 2] : 1.f;
+  float gT = dc0 * b0 + dc1 * b1 + dc2 * b2;  // dL/dT_end
+  for (int k = cnt - 1; k >= 0; k--) {
+    const int s = off + k;
+    const float a = s_alpha[s], T = s_T[s];
+    const int arg = s_arg[s];
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (arg >= 0) { r0 = cand_rgb[(size_t)arg * 3]; r1 = cand_rgb[(size_t)arg * 3 + 1]; r2 = cand_rgb[(size_t)arg * 3 + 2]; }
+    const float gw = dc0 * r0 + dc1 * r1 + dc2 * r2 + dd * s_z[s] + da + (d_weights ? d_weights[(size_t)n * max_samples + s_slot[s]] : 0.f);
+    const float w = a * T;
+    const float g_alpha = gw * T - gT * T;
+    gT = gw * a + gT * (1.0f - a + 1e-10f);
+    if (arg >= 0) {
+      d_cand_rgb[(size_t)arg * 3] = w * dc0; d_cand_rgb[(size_t)arg * 3 + 1] = w * dc1; d_cand_rgb[(size_t)arg * 3 + 2] = w * dc2;
+      // d alpha / d sigma = exp(-tau) * dt for sigma > 0 (relu), exp(-tau) = 1 - alpha
+      d_cand_sigma[arg] = (s_sigma[s] > 0.f) ? g_alpha * (1.0f - a) * dt : 0.f;
+    }
+  }
+}
+
+extern "C" int ia_march_train_compact(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                                      int n_rays, const uint32_t *occ_bits, const ia_occ_grid *occ, int max_samples,
+                                      const float *jitter, float *s_pts, float *s_z, int32_t *s_slot,
+                                      int32_t *ray_off, int32_t *ray_cnt, int32_t *n_samples, int sample_cap,
+                                      void *stream) {
+  IA_CHECK_ARG(n_rays >= 0 && max_samples > 0, "ia_march_train_compact: bad sizes");
+  IA_CHECK_ARG(n_samples, "ia_march_train_compact: n_samples is null");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, n_samples, 0, 1);
+  if (n_rays == 0) return IA_OK;
+  IA_CHECK_ARG(rays_o && rays_d && nears && fars && occ_bits && occ && s_pts && s_z && s_slot && ray_off && ray_cnt,
+               "ia_march_train_compact: null pointer");
+  hipLaunchKernelGGL(k_march_train_compact, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, s, rays_o, rays_d, nears, fars,
+                     n_rays, occ_bits, make_occ(occ), max_samples, jitter, s_pts, s_z, s_slot, ray_off, ray_cnt,
+                     n_samples, sample_cap);
+  IA_LAUNCH_CHECK("k_march_train_compact");
+  return IA_OK;
+}
+
+extern "C" int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *pt_off,
+                                      const uint8_t *pt_cnt, int n_init, const int32_t *ray_off, const int32_t *ray_cnt,
+                                      const float *s_z, const float *nears, const float *fars, int n_rays,
+                                      int max_samples, const float *noise, float noise_scale, const float *bg,
+                                      float *color, float *depth, float *alpha, float *weights_dense,
+                                      const int32_t *s_slot, int32_t *s_arg, float *s_sigma, float *s_alpha,
+                                      float *s_T, void *stream) {
+  IA_CHECK_ARG(n_rays >= 0 && max_samples > 0, "ia_composite_train_fwd: bad sizes");
+  if (n_rays == 0) return IA_OK;
+  IA_CHECK_ARG(pt_off && pt_cnt && ray_off && ray_cnt && s_z && nears && fars && color && depth && alpha &&
+               weights_dense && s_slot && s_arg && s_sigma && s_alpha && s_T, "ia_composite_train_fwd: null pointer");
+  hipLaunchKernelGGL(k_composite_train_fwd, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, cand_rgb,
+                     cand_sigma, pt_off, pt_cnt, n_init, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, noise,
+                     noise_scale, bg, color, depth, alpha, weights_dense, s_slot, s_arg, s_sigma, s_alpha, s_T);
+  IA_LAUNCH_CHECK("k_composite_train_fwd");
+  return IA_OK;
+}
+
+extern "C" int ia_composite_train_bwd(const float *d_color, const float *d_depth, const float *d_alpha,
+                                      const float *d_weights, const float *cand_rgb, const int32_t *ray_off,
+                                      const int32_t *ray_cnt, const float *s_z, const float *nears, const float *fars,
+                                      int n_rays, int max_samples, const float *bg, const int32_t *s_slot,
+                                      const int32_t *s_arg, const float *s_sigma, const float *s_alpha, const float *s_T,
+                                      float *d_cand_rgb, float *d_cand_sigma, void *stream) {
+  IA_CHECK_ARG(n_rays >= 0 && max_samples > 0, "ia_composite_train_bwd: bad sizes");
+  if (n_rays == 0) return IA_OK;
+  IA_CHECK_ARG(ray_off && ray_cnt && s_z && nears && fars && s_slot && s_arg && s_sigma && s_alpha && s_T && d_cand_rgb &&
+               d_cand_sigma, "ia_composite_train_bwd: null pointer");
+  hipLaunchKernelGGL(k_composite_train_bwd, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, d_color,
+                     d_depth, d_alpha, d_weights, cand_rgb, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, bg,
+                     s_slot, s_arg, s_sigma, s_alpha, s_T, d_cand_rgb, d_cand_sigma);
+  IA_LAUNCH_CHECK("k_composite_train_bwd");
+  return IA_OK;
+}
+
+// arg-max candidate per point for the training path (fill = -1e5 wins -> -1)
+__global__ __launch_bounds__(256) void k_candidate_argmax(const float *__restrict__ cand_sigma,
+                                                          const int32_t *__restrict__ pt_off,
+                                                          const uint8_t *__restrict__ pt_cnt, int P, int n_init,
+                                                          int32_t *__restrict__ arg) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float sg; int a;
+  cand_max_train(cand_sigma, pt_off[p], pt_cnt[p], n_init, sg, a);
+  arg[p] = a;
+}
+
+extern "C" int ia_candidate_argmax(const float *cand_sigma, const int32_t *pt_off, const uint8_t *pt_cnt, int P,
+                                   int n_init, int32_t *arg, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_candidate_argmax: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pt_off && pt_cnt && arg, "ia_candidate_argmax: null pointer");
+  hipLaunchKernelGGL(k_candidate_argmax, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_sigma, pt_off,
+                     pt_cnt, P, n_init, arg);
+  IA_LAUNCH_CHECK("k_candidate_argmax");
+  return IA_OK;
+}

@@ -214,8 +214,49 @@ class SNARFDeformer():
                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_deform_query")
         return rgb, sigma
 
+    def search_compact(self, pts, n_pts_dev=None):
+        """Search + filter + compaction (`ia_snarf_search_compact`): returns a dict with
+        cand_xc [cap,3], pt_off [P], pt_cnt [P] and n_cand (device int32[1])."""
+        pts = pts.detach().reshape(-1, 3).float().contiguous()
+        P = pts.shape[0]
+        k = len(self.deformer.init_bones)
+        dev = pts.device
+        out = dict(cand_xc=torch.empty((P * k, 3), device=dev), pt_off=torch.empty(P, dtype=torch.int32, device=dev),
+                   pt_cnt=torch.empty(P, dtype=torch.uint8, device=dev), n_cand=torch.zeros(1, dtype=torch.int32, device=dev))
+        tfs = self.tfs.detach().float().contiguous()
+        _lib.check(_lib.lib().ia_snarf_search_compact(_lib.ptr(pts), P, _lib.ptr(n_pts_dev), _lib.ptr(self.deformer.voxel_J_cl),
+                                                      _lib.ptr(tfs), self.deformer._bones_c, k,
+                                                      C.byref(self.deformer.grid_desc()), 1e-5, 1e-1, _lib.ptr(out["cand_xc"]),
+                                                      P * k, _lib.ptr(out["pt_off"]), _lib.ptr(out["pt_cnt"]),
+                                                      _lib.ptr(out["n_cand"]), 0, _lib.stream()), "ia_snarf_search_compact")
+        return out
+
+    def query_train_fused(self, pts, net):
+        """deform_train (snarf_deformer.py:143-159) without the dense [P,13,*] temporaries:
+        compacted candidates -> field under autograd -> arg-max gather.  One 4-byte host
+        read (the candidate count sizes the autograd graph)."""
+        P = pts.shape[0]
+        k = len(self.deformer.init_bones)
+        sc = self.search_compact(pts)
+        n_cand = int(sc["n_cand"].item())
+        dev = pts.device
+        if n_cand == 0:
+            return torch.zeros((P, 3), device=dev), torch.full((P,), -1e5, device=dev)
+        rgb_c, sig_c = net(sc["cand_xc"][:n_cand], None)
+        arg = torch.empty(P, dtype=torch.int32, device=dev)
+        sig_d = sig_c.detach().float().contiguous()
+        _lib.check(_lib.lib().ia_candidate_argmax(_lib.ptr(sig_d), _lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), P, k,
+                                                  _lib.ptr(arg), _lib.stream()), "ia_candidate_argmax")
+        has = arg >= 0
+        idx = arg.clamp(min=0).long()
+        sigma = torch.where(has, sig_c.float()[idx], torch.full_like(sig_c[:1], -1e5).expand(P))
+        rgb = torch.where(has[:, None], rgb_c.float()[idx], torch.zeros((), device=dev))
+        return rgb, sigma
+
     def deform_train(self, pts, model):
         """snarf_deformer.py:143-159."""
+        if self._is_native_field(model) and pts.is_cuda and not self.tfs.requires_grad:
+            return self.query_train_fused(pts.type(self.dtype), model)
         pts_cano_all, valid = self.deform(pts.type(self.dtype), eval_mode=False)
         rgb_cano = torch.zeros_like(pts_cano_all).float()
         sigma_cano = -torch.ones_like(pts_cano_all[..., 0]).float() * 1e5

@@ -95,6 +95,12 @@ class NeRFNGPNet(nn.Module):
         self._desc = None
 
     # -- fp16 shadow + C descriptor ------------------------------------------
+    def mark_updated(self):
+        """Invalidate the fp16 shadow.  Call after an optimizer step: fused / foreach
+        optimizers update parameters without bumping Tensor._version."""
+        self._half = None
+        self._desc = None
+
     def _half_params(self):
         key = (self.encoder.params._version, self.color_net.params._version, self.encoder.params.data_ptr())
         if self._half is None or self._half_key != key:

@@ -53,6 +53,51 @@ def _find_native_pair(model):
     return (d, n) if d is not None and n is not None else None
 
 
+class _CompositeTrainFn(torch.autograd.Function):
+    """composite() + render_train tail (raymarcher_acc.py:25-36,161-186) on compact samples:
+    `ia_composite_train_fwd` / `ia_composite_train_bwd`."""
+
+    @staticmethod
+    def forward(ctx, cand_rgb, cand_sigma, st):
+        L = _lib.lib()
+        dev = cand_rgb.device
+        n, S = st["n"], st["S"]
+        cand_rgb, cand_sigma = cand_rgb.contiguous(), cand_sigma.contiguous()
+        cap = st["s_z"].shape[0]
+        color, depth, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+        weights = torch.empty((n, S), device=dev)
+        sv = dict(arg=torch.empty(cap, dtype=torch.int32, device=dev), sigma=torch.empty(cap, device=dev),
+                  alpha=torch.empty(cap, device=dev), T=torch.empty(cap, device=dev))
+        _lib.check(L.ia_composite_train_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), _lib.ptr(st["pt_off"]), _lib.ptr(st["pt_cnt"]),
+                                            st["n_init"], _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]), _lib.ptr(st["s_z"]),
+                                            _lib.ptr(st["near"]), _lib.ptr(st["far"]), n, S, _lib.ptr(st["noise"]), st["noise_scale"],
+                                            _lib.ptr(st["bg"]), _lib.ptr(color), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(weights),
+                                            _lib.ptr(st["s_slot"]), _lib.ptr(sv["arg"]), _lib.ptr(sv["sigma"]), _lib.ptr(sv["alpha"]),
+                                            _lib.ptr(sv["T"]), _lib.stream()), "ia_composite_train_fwd")
+        ctx.st, ctx.sv = st, sv
+        ctx.save_for_backward(cand_rgb)
+        ctx.n_cand = cand_sigma.shape[0]
+        return color, depth, alpha, weights
+
+    @staticmethod
+    def backward(ctx, d_color, d_depth, d_alpha, d_weights):
+        L = _lib.lib()
+        st, sv = ctx.st, ctx.sv
+        (cand_rgb,) = ctx.saved_tensors
+        dev = cand_rgb.device
+        c = lambda t: None if t is None else t.float().contiguous()
+        d_color, d_depth, d_alpha, d_weights = c(d_color), c(d_depth), c(d_alpha), c(d_weights)
+        d_rgb = torch.zeros((ctx.n_cand, 3), device=dev)
+        d_sig = torch.zeros(ctx.n_cand, device=dev)
+        _lib.check(L.ia_composite_train_bwd(_lib.ptr(d_color), _lib.ptr(d_depth), _lib.ptr(d_alpha), _lib.ptr(d_weights),
+                                            _lib.ptr(cand_rgb), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]), _lib.ptr(st["s_z"]),
+                                            _lib.ptr(st["near"]), _lib.ptr(st["far"]), st["n"], st["S"], _lib.ptr(st["bg"]),
+                                            _lib.ptr(st["s_slot"]), _lib.ptr(sv["arg"]), _lib.ptr(sv["sigma"]), _lib.ptr(sv["alpha"]),
+                                            _lib.ptr(sv["T"]), _lib.ptr(d_rgb), _lib.ptr(d_sig), _lib.stream()),
+                   "ia_composite_train_bwd")
+        return d_rgb, d_sig, None
+
+
 class Raymarcher(torch.nn.Module):
     def __init__(self, MAX_SAMPLES: int, MAX_BATCH_SIZE: int, smpl_init: bool = False) -> None:
         super().__init__()
@@ -211,9 +256,59 @@ class Raymarcher(torch.nn.Module):
         }
 
     # ----------------------------------------------------------------- train
+    def render_train_fused(self, rays, deformer, net, noise, bg_color):
+        """render_train (raymarcher_acc.py:140-186) over COMPACT samples: march + jitter +
+        compaction, candidate search + compaction, field under autograd on the surviving
+        candidates, compositing forward/backward as two kernels.  One 8-byte host read per
+        step (sample / candidate counts size the autograd graph)."""
+        L = _lib.lib()
+        dev = rays.o.device
+        o = rays.o.reshape(-1, 3).float().contiguous()
+        d = rays.d.reshape(-1, 3).float().contiguous()
+        near = rays.near.reshape(-1).float().contiguous()
+        far = rays.far.reshape(-1).float().contiguous()
+        n, S = o.shape[0], self.MAX_SAMPLES
+        cap = n * S
+        grid = self.density_grid_train
+        occ = self._occ_desc_cached(grid)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        st = dict(s_pts=torch.empty((cap, 3), device=dev), s_z=torch.empty(cap, device=dev), s_slot=i32(cap),
+                  ray_off=i32(n), ray_cnt=i32(n), n_samples=i32(1), near=near, far=far, n=n, S=S)
+        jitter = torch.rand((n, S), device=dev)                                    # :156
+        with torch.no_grad():
+            _lib.check(L.ia_march_train_compact(_lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), n, _lib.ptr(grid.occ_bits),
+                                                C.byref(occ), S, _lib.ptr(jitter), _lib.ptr(st["s_pts"]), _lib.ptr(st["s_z"]),
+                                                _lib.ptr(st["s_slot"]), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]),
+                                                _lib.ptr(st["n_samples"]), cap, _lib.stream()), "ia_march_train_compact")
+            sc = deformer.search_compact(st["s_pts"], n_pts_dev=st["n_samples"])
+        n_samples, n_cand = torch.cat([st["n_samples"], sc["n_cand"]]).tolist()      # the one host read
+        st.update(pt_off=sc["pt_off"], pt_cnt=sc["pt_cnt"], n_init=len(deformer.deformer.init_bones),
+                  bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
+                  noise=torch.randn(max(n_samples, 1), device=dev) if noise > 0 else None, noise_scale=float(noise))
+        if n_cand > 0:
+            rgb_c, sig_c = net(sc["cand_xc"][:n_cand], None)
+        else:
+            rgb_c, sig_c = torch.zeros((1, 3), device=dev, requires_grad=True), torch.zeros(1, device=dev, requires_grad=True)
+        color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
+        return {
+            "rgb_coarse": color.reshape(rays.o.shape),
+            "depth_coarse": depth.reshape(rays.near.shape),
+            "alpha_coarse": alpha.reshape(rays.near.shape),
+            "weight_coarse": weights.reshape(*rays.near.shape, -1),
+        }
+
+    def _occ_desc_cached(self, grid):
+        key = id(grid.aabb)
+        if getattr(self, "_occ_key", None) != key:
+            self._occ_cache, self._occ_key = self._occ_desc(grid), key
+        return self._occ_cache
+
     def render_train(self, rays, model, noise, bg_color):
         """raymarcher_acc.py:140-186: fixed MAX_SAMPLES slots per ray from
         `ia_raymarch_train`, jitter, masked field evaluation, cumprod compositing."""
+        pair = self._fused or _find_native_pair(model)
+        if pair is not None and rays.o.is_cuda and not pair[0].tfs.requires_grad:
+            return self.render_train_fused(rays, pair[0], pair[1], noise, bg_color)
         L = _lib.lib()
         _lib.require_cuda(rays.o)
         rays_o = rays.o.reshape(-1, 3).float().contiguous()

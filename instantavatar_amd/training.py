@@ -110,7 +110,8 @@ def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
     enc, rest = [], []
     for name, p in model.named_parameters():
         (enc if "encoder" in name else rest).append(p)
-    opt = torch.optim.Adam([{"params": enc}, {"params": rest}], lr=lr, betas=betas, eps=eps)
+    opt = torch.optim.Adam([{"params": enc}, {"params": rest}], lr=lr, betas=betas, eps=eps,
+                           fused=bool(enc and enc[0].is_cuda))
     return opt
 
 
@@ -161,5 +162,7 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     losses["loss"].backward()
     all_reduce_grads(model, world_size)
     optimizer.step()
+    if hasattr(model.net_coarse, "mark_updated"):
+        model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
     model.global_step += 1
     return losses

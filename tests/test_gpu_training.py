@@ -131,3 +131,52 @@ def test_training_step_learns(gw):
             for n, p in tmodel.named_parameters():
                 assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
     assert losses[-1] < losses[0], losses
+
+
+def test_fused_train_render_matches_reference_structure(gw):
+    """render_train over compact samples (ia_march_train_compact / ia_composite_train_*) against
+    the reference-structured route (dense [n,256] tensors, boolean masks, torch cumprod compositing,
+    raymarcher_acc.py:140-186): same outputs and same parameter gradients."""
+    from instantavatar_amd.models.structures.utils import Rays
+    model = gw[0]
+    poses, tr = W.poses()
+    res = 64
+    batch = make_batch(DEV, res, poses[2], tr[2])
+    model.deformer.prepare_deformer(batch)
+    grid = model.renderer.density_grid_train
+    # give the training grid a real occupancy: the test-time grid of this frame, in the train aabb
+    model.renderer.density_grid_test.initialize(model.deformer, model.net_coarse, iters=2)
+    G = 64
+    coords = (grid.coords + 0.5 / G) * (grid.aabb[1] - grid.aabb[0]) + grid.aabb[0]
+    with torch.no_grad():
+        _, dens = model.deformer(coords.reshape(-1, 3), model.net_coarse, True)
+    grid._postprocess(dens.reshape(G, G, G))
+    assert grid.density_field.sum() > 500
+    sel = torch.randperm(res * res, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))[:2048]
+    net = model.net_coarse
+    bg = torch.rand((1, 2048, 3), device=DEV)
+    wc = torch.rand((2048, 3), device=DEV); wa = torch.rand(2048, device=DEV); ww = torch.rand((2048, 256), device=DEV) * 0.01
+
+    def run(fused):
+        rays = Rays(o=batch["rays_o"][:, sel].clone(), d=batch["rays_d"][:, sel].clone(), near=batch["near"][:, sel].clone(),
+                    far=batch["far"][:, sel].clone())
+        model.deformer.transform_rays_w2s(rays)
+        for p in net.parameters():
+            p.grad = None
+        torch.manual_seed(7)
+        if fused:
+            out = model.renderer.render_train_fused(rays, model.deformer, net, 0, bg)
+        else:  # hide the native pair from the renderer and the deformer: generic masked route
+            out = model.renderer.render_train(rays, lambda x, _: model.deformer(x, lambda p, d: net(p, d), False), 0, bg)
+        loss = (out["rgb_coarse"].reshape(-1, 3) * wc).sum() + (out["alpha_coarse"].reshape(-1) * wa).sum() + \
+            (out["weight_coarse"].reshape(-1, 256) * ww).sum() + out["depth_coarse"].sum() * 0.01
+        loss.backward()
+        return {k: v.detach().clone() for k, v in out.items()}, net.encoder.params.grad.clone(), net.color_net.params.grad.clone()
+
+    of, ge_f, gc_f = run(True)
+    og, ge_g, gc_g = run(False)
+    assert (og["alpha_coarse"] > 0.5).float().mean() > 0.02
+    for k in ("rgb_coarse", "alpha_coarse", "depth_coarse", "weight_coarse"):
+        assert torch.allclose(of[k].reshape(-1), og[k].reshape(-1), atol=2e-5), k
+    assert _cos(ge_f, ge_g) > 0.9999 and _cos(gc_f, gc_g) > 0.9999
+    assert (ge_f - ge_g).norm() / ge_g.norm() < 1e-3 and (gc_f - gc_g).norm() / gc_g.norm() < 1e-3
