@@ -211,8 +211,19 @@ def main():
         k = kernels[dom]
         per_launch_ms = k["ms"] / max(k["launches"], 1)
         achieved = k["bytes"] / max(k["launches"], 1) / (per_launch_ms * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py)
+            try:
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+            except Exception:
+                pass
         roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "note": ("algorithmic bytes: k_search = 384 B per trilinear fetch of the 25 MB transform grid (L2 / Infinity-Cache "
+                         "resident, so achieved can exceed the HBM peak; `traffic` is what reached the fabric); "
+                         "k_field = 540 B per sample (512 B hash-table gathers)"),
                 "avg_launch_us": per_launch_ms * 1e3, "launches": k["launches"],
                 "algorithmic_bytes_per_launch": k["bytes"] / max(k["launches"], 1),
                 "other": {n: {"avg_launch_us": v["ms"] * 1e3 / max(v["launches"], 1), "launches": v["launches"],

@@ -290,7 +290,8 @@ int ia_transform_rays_w2s(const float *rays_o, const float *rays_d,
  *   [n_rays], n_samples (device int32, zeroed inside).
  * ia_composite_train_fwd: per sample max over its candidates (invalid = -1e5),
  *   optional sigma noise, alpha = 1-exp(-relu(sigma)*dt), T = cumprod(1-alpha+1e-10);
- *   outputs color [n,3] (+T*bg), depth, alpha (= sum w), weights_dense [n,max_samples];
+ *   outputs color [n,3] (+T*bg), depth, alpha (= sum w), weights_dense [n,max_samples]
+ *   (zero-filled by the caller; only occupied slots are written);
  *   saves s_arg (winning candidate or -1), s_sigma, s_alpha, s_T for the backward.
  * ia_composite_train_bwd: gradients w.r.t. the candidates' rgb [n_cand,3] / sigma
  *   [n_cand] (buffers zero-filled by the caller).                              */

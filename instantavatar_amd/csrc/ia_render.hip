@@ -916,8 +916,7 @@ __global__ __launch_bounds__(256) void k_composite_train_fwd(
   if (n >= n_rays) return;
   const int off = ray_off[n], cnt = ray_cnt[n];
   const float dt = (fars[n] - nears[n]) / max_samples;
-  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, asum = 0.f;
-  for (int k = 0; k < max_samples; k++) weights_dense[(size_t)n * max_samples + k] = 0.f;
+  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, asum = 0.f;  // weights_dense is zero-filled by the caller
   for (int k = 0; k < cnt; k++) {
     const int s = off + k;
     float sg; int arg;

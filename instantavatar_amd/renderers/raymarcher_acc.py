@@ -65,7 +65,7 @@ class _CompositeTrainFn(torch.autograd.Function):
         cand_rgb, cand_sigma = cand_rgb.contiguous(), cand_sigma.contiguous()
         cap = st["s_z"].shape[0]
         color, depth, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
-        weights = torch.empty((n, S), device=dev)
+        weights = torch.zeros((n, S), device=dev)  # the kernel writes the occupied slots only
         sv = dict(arg=torch.empty(cap, dtype=torch.int32, device=dev), sigma=torch.empty(cap, device=dev),
                   alpha=torch.empty(cap, device=dev), T=torch.empty(cap, device=dev))
         _lib.check(L.ia_composite_train_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), _lib.ptr(st["pt_off"]), _lib.ptr(st["pt_cnt"]),

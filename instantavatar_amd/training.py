@@ -21,6 +21,23 @@ from . import _lib
 from .deformers import _opt
 
 
+_MM_OUT_DTYPE = [None]
+
+
+def _mm_f32(a, b):
+    """fp16 x fp16 -> fp32 GEMM (MFMA, fp32 accumulate and output): aten::mm.dtype where the
+    backend provides it, fp32 GEMM otherwise."""
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:1].contiguous(), b[:, :1].contiguous() if b.dim() == 2 else b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except Exception:
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return a.float() @ b.float()
+
+
 class _FieldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, enc_params, col_params, net):
@@ -45,30 +62,37 @@ class _FieldFn(torch.autograd.Function):
         V = xc.shape[0]
         nf = 2 * net.n_levels
         enc_h, col_h = net._half_params()
-        W1 = enc_h[:net.sig_w1_size].float().view(64, nf)
-        W2 = enc_h[net.sig_w1_size:net.sig_w1_size + 1024].float().view(16, 64)
-        Wc1 = col_h[:1024].float().view(64, 16)
-        Wc2 = col_h[1024:5120].float().view(64, 64)
-        Wc3 = col_h[5120:6144].float().view(16, 64)
-        a = acts.float()
-        feat, h1, o16 = a[:, :nf], a[:, nf:nf + 64], a[:, nf + 64:nf + 80]
-        c1, c2 = a[:, nf + 80:nf + 144], a[:, nf + 144:nf + 208]
+        # MLP backward as fp16 GEMMs with fp32 accumulation (hipBLASLt MFMA kernels): the saved
+        # activations are fp16 already; incoming gradients are rescaled per call so that their
+        # largest magnitude sits at 2^10 before the cast (tcnn relies on a fixed 1024x loss scale,
+        # DNeRF.py:58) and the scale is divided out of every product in fp32.
+        h = torch.float16
+        W1h, W2h = enc_h[:net.sig_w1_size].view(64, nf), enc_h[net.sig_w1_size:net.sig_w1_size + 1024].view(16, 64)
+        Wc1h, Wc2h, Wc3h = col_h[:1024].view(64, 16), col_h[1024:5120].view(64, 64), col_h[5120:6144].view(16, 64)
+        feat, h1, o16 = acts[:, :nf], acts[:, nf:nf + 64], acts[:, nf + 64:nf + 80]
+        c1, c2 = acts[:, nf + 80:nf + 144], acts[:, nf + 144:nf + 208]
         cin = torch.cat([o16[:, 1:], torch.ones_like(o16[:, :1])], dim=1)  # colour input: out[1:16] + padding 1
         d_rgb = d_rgb.reshape(V, 3).float()
         d_sigma = d_sigma.reshape(V).float()
-        dY = torch.zeros((V, 16), device=xc.device)
-        dY[:, :3] = d_rgb * rgb * (1 - rgb)  # sigmoid'
-        dWc3 = dY.t() @ c2
-        dC2 = (dY @ Wc3) * (c2 > 0)
-        dWc2 = dC2.t() @ c1
-        dC1 = (dC2 @ Wc2) * (c1 > 0)
-        dWc1 = dC1.t() @ cin
-        dcin = dC1 @ Wc1
-        dO = torch.cat([d_sigma[:, None], dcin[:, :15]], dim=1)
-        dW2 = dO.t() @ h1
-        dH1 = (dO @ W2) * (h1 > 0)
-        dW1 = dH1.t() @ feat
-        dfeat = (dH1 @ W1).contiguous()
+        dY32 = torch.zeros((V, 16), device=xc.device)
+        dY32[:, :3] = d_rgb * rgb * (1 - rgb)  # sigmoid'
+        amax = torch.maximum(dY32.abs().max(), d_sigma.abs().max()).clamp(min=1e-30)
+        S = 1024.0 / amax                      # device scalar, no host sync
+        dY = (dY32 * S).to(h)
+        mm = torch.matmul                       # data path: K <= 64, fp16 in/out, fp32 accumulate
+        dWc3 = _mm_f32(dY.t(), c2)              # weight gradients: K = V samples -> fp32 output
+        dC2 = mm(dY, Wc3h) * (c2 > 0)
+        dWc2 = _mm_f32(dC2.t(), c1)
+        dC1 = mm(dC2, Wc2h) * (c1 > 0)
+        dWc1 = _mm_f32(dC1.t(), cin)
+        dcin = mm(dC1, Wc1h)
+        dO = torch.cat([(d_sigma * S).to(h)[:, None], dcin[:, :15]], dim=1)
+        dW2 = _mm_f32(dO.t(), h1)
+        dH1 = mm(dO, W2h) * (h1 > 0)
+        dW1 = _mm_f32(dH1.t(), feat)
+        inv = 1.0 / S
+        dfeat = (_mm_f32(dH1, W1h) * inv).contiguous()
+        dW1, dW2, dWc1, dWc2, dWc3 = [t * inv for t in (dW1, dW2, dWc1, dWc2, dWc3)]
         g_enc = torch.zeros_like(net.encoder.params)
         g_enc[:net.sig_w1_size] = dW1.reshape(-1)
         g_enc[net.sig_w1_size:net.sig_w1_size + 1024] = dW2.reshape(-1)

@@ -1,0 +1,51 @@
+"""Turns `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` counter_collection CSVs of a bench.py run
+into HBM traffic per launch for the two dominant kernels -> profiles/r01_pmc_traffic.json
+(read by bench.py to fill roofline.traffic).
+
+Units and corrections as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
+KiB of 64-byte fabric requests; on gfx950 FETCH_SIZE under-reports wide reads by 2x -> doubled.
+
+    python tools/pmc_traffic.py <fetch_csv> <write_csv> <out_json>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    tot = collections.Counter()
+    n = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        k = "k_search" if "k_search" in k else "k_field" if "k_field" in k else None
+        if k is None:
+            continue
+        tot[k] += float(r["Counter_Value"])
+        key = (k, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            n[k] += 1
+    return {k: (tot[k], n[k]) for k in tot}
+
+
+def main(fetch_csv, write_csv, out):
+    f = per_kernel(fetch_csv, "FETCH_SIZE")
+    w = per_kernel(write_csv, "WRITE_SIZE")
+    res = {}
+    for k in f:
+        fb = f[k][0] * 1024.0 * 2.0 / f[k][1]          # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+        wb = w.get(k, (0.0, 1))[0] * 1024.0 / max(w.get(k, (0, 1))[1], 1)
+        res[k] = {"launches": f[k][1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                  "hbm_bytes_per_launch": fb + wb}
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2`; "
+                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
