@@ -25,9 +25,10 @@ struct MarchRay {
 __device__ __forceinline__ bool march_occupied(const MarchRay &r, const uint32_t *__restrict__ bits, int G,
                                                float t, float &x, float &y, float &z) {
   x = __builtin_fmaf(t, r.dx, r.ox); y = __builtin_fmaf(t, r.dy, r.oy); z = __builtin_fmaf(t, r.dz, r.oz);
-  const int nx = (int)clampf((x - r.cx) * r.sx, 0.0f, G - 1.0f);  // raymarcher.cu:49-51
-  const int ny = (int)clampf((y - r.cy) * r.sy, 0.0f, G - 1.0f);
-  const int nz = (int)clampf((z - r.cz) * r.sz, 0.0f, G - 1.0f);
+  const float fx = (x - r.cx) * r.sx, fy = (y - r.cy) * r.sy, fz = (z - r.cz) * r.sz;
+  const int nx = (int)clampf(fx, 0.0f, G - 1.0f);  // raymarcher.cu:49-51
+  const int ny = (int)clampf(fy, 0.0f, G - 1.0f);
+  const int nz = (int)clampf(fz, 0.0f, G - 1.0f);
   return occ_test(bits, G, nx, ny, nz);
 }
 
@@ -198,9 +199,15 @@ struct OccWs {
 
 __global__ void k_occ_reset(OccWs *w) { w->sum = 0.0; w->best = 0ull; }
 
-// f = 1 - exp(0.01 * -density); g = maxpool3(f); accumulate sum(g)
+// f = 1 - exp(0.01 * -density)  (density_grid.py:104)
+__global__ __launch_bounds__(256) void k_occ_f(const float *__restrict__ density, int n, float *__restrict__ f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = 1.f - expf(0.01f * -density[i]);
+}
+
+// g = maxpool3(f); accumulate sum(g)
 __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ density, int G,
-                                                  float *__restrict__ pooled, OccWs *ws) {
+                                                  float *__restrict__ pooled, double *__restrict__ partial) {
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float m = 0.f;
@@ -212,15 +219,33 @@ __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ dens
         for (int c = -1; c <= 1; c++) {
           const int xx = x + a, yy = y + b, zz = z + c;
           if (xx < 0 || yy < 0 || zz < 0 || xx >= G || yy >= G || zz >= G) continue;
-          const float f = 1.f - expf(0.01f * -density[(xx * G + yy) * G + zz]);  // density_grid.py:104
+          const float f = density[(xx * G + yy) * G + zz];  // f precomputed by k_occ_f
           m = (f > m || isnan(f)) ? f : m;
         }
     pooled[i] = m;
   }
+  // deterministic mean: fixed-order tree inside the workgroup, one partial per workgroup
+  __shared__ double s_part[4];
   double v = (i < n) ? (double)m : 0.0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if (ia_lane() == 0) atomicAdd(&ws->sum, v);
+  if (ia_lane() == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// fixed-order reduction of the workgroup partials (one workgroup)
+__global__ __launch_bounds__(256) void k_occ_mean(const double *__restrict__ partial, int n_part, OccWs *ws) {
+  __shared__ double s[256];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n_part; k += 256) v += partial[k];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ws->sum = s[0];
 }
 
 // grid = g > clamp(mean, max=0.01); union-find parent init
@@ -236,8 +261,12 @@ __global__ __launch_bounds__(256) void k_occ_threshold(const float *__restrict__
 }
 
 __device__ __forceinline__ int uf_find(int32_t *parent, int i) {
+  const int start = i;
   int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (p != i) { i = p; p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  // path compression: parents only ever grow towards the (maximum-index) root, so a
+  // monotone atomicMax can never undo a concurrent link
+  if (start != i) atomicMax(&parent[start], i);
   return i;
 }
 
@@ -275,8 +304,15 @@ __global__ __launch_bounds__(256) void k_occ_count(int G, int32_t *parent, int32
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int l = -1;
-  if (parent[i] >= 0) { l = uf_find(parent, i); atomicAdd(&count[l], 1); }
+  if (parent[i] >= 0) l = uf_find(parent, i);
   label[i] = l;
+  // most lanes of a wave belong to the same (largest) component: one atomic per wave then
+  const unsigned long long m = __ballot(l >= 0);
+  if (m) {
+    const int first = __shfl(l, __ffsll((long long)m) - 1, 64);
+    if (__all(l < 0 || l == first)) { if (ia_lane() == __ffsll((long long)m) - 1) atomicAdd(&count[first], __popcll(m)); }
+    else if (l >= 0) atomicAdd(&count[l], 1);
+  }
 }
 
 // torch.mode(mcc[field]): most frequent label, smallest label on ties (:109)
@@ -303,12 +339,23 @@ __global__ __launch_bounds__(256) void k_occ_final(int G, const int32_t *__restr
     if (lane == 0) bits[(i >> 5)] = (uint32_t)m;
     if (lane == 32) bits[(i >> 5)] = (uint32_t)(m >> 32);
   }
+  // border flag (word n/32, preset to 1 by k_occ_reset_flag): cleared if a border cell is occupied
+  if (on) {
+    const int x = i / (G * G), y = i / G % G, z = i % G;
+    if (x == 0 || y == 0 || z == 0 || x == G - 1 || y == G - 1 || z == G - 1) bits[n >> 5] = 0u;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_occ_pack(const uint8_t *__restrict__ occ_bool, int n,
+__global__ void k_occ_set_flag(uint32_t *bits, int n) { bits[n >> 5] = 1u; }
+
+__global__ __launch_bounds__(256) void k_occ_pack(const uint8_t *__restrict__ occ_bool, int n, int G,
                                                   uint32_t *__restrict__ bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = (i < n) && occ_bool[i] != 0;
+  if (on) {
+    const int x = i / (G * G), y = i / G % G, z = i % G;
+    if (x == 0 || y == 0 || z == 0 || x == G - 1 || y == G - 1 || z == G - 1) bits[n >> 5] = 0u;
+  }
   const unsigned long long m = __ballot(on);
   const int lane = ia_lane();
   if ((i - lane) < n) {
@@ -440,11 +487,12 @@ __global__ __launch_bounds__(256) void k_march_compact(
   if (live) {
     n = (size_t)alive[i];
     r = load_ray(rays_o, rays_d, fars, step, n, aabb, aabb + 3, G);
-    t0 = near_w[n];
-    float t = t0;
+    float t = near_w[n];
+    t0 = t;
+    bool found = false;
     while (t < r.far && cnt < N_steps) {
       float x, y, z;
-      if (march_occupied(r, bits, G, t, x, y, z)) cnt++;
+      if (march_occupied(r, bits, G, t, x, y, z)) { if (!found) { found = true; t0 = t; } cnt++; }  // t0: exact depth of the first hit
       t += r.dt;
     }
     t_end = t;
@@ -459,6 +507,7 @@ __global__ __launch_bounds__(256) void k_march_compact(
   ray_cnt[i] = cnt;
   counter[n] += (float)cnt;  // raymarcher_acc.py:116
   near_w[n] = t_end;         // raymarcher.cu:72
+  // second pass: re-march from the first hit (same float sequence t0, t0+dt, ...) and write
   int s = 0;
   float t = t0;
   while (t < r.far && s < cnt) {
@@ -621,7 +670,7 @@ extern "C" int ia_candidate_max(const float *cand_rgb, const float *cand_sigma, 
 // ---- occupancy -------------------------------------------------------------
 extern "C" size_t ia_occupancy_workspace_bytes(int G) {
   const size_t n = (size_t)G * G * G;
-  return ia_align(sizeof(OccWs)) + 4 * ia_align(n * 4) + 1024;
+  return ia_align(sizeof(OccWs)) + 5 * ia_align(n * 4) + ia_align((n / 256 + 1) * 8) + 1024;
 }
 
 extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *occ_bits, uint8_t *occ_bool,
@@ -637,14 +686,19 @@ extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *
   int32_t *parent = w.take<int32_t>(n);
   int32_t *label = w.take<int32_t>(n);
   int32_t *count = w.take<int32_t>(n);
+  float *fval = w.take<float>(n);
+  double *partial = w.take<double>(ia_div_up(n, 256));
   const dim3 grid(ia_div_up(n, 256)), blk(256);
   hipLaunchKernelGGL(k_occ_reset, dim3(1), dim3(1), 0, s, ow);
   hipLaunchKernelGGL(k_fill_i32, grid, blk, 0, s, count, 0, n);
-  hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, density, G, pooled, ow);
+  hipLaunchKernelGGL(k_occ_f, grid, blk, 0, s, density, n, fval);
+  hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, fval, G, pooled, partial);
+  hipLaunchKernelGGL(k_occ_mean, dim3(1), blk, 0, s, partial, ia_div_up(n, 256), ow);
   hipLaunchKernelGGL(k_occ_threshold, grid, blk, 0, s, pooled, G, ow, parent);
   hipLaunchKernelGGL(k_occ_union, grid, blk, 0, s, G, parent);
   hipLaunchKernelGGL(k_occ_count, grid, blk, 0, s, G, parent, label, count);
   hipLaunchKernelGGL(k_occ_best, grid, blk, 0, s, G, count, ow);
+  hipLaunchKernelGGL(k_occ_set_flag, dim3(1), dim3(1), 0, s, occ_bits, n);
   hipLaunchKernelGGL(k_occ_final, grid, blk, 0, s, G, label, ow, occ_bits, occ_bool);
   IA_LAUNCH_CHECK("occupancy_from_density");
   return IA_OK;
@@ -653,7 +707,8 @@ extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *
 extern "C" int ia_occupancy_pack(const uint8_t *occ_bool, int G, uint32_t *occ_bits, void *stream) {
   IA_CHECK_ARG(occ_bool && occ_bits && G > 0 && (G * G * G) % 64 == 0, "ia_occupancy_pack: bad arguments");
   const int n = G * G * G;
-  hipLaunchKernelGGL(k_occ_pack, dim3(ia_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, occ_bool, n, occ_bits);
+  hipLaunchKernelGGL(k_occ_set_flag, dim3(1), dim3(1), 0, (hipStream_t)stream, occ_bits, n);
+  hipLaunchKernelGGL(k_occ_pack, dim3(ia_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, occ_bool, n, G, occ_bits);
   IA_LAUNCH_CHECK("k_occ_pack");
   return IA_OK;
 }

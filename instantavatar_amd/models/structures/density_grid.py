@@ -9,7 +9,9 @@ plugins, and the same sequence through the `deformer(pts, net)` closure +
 (density_grid.py:46-92).
 
 Besides the reference's `density_field` (bool [G,G,G]) the grid keeps `occ_bits`,
-the bit-packed copy (32 KB) the marcher kernels read.
+the bit-packed copy (32 KB) the marcher kernels read, followed by one flag word
+(1 = no border cell occupied, which lets the marcher reject samples outside the aabb
+without a lookup).
 """
 import ctypes as C
 
@@ -36,7 +38,7 @@ class DensityGrid(torch.nn.Module):
         G = grid_size
         self.register_buffer("density_cached", torch.zeros(G, G, G))
         self.register_buffer("density_field", torch.zeros(G, G, G, dtype=torch.bool))
-        self.register_buffer("occ_bits", torch.zeros(G * G * G // 32, dtype=torch.int32), persistent=False)
+        self.register_buffer("occ_bits", torch.zeros(G * G * G // 32 + 1, dtype=torch.int32), persistent=False)
         self.aabb = aabb
         self.initialized = False
         self.smpl_init = smpl_init

@@ -174,7 +174,7 @@ def test_occupancy_postprocess_bit_exact(oracle, gpu_world):
     grid._postprocess(torch.as_tensor(dens, device=DEV))
     got = grid.density_field.cpu().numpy()
     assert np.array_equal(got, ref.astype(bool))
-    bits = grid.occ_bits.cpu().numpy().view(np.uint32)
+    bits = grid.occ_bits.cpu().numpy().view(np.uint32)[:G ** 3 // 32]  # (+1 border-flag word)
     unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(G, G, G).astype(bool)
     assert np.array_equal(unpacked, got)
     grid._postprocess(torch.zeros((G, G, G), device=DEV))   # empty grid edge case
@@ -205,7 +205,7 @@ def test_raymarch_and_composite_kernels(oracle, gpu_world):
                                        aabb[0].ctypes.data_as(C.c_void_p), step.ctypes.data_as(C.c_void_p), Ns,
                                        pts.ctypes.data_as(C.c_void_p), dn.ctypes.data_as(C.c_void_p), zn.ctypes.data_as(C.c_void_p))
         t = lambda a: torch.as_tensor(a, device=DEV)
-        bits = torch.zeros(G ** 3 // 32, dtype=torch.int32, device=DEV)
+        bits = torch.zeros(G ** 3 // 32 + 1, dtype=torch.int32, device=DEV)  # + border-flag word
         tocc = t(occ)
         _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(tocc), G, _lib.ptr(bits), _lib.stream()))
         og = _lib.OccGrid(); og.G = G; og.aabb_min[:] = aabb[0].tolist(); og.aabb_max[:] = aabb[1].tolist()
