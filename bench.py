@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
+    ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying the captured HIP "
+                    "graph (eager is host-bound: 4.2-5.2 ms/frame depending on host jitter vs a stable 4.2 ms replayed)")
     ap.add_argument("--train-steps", type=int, default=30, help="training iterations timed after the render loop (0 = skip)")
     return ap.parse_args()
 
@@ -166,13 +168,29 @@ def main():
         return model.render_image_fast(b, (res, res))
 
     L = _lib.lib()
+    eager_frame = frame
+    graphed = None
+    mode = "eager"
+    if not args.no_graph:
+        try:
+            from instantavatar_amd.pipeline import GraphedRenderer
+            graphed = GraphedRenderer(model, batches[0], (res, res))
+
+            def frame(i):  # noqa: F811  (same work, replayed from the captured HIP graph)
+                f = my[i] % len(poses)
+                d = float(np.sqrt((tr[f] ** 2).sum()))
+                b = batches[0]
+                b["global_orient"], b["body_pose"], b["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
+                b["near"].fill_(d - 1)
+                b["far"].fill_(d + 1)
+                return graphed(b)
+            mode = "hip_graph"
+        except Exception as e:  # capture not possible on this stack: stay eager (still the HIP path)
+            print("graph capture failed, running eagerly:", repr(e)[:200], file=sys.stderr)
+            frame = eager_frame
     for i in range(args.warmup):
         out = frame(i)
     torch.cuda.synchronize()
-    prof = not args.no_profile
-    if prof:
-        _lib.check(L.ia_profile_enable(1))
-        _lib.check(L.ia_profile_reset())
     if world_size > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -188,6 +206,21 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel timing for the roofline block: HIP events around every launch of the two dominant
+    # kernels on the stream they run on.  Recording ~50 events per frame costs ~10 % of the frame,
+    # so `value` comes from the un-instrumented pass above and the SAME K frames are then launched
+    # once more with the events enabled (`ms_per_step_instrumented`).
+    prof = not args.no_profile
+    dt_prof = None
+    if prof:
+        _lib.check(L.ia_profile_enable(1))
+        _lib.check(L.ia_profile_reset())
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            eager_frame(i)
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - tp0
     if world_size > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -244,7 +277,8 @@ def main():
         "rays_per_sec": fps * res * res,
         "samples_per_ray": float(cnt_sum.item()) / args.steps,
         "alpha_coverage": float(cov_sum.item()) / args.steps,
-        "render_loop_iters": model.renderer.last_iters,
+        "render_loop_iters": model.renderer.last_iters, "launch_mode": mode,
+        "ms_per_step_instrumented": (dt_prof / args.steps * 1e3) if dt_prof else None,
     }
     if roof is not None:
         result["roofline"] = roof

@@ -44,6 +44,41 @@ class AvatarModel(torch.nn.Module):
         return rgb, depth, alpha, counter
 
 
+class GraphedRenderer:
+    """render_image_fast replayed from a HIP graph (torch.cuda.CUDAGraph).
+
+    The per-frame pipeline has no host synchronisation and fixed launch geometry (counts
+    live on the device), so one capture serves every frame: pose / translation / near /
+    far are copied into static buffers, the graph is replayed, and the device-side alive
+    counter is checked once afterwards (rays still alive -> the eager path finishes them).
+    Removes the ~0.5 ms of launch gaps per frame."""
+
+    def __init__(self, model, batch, img_size, warmup=3):
+        self.model, self.img_size = model, img_size
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        r = model.renderer
+        for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration hint
+            model.render_image_fast(self.static, img_size)
+        r._iters_hint = max(r._iters_hint, r.last_iters)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        r._graph_capture = True
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = model.render_image_fast(self.static, img_size)
+        finally:
+            r._graph_capture = False
+
+    def __call__(self, batch):
+        for k in ("global_orient", "body_pose", "transl", "near", "far"):
+            self.static[k].copy_(batch[k])
+        self.graph.replay()
+        r = self.model.renderer
+        if int(r._n_alive_dev.item()) > 0:  # hint too short for this frame: finish eagerly (rare)
+            return self.model.render_image_fast(batch, self.img_size)
+        return self.out
+
+
 def build_synthetic_model(device, resolution=128, n_levels=16, max_samples=256, max_batch=291600, seed=42,
                           cano_pose="A_pose"):
     """Synthetic body + field wired into the three plugins.

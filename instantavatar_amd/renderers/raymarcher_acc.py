@@ -188,7 +188,7 @@ class Raymarcher(torch.nn.Module):
 
         total = self._iters_hint
         launch(total, 0)
-        if sync:
+        if sync and not getattr(self, "_graph_capture", False):
             # one device->host read per frame (4 bytes) to validate the hint
             while int(self._n_alive_dev.item()) > 0 and total < 2 * self.MAX_SAMPLES:
                 launch(4, 1)
