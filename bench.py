@@ -206,6 +206,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    incomplete = graphed.finish() if graphed is not None else 0
+    if incomplete:
+        raise SystemExit("bench: %d frames left rays alive (graph too short) -- result invalid" % incomplete)
     # per-kernel timing for the roofline block: HIP events around every launch of the two dominant
     # kernels on the stream they run on.  Recording ~50 events per frame costs ~10 % of the frame,
     # so `value` comes from the un-instrumented pass above and the SAME K frames are then launched

@@ -49,17 +49,22 @@ class GraphedRenderer:
 
     The per-frame pipeline has no host synchronisation and fixed launch geometry (counts
     live on the device), so one capture serves every frame: pose / translation / near /
-    far are copied into static buffers, the graph is replayed, and the device-side alive
-    counter is checked once afterwards (rays still alive -> the eager path finishes them).
-    Removes the ~0.5 ms of launch gaps per frame."""
+    far are copied into static buffers and the graph is replayed.  The wave-front loop's
+    length is data dependent; the graph holds `margin` more iterations than the warm-up
+    frames needed (idle iterations are a few empty launches) and the device-side alive
+    counter of every frame is copied to pinned host memory and checked one call later
+    (`incomplete` counts frames whose loop would have continued; they must be re-rendered
+    through `model.render_image_fast`).  `sync_check=True` checks before returning."""
 
-    def __init__(self, model, batch, img_size, warmup=3):
-        self.model, self.img_size = model, img_size
+    def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False):
+        self.model, self.img_size, self.sync_check = model, img_size, sync_check
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         r = model.renderer
-        for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration hint
+        need = 0
+        for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration count
             model.render_image_fast(self.static, img_size)
-        r._iters_hint = max(r._iters_hint, r.last_iters)
+            need = max(need, r.last_iters)
+        r._iters_hint = need + margin + ((need + margin) & 1)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         r._graph_capture = True
@@ -68,15 +73,32 @@ class GraphedRenderer:
                 self.out = model.render_image_fast(self.static, img_size)
         finally:
             r._graph_capture = False
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._ev = None
+        self.incomplete = 0
+
+    def _check_previous(self):
+        if self._ev is not None:
+            self._ev.synchronize()
+            if int(self._host[0]) > 0:
+                self.incomplete += 1
+            self._ev = None
 
     def __call__(self, batch):
+        self._check_previous()
         for k in ("global_orient", "body_pose", "transl", "near", "far"):
-            self.static[k].copy_(batch[k])
+            self.static[k].copy_(batch[k], non_blocking=True)
         self.graph.replay()
-        r = self.model.renderer
-        if int(r._n_alive_dev.item()) > 0:  # hint too short for this frame: finish eagerly (rare)
-            return self.model.render_image_fast(batch, self.img_size)
+        self._host.copy_(self.model.renderer._n_alive_dev, non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+        if self.sync_check:
+            self._check_previous()
         return self.out
+
+    def finish(self):
+        self._check_previous()
+        return self.incomplete
 
 
 def build_synthetic_model(device, resolution=128, n_levels=16, max_samples=256, max_batch=291600, seed=42,

@@ -317,7 +317,7 @@ def test_hip_graph_replay_equals_eager(gpu_world):
     jit = torch.rand((5, 64 ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(11))
     grid.initialize = lambda deformer, net, iters=5, jitter=None: orig(deformer, net, iters=iters, jitter=jit)
     try:
-        g = GraphedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res))
+        g = GraphedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), sync_check=True)
         for i in (1, 4, 6):
             b = make_batch(DEV, res, poses[i], tr[i])
             out_g = [t.clone() for t in g(b)]
@@ -325,5 +325,6 @@ def test_hip_graph_replay_equals_eager(gpu_world):
             for a, e in zip(out_g, out_e):
                 assert torch.equal(a, e)
             assert (out_e[2] > 0.5).float().mean() > 0.02
+        assert g.finish() == 0
     finally:
         grid.initialize = orig
