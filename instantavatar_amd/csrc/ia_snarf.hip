@@ -242,6 +242,13 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
   Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
 }
 
+// true when none of the 8 trilinear corners of the fetch at normalised (gx,gy,gz) lies inside
+// the grid, i.e. fetch_J would return J = 0 without touching memory
+__device__ __forceinline__ bool fetch_all_oob(const SnarfGridDev &g, float gx, float gy, float gz) {
+  const int x0 = (int)floorf(src_index(gx, g.W)), y0 = (int)floorf(src_index(gy, g.H)), z0 = (int)floorf(src_index(gz, g.D));
+  return x0 < -1 || x0 >= g.W || y0 < -1 || y0 >= g.H || z0 < -1 || z0 >= g.D;
+}
+
 struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
 
 // ---------------------------------------------------------------------------
@@ -282,19 +289,59 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
   __shared__ int s_wtot[IA_SEARCH_THREADS / 64];
   __shared__ int s_next;
   __shared__ int s_blockbase;
+  __shared__ int s_nlive;
+  __shared__ uint16_t s_list[IA_N_INIT_MAX * NP];
   if (n_pts_dev) P = min(P, *n_pts_dev);
   const int tid = threadIdx.x, lane = tid & 63;
   const int p0 = blockIdx.x * NP;
   if (p0 >= P) return;  // uniform per workgroup
   const int np = min(NP, P - p0);
   const int n_items = np * n_init;
-  if (tid == 0) s_next = 0;
+  if (tid == 0) { s_next = 0; s_nlive = 0; }
   for (int e = tid; e < np * 3; e += IA_SEARCH_THREADS) (&s_xd[0][0])[e] = xd[(size_t)p0 * 3 + e];
   __syncthreads();
 
+  // ---- classification -------------------------------------------------------------------
+  // A solve whose INITIAL fetch has all 8 corners outside the grid is invalid by construction:
+  // J = 0 gives J_inv0 = 0, so the update is 0, x never moves, every later fetch is zero too
+  // and the residual stays -x_d: the reference kernel ends in `diverged`, in `converged` with
+  // the bounds test failing, or (1e-5 < |x_d| < 0.1) in ten iterations of NaN -- never valid.
+  // Most (point, init) pairs of the occupancy probes are of this kind; they are resolved here,
+  // and only the remaining items enter the queue, so the waves of the solver stay dense.
+  for (int q0 = 0; q0 < n_items; q0 += IA_SEARCH_THREADS) {
+    const int q = q0 + tid;
+    bool keep = false;
+    if (q < n_items) {
+      const int init = q / np, pt = q - init * np;
+      const float a0 = s_xd[pt][0], a1 = s_xd[pt][1], a2 = s_xd[pt][2];
+      const float *T = tfs + bones.id[init] * 16;
+      const float ixd = a0 - T[3], iyd = a1 - T[7], izd = a2 - T[11];
+      const float c0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
+      const float c1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
+      const float c2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
+      keep = !fetch_all_oob(g, g.scl[0] * (c0 + g.off[0]), g.scl[1] * (c1 + g.off[1]), g.scl[2] * (c2 + g.off[2]));
+      if (!keep) {
+        s_x[init][pt][0] = 0.f; s_x[init][pt][1] = 0.f; s_x[init][pt][2] = 0.f;
+        s_valid[init][pt] = 0;
+        if (MODE == 0 && J_inv) {
+          const size_t o = ((size_t)(p0 + pt) * n_init + init) * 9;
+#pragma unroll
+          for (int k = 0; k < 9; k++) J_inv[o + k] = 0.f;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_nlive, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (keep) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)q;
+  }
+  __syncthreads();
+  const int n_live = s_nlive;
+
   // ---- lane state machine ----
   bool active = false, first = false;
-  int item = 0, iter = 0, fetches = 0, solves = 0;
+  int item = 0, iter = 0, fetches = 0, solves = 0;  // `solves` counts the queued (non-trivial) ones
   float t0 = 0, t1 = 0, t2 = 0, xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
   float Ji[9];
 #pragma unroll
@@ -307,11 +354,11 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_next, __popcll(need));
         base = __shfl(base, 0, 64);
-        if (base >= n_items) queue_empty = true;
+        if (base >= n_live) queue_empty = true;
         const int my = base + __popcll(need & ((1ull << lane) - 1ull));
-        if (!active && my < n_items) {
-          item = my;
-          const int init = my / np, pt = my - init * np;
+        if (!active && my < n_live) {
+          item = s_list[my];
+          const int init = item / np, pt = item - init * np;
           t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
           const float *T = tfs + bones.id[init] * 16;
           // :287-293  x0 = R^T (xd - t)
