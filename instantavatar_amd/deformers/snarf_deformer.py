@@ -168,7 +168,8 @@ class SNARFDeformer():
         """snarf_deformer.py:109-125: canonical candidates [P,13,3] + validity [P,13]."""
         point_size = pts.shape[0]
         pts_cano, others = self.deformer.forward(pts.reshape(1, -1, 3), cond=None, tfs=self.tfs, eval_mode=eval_mode)
-        return pts_cano.reshape(point_size, -1, 3), others["valid_ids"].reshape(point_size, -1)
+        k = len(self.deformer.init_bones)
+        return pts_cano.reshape(point_size, k, 3), others["valid_ids"].reshape(point_size, k)
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:

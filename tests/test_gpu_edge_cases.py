@@ -1,0 +1,119 @@
+"""Edge cases of the C ABI on the GPU (-m gpu): empty / ragged inputs, argument errors,
+non-finite inputs, rays that miss everything, state-dict surface."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from instantavatar_amd import _lib, synthetic as syn
+from instantavatar_amd.models.structures.utils import Rays
+from instantavatar_amd.pipeline import make_batch
+
+import world as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gw():
+    model, body, fp, init = W.build(DEV, 64, 16)
+    poses, tr = W.poses()
+    model.deformer.prepare_deformer(make_batch(DEV, 32, poses[1], tr[1]))
+    return model, poses, tr
+
+
+def test_argument_errors_raise_and_report(gw):
+    model = gw[0]
+    L = _lib.lib()
+    with pytest.raises(_lib.IAError) as e:
+        _lib.check(L.ia_field_fwd(None, 10, None, C.byref(model.net_coarse.field_desc()), None, None, None), "ia_field_fwd")
+    assert "null pointer" in str(e.value)
+    g = _lib.SnarfGrid(); g.D, g.H, g.W = 8, 32, 30  # W not a multiple of 4
+    t = torch.zeros(16, device=DEV)
+    with pytest.raises(_lib.IAError):
+        _lib.check(L.ia_precompute(_lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, C.byref(g), None), "ia_precompute")
+    bones = _lib.bone_array([0, 1, 99])  # joint id out of range
+    with pytest.raises(_lib.IAError):
+        _lib.check(L.ia_snarf_search(_lib.ptr(t), 1, _lib.ptr(t), _lib.ptr(t), bones, 3, C.byref(model.deformer.deformer.grid_desc()),
+                                     1e-5, 1e-1, _lib.ptr(t), _lib.ptr(t), None, None, None), "ia_snarf_search")
+    ws = torch.empty(16, dtype=torch.uint8, device=DEV)  # workspace too small
+    rc = L.ia_occupancy_from_density(_lib.ptr(torch.zeros(64 ** 3, device=DEV)), 64, _lib.ptr(torch.zeros(8193, dtype=torch.int32, device=DEV)),
+                                     None, _lib.ptr(ws), 16, None)
+    assert rc == -3 and b"workspace" in L.ia_last_error()
+    with pytest.raises(_lib.IAError):
+        model.net_coarse(torch.zeros(4, 3), None)  # CPU tensor: no fallback
+
+
+def test_empty_and_ragged_sizes(gw):
+    model = gw[0]
+    net, dfm = model.net_coarse, model.deformer
+    with torch.no_grad():
+        r, s = net(torch.zeros((0, 3), device=DEV), None)
+    assert r.shape == (0, 3) and s.shape == (0,)
+    bb = dfm.bbox
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for n in (1, 2, 63, 64, 65, 127, 129, 1000, 4097):
+        x = torch.rand((n, 3), device=DEV, generator=g) * (bb[1] - bb[0]) + bb[0]
+        with torch.no_grad():
+            r1, s1 = net(x, None)
+            r2, s2 = net(torch.cat([x, x.flip(0)]), None)  # other tile composition, same samples
+        assert torch.equal(r1, r2[:n]) and torch.equal(s1, s2[:n])
+        assert torch.equal(r1, r2[n:].flip(0)) and torch.equal(s1, s2[n:].flip(0))
+        rq, sq = dfm(x, net, True)                     # fused query
+        rc, sc = dfm(x, lambda p, d: net(p, d), True)  # generic route
+        assert torch.equal(sq, sc) and torch.equal(rq, rc)
+    rq, sq = dfm(torch.zeros((0, 3), device=DEV), lambda p, d: net(p, d), True)
+    assert sq.shape == (0,)
+
+
+def test_non_finite_inputs_do_not_fault(gw):
+    model = gw[0]
+    x = torch.tensor([[float("nan"), 0, 0], [float("inf"), 1, 1], [-float("inf"), 0, 0], [1e30, -1e30, 0], [0.0, 0.0, 0.0]], device=DEV)
+    with torch.no_grad():
+        r, s = model.net_coarse(x, None)
+        rq, sq = model.deformer(x, model.net_coarse, True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(s[1:]).all() and torch.isfinite(sq).all()   # nan_to_num at test time (snarf_deformer.py:136-137)
+    assert (sq >= 0).all()
+
+
+def test_rays_that_miss_everything(gw):
+    model, poses, tr = gw
+    res = 32
+    batch = make_batch(DEV, res, poses[1], tr[1])
+    batch["rays_d"] = -batch["rays_d"]  # look away from the body
+    rgb, depth, alpha, counter = model.render_image_fast(batch, (res, res))
+    assert torch.all(alpha == 0) and torch.all(counter == 0) and torch.allclose(rgb, torch.ones_like(rgb))
+    assert model.renderer.last_iters >= 2
+
+
+def test_large_render_1024(gw):
+    """BASELINE configs[4] image size: 1024x1024 = 1 048 576 rays (> MAX_BATCH_SIZE: N_step = 1 until rays retire)."""
+    model, poses, tr = gw
+    res = 1024
+    rgb, depth, alpha, counter = model.render_image_fast(make_batch(DEV, res, poses[2], tr[2]), (res, res))
+    cov = (alpha > 0.5).float().mean().item()
+    assert 0.03 < cov < 0.5 and torch.isfinite(rgb).all()
+    # downsampled silhouette agrees with a 256^2 render of the same frame
+    rgb2, _, alpha2, _ = model.render_image_fast(make_batch(DEV, 256, poses[2], tr[2]), (256, 256))
+    a_ds = torch.nn.functional.avg_pool2d(alpha[None], 4)[0]
+    assert ((a_ds > 0.5) != (alpha2 > 0.5)).float().mean() < 0.02
+
+
+def test_state_dict_surface_matches_reference_keys(gw):
+    """Checkpoint keys on the path: names and shapes of the reference's tcnn modules."""
+    model = gw[0]
+    sd = model.state_dict()
+    assert sd["net_coarse.encoder.params"].shape == (3072 + 13026992,)
+    assert sd["net_coarse.color_net.params"].shape == (6144,)
+    for k in ("net_coarse.center", "net_coarse.scale", "renderer.density_grid_test.density_cached",
+              "renderer.density_grid_test.density_field"):
+        assert k in sd, k
+    assert sd["renderer.density_grid_test.density_field"].dtype == torch.bool
+    # round trip + occupancy bits refresh
+    model.renderer.density_grid_test.load_state_dict(model.renderer.density_grid_test.state_dict())
+    model.renderer.density_grid_test.pack_bits()
+    names = [n for n, _ in model.named_parameters()]
+    assert any("encoder" in n for n in names)  # optimiser grouping of DNeRF.py:42-45
