@@ -100,6 +100,17 @@ int ia_smpl_tfs(const float *joints_rest, const int32_t *parents,
                 const float *pose, const float *transl, const float *tfs_inv_t,
                 float *tfs, float *w2s, float *A, void *stream);
 
+/* ---- a20: skinning-weight voxelisation (one-time) ---------------------------
+ * Replaces query_weights_smpl (fast_snarf/deformer_torch.py:225-244) including the
+ * pytorch3d knn_points call (third_parties/pytorch3d/ops.py:123): for every voxel
+ * centre pts[i] (i in (d,h,w) raster order) the 30 nearest of the n_verts SMPL
+ * vertices, inverse-distance blend of their weights [n_verts,24], then n_smooth
+ * (30) 6-neighbour smoothing + renormalisation passes.  voxel_w: OUT [24,d,h,w]. */
+size_t ia_voxelise_workspace_bytes(int d, int h, int w);
+int ia_voxelise_weights(const float *pts, const float *verts, int n_verts,
+                        const float *vert_weights, int d, int h, int w, int n_smooth,
+                        float *voxel_w, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- a3: precompute -------------------------------------------------------
  * Replaces precompute(voxel_w, tfs, voxel_d, voxel_J, offset, scale)
  * (fast_snarf/cuda/precompute/precompute.cpp:7-13, precompute.cu:24-71).

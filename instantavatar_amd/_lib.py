@@ -43,6 +43,8 @@ _SIGS = {
     "ia_last_error": (C.c_char_p, []),
     "ia_hash_desc_init": (C.c_int, [C.POINTER(HashDesc), C.c_int, C.c_int, C.c_int, C.c_float]),
     "ia_smpl_tfs": (C.c_int, [_VP] * 8 + [_VP]),
+    "ia_voxelise_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ia_voxelise_weights": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
     "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
                                   C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),

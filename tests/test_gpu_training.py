@@ -180,3 +180,51 @@ def test_fused_train_render_matches_reference_structure(gw):
         assert torch.allclose(of[k].reshape(-1), og[k].reshape(-1), atol=2e-5), k
     assert _cos(ge_f, ge_g) > 0.9999 and _cos(gc_f, gc_g) > 0.9999
     assert (ge_f - ge_g).norm() / ge_g.norm() < 1e-3 and (gc_f - gc_g).norm() / gc_g.norm() < 1e-3
+
+
+def test_implicit_differentiation_of_roots_wrt_pose(gw):
+    """Row a7 (deformer_torch.py:50-67): canonical roots are differentiable w.r.t. the SMPL pose
+    through x_c <- x_c* - J^-1 (d(x_c*) - sg[d(x_c*)]).  Autograd gradient of a linear functional of
+    the roots against central finite differences of the pose (config 4: SMPL refinement)."""
+    model = gw[0]
+    dfm = model.deformer
+    poses, tr = W.poses()
+    base = make_batch(DEV, 16, poses[3], tr[3])
+    g = torch.Generator(device=DEV).manual_seed(5)
+
+    def roots(body_pose):
+        b = dict(base)
+        b["body_pose"] = body_pose
+        dfm.prepare_deformer(b)       # differentiable torch route when the pose carries grad
+        return dfm.deform(pts, eval_mode=False)
+
+    bp0 = base["body_pose"].clone()
+    dfm.prepare_deformer(base)
+    vd = dfm.deformer.voxel_d[0].reshape(3, -1)
+    sel = torch.randint(0, vd.shape[1], (3000,), device=DEV, generator=g)
+    pts = (vd[:, sel].T + 0.01 * torch.randn((3000, 3), device=DEV, generator=g)).contiguous()
+    r = torch.randn((3000, 13, 3), device=DEV, generator=g)
+    bp = bp0.clone().requires_grad_(True)
+    xc, valid = roots(bp)
+    assert valid.float().mean() > 0.05
+    loss = (xc * r)[valid].sum()
+    (grad,) = torch.autograd.grad(loss, bp)
+    assert torch.isfinite(grad).all() and grad.abs().max() > 0
+    # finite differences on the 6 pose entries with the largest gradient
+    idx = grad.abs().reshape(-1).topk(6).indices
+    eps = 2e-3
+    fd = []
+    for k in idx.tolist():
+        vals = []
+        for sgn in (+1, -1):
+            p = bp0.clone(); p.reshape(-1)[k] += sgn * eps
+            with torch.no_grad():
+                x2, v2 = roots(p)
+            vals.append((x2, v2))
+        both = valid & vals[0][1] & vals[1][1]
+        fd.append((((vals[0][0] - vals[1][0]) * r)[both].sum() / (2 * eps)).item())
+        # restrict the analytic value to the same candidates
+    fd = torch.tensor(fd)
+    an = grad.reshape(-1)[idx].cpu()
+    cos = float((fd * an).sum() / (fd.norm() * an.norm()))
+    assert cos > 0.98, (cos, fd, an)
