@@ -70,6 +70,12 @@ typedef struct ia_field {
    * matrices above (ia_field_frags_bytes() bytes); NULL = built inside every
    * field kernel launch (slower).  Must be rebuilt whenever the weights change. */
   const uint16_t *mlp_frags;
+  /* optional: scratch for the XCD-sharded encoding, n_levels planes of enc_ws_samples
+   * packed half2 (4 B) each.  When non-NULL the field kernels encode a call of
+   * V <= enc_ws_samples samples level-by-level, each hashed level pinned to one XCD's
+   * L2 (same results, higher gather rate); NULL = single fused kernel.            */
+  uint32_t *enc_ws;
+  size_t enc_ws_samples;
 } ia_field;
 
 /* Occupancy grid (models/structures/density_grid.py): G^3 cells over aabb.   */
@@ -182,6 +188,11 @@ int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream);
 /* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */
 int ia_hashgrid_fwd(const float *x, int V, const ia_field *field,
                     uint16_t *feat, void *stream);
+/* Same encoding, XCD-sharded (one hashed level per XCD L2, see ia_field.enc_ws):
+ * planes [n_levels][stride] of packed half2, stride >= V.  Needs the tcnn default
+ * table shape (4 dense + 4 or 12 equal hashed levels).                          */
+int ia_hashgrid_fwd_planes(const float *x, int V, const ia_field *field,
+                           uint32_t *planes, size_t stride, void *stream);
 
 /* ---- a6: candidate reduction ----------------------------------------------
  * Replaces SNARFDeformer.deform_test tail (snarf_deformer.py:130-141):

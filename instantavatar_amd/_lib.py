@@ -28,7 +28,8 @@ class HashDesc(C.Structure):
 class Field(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("scale", C.c_float * 3), ("hash", HashDesc),
                 ("table", C.c_void_p), ("sig_w1", C.c_void_p), ("sig_w2", C.c_void_p),
-                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p), ("mlp_frags", C.c_void_p)]
+                ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p), ("mlp_frags", C.c_void_p),
+                ("enc_ws", C.c_void_p), ("enc_ws_samples", C.c_size_t)]
 
 
 class OccGrid(C.Structure):
@@ -58,6 +59,7 @@ _SIGS = {
     "ia_field_frags_bytes": (C.c_size_t, []),
     "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
     "ia_hashgrid_fwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP]),
+    "ia_hashgrid_fwd_planes": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, C.c_size_t, _VP]),
     "ia_candidate_max": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_float, C.c_int, _VP, _VP, _VP]),
     "ia_raymarch_test": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), _VP, C.c_int,
                                    _VP, _VP, _VP, _VP]),

@@ -58,6 +58,8 @@ struct FieldDev {
   const uint32_t *table;  // half2 per entry
   const uint16_t *sig_w1, *sig_w2, *col_w1, *col_w2, *col_w3;
   const uint16_t *frags;  // prebuilt MFMA A-fragment image or null
+  uint32_t *enc_ws;       // level-plane scratch of the XCD-sharded encoding or null
+  size_t enc_ws_samples;
   // set when all hashed levels have the same size and follow each other (tcnn default):
   // level l >= n_dense lives at table + hash_base + (l - n_dense) * hash_size
   uint32_t n_dense, hash_base, hash_size;

@@ -59,6 +59,8 @@ int ia_make_field_dev(const ia_field *f, FieldDev *o) {
   o->sig_w1 = f->sig_w1; o->sig_w2 = f->sig_w2;
   o->col_w1 = f->col_w1; o->col_w2 = f->col_w2; o->col_w3 = f->col_w3;
   o->frags = f->mlp_frags;
+  o->enc_ws = f->enc_ws;
+  o->enc_ws_samples = f->enc_ws ? f->enc_ws_samples : 0;
   // uniform-hash pattern (lets the kernel derive per-level pointers instead of holding 16 of them)
   uint32_t nd = 0;
   while ((int)nd < L && !o->lv.hashed[nd]) nd++;
@@ -273,6 +275,164 @@ __device__ __forceinline__ void encode_all(const FieldDev &F, const uint32_t *__
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// XCD-sharded encoding.  The fp16 table (26 MB) does not fit one XCD's 4 MB L2, so
+// when every workgroup walks all 16 levels each L2 thrashes and the hashed gathers
+// are served across the fabric.  Here a workgroup encodes ONE hashed level (plus, in
+// the second phase, one dense level) for a tile of samples, and the level is chosen
+// from blockIdx % 8 -- the XCD the dispatcher places the workgroup on (observed
+// placement; only speed depends on it).  Each XCD then gathers from a 2 MB slice
+// that stays resident in its own L2:
+//   phase A  (blocks s <  tiles):  XCD x -> hashed level ND+x          , tile s
+//   phase B  (blocks s >= tiles):  XCD x -> hashed level ND+8+(x&3)    , tiles of
+//            parity x>>2, together with dense level (x&3)
+// (8-level tables have 4 hashed levels: phase B only).  Features are written as
+// level-major planes [L][stride] of packed half2 (coalesced 256 B per wave) and
+// consumed by k_field<..., PLANES>.  Per-level arithmetic is identical to
+// level_loads/level_reduce, so the features are bit-identical.
+// Hashed levels use the x-neighbour pairing: for even cx the two corners differ in
+// index bit 0 only -> one aligned 8-byte load; odd cx adds a predicated 4-byte load.
+// ---------------------------------------------------------------------------
+#ifndef IA_ENC_S
+#define IA_ENC_S 4  // samples per thread (gathers in flight per lane = 8 * S)
+#endif
+#define IA_ENC_THREADS 256
+#define IA_ENC_TILE (IA_ENC_S * IA_ENC_THREADS)
+#ifndef IA_ENC_MAX_WG_PER_XCD
+#define IA_ENC_MAX_WG_PER_XCD 256  // 32 CUs x 8 resident workgroups
+#endif
+
+__device__ __forceinline__ void hashed_pair_loads(const uint32_t *__restrict__ tab, float scale, uint32_t mask,
+                                                  const float xn[3], float w[3], uint32_t px[4], uint32_t py[4],
+                                                  uint32_t ext[4], uint32_t &meta) {
+  uint32_t g[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float pos = __builtin_fmaf(xn[d], scale, 0.5f);
+    const float fl = floorf(pos);
+    g[d] = (uint32_t)(int)fl;
+    w[d] = pos - fl;
+  }
+  const bool odd = g[0] & 1u;
+  meta = odd ? 16u : 0u;
+#pragma unroll
+  for (int pr = 0; pr < 4; pr++) {
+    const uint32_t cy = g[1] + (pr & 1), cz = g[2] + (pr >> 1);
+    const uint32_t hsh = (cy * 2654435761u) ^ (cz * 805459861u);
+    const uint32_t i0 = (g[0] ^ hsh) & mask;
+    const uint2 pair = *reinterpret_cast<const uint2 *>(tab + (i0 & ~1u));
+    px[pr] = pair.x;
+    py[pr] = pair.y;
+    meta |= (i0 & 1u) << pr;
+    ext[pr] = 0u;
+    if (odd) ext[pr] = tab[((g[0] + 1) ^ hsh) & mask];
+  }
+}
+
+__device__ __forceinline__ uint32_t hashed_pair_reduce(const float w[3], const uint32_t px[4], const uint32_t py[4],
+                                                       const uint32_t ext[4], uint32_t meta) {
+  _Float16 r0 = (_Float16)0.f, r1 = (_Float16)0.f;
+  const bool odd = meta & 16u;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    float wt = 1.f;
+    wt *= (idx & 1) ? w[0] : 1.f - w[0];
+    wt *= (idx & 2) ? w[1] : 1.f - w[1];
+    wt *= (idx & 4) ? w[2] : 1.f - w[2];
+    const int pr = idx >> 1;
+    const bool hi0 = (meta >> pr) & 1u;  // corner cx sits in the upper half of its aligned pair
+    const uint32_t c0 = hi0 ? py[pr] : px[pr];
+    const uint32_t c1 = odd ? ext[pr] : (hi0 ? px[pr] : py[pr]);
+    union { uint32_t u; half2v h; } c;
+    c.u = (idx & 1) ? c1 : c0;
+    r0 = r0 + (_Float16)(wt * (float)c.h.x);
+    r1 = r1 + (_Float16)(wt * (float)c.h.y);
+  }
+  union { uint32_t u; half2v h; } o;
+  o.h.x = r0; o.h.y = r1;
+  return o.u;
+}
+
+template <int L>
+__global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__restrict__ x, int V,
+                                                                const int32_t *__restrict__ n_dev, FieldDev F,
+                                                                uint32_t *__restrict__ planes, size_t stride) {
+  constexpr int ND = 4, NH = L - ND;  // tcnn default pattern (checked by the host)
+  if (n_dev) V = min(V, *n_dev);
+  const int n_tiles = (V + IA_ENC_TILE - 1) / IA_ENC_TILE;
+  const int n_items = (NH > 4 ? n_tiles : 0) + (n_tiles + 1) / 2;  // per XCD
+  const int xcd = blockIdx.x & 7;
+  for (int s = blockIdx.x >> 3; s < n_items; s += gridDim.x >> 3) {
+    int tile, lev_h, lev_d;
+    if (NH > 4 && s < n_tiles) {
+      tile = s; lev_h = ND + xcd; lev_d = -1;
+    } else {
+      const int sb = NH > 4 ? s - n_tiles : s;
+      tile = 2 * sb + (xcd >> 2); lev_h = (NH > 4 ? ND + 8 : ND) + (xcd & 3); lev_d = xcd & 3;
+    }
+    if (tile >= n_tiles) continue;
+    const int base = tile * IA_ENC_TILE + threadIdx.x;
+    float xn[IA_ENC_S][3];
+#pragma unroll
+    for (int k = 0; k < IA_ENC_S; k++) {
+      const int i = base + k * IA_ENC_THREADS;
+      xn[k][0] = xn[k][1] = xn[k][2] = 0.f;
+      if (i < V) normalise(F, x, (size_t)i, xn[k]);
+    }
+    {
+      const uint32_t *tab = F.table + F.hash_base + (uint32_t)(lev_h - ND) * F.hash_size;
+      const float scale = F.lv.scale[lev_h];
+      float w[IA_ENC_S][3];
+      uint32_t px[IA_ENC_S][4], py[IA_ENC_S][4], ext[IA_ENC_S][4], meta[IA_ENC_S];
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) hashed_pair_loads(tab, scale, F.hash_size - 1, xn[k], w[k], px[k], py[k], ext[k], meta[k]);
+      uint32_t *out = planes + (size_t)lev_h * stride;
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) {
+        const int i = base + k * IA_ENC_THREADS;
+        const uint32_t f = hashed_pair_reduce(w[k], px[k], py[k], ext[k], meta[k]);
+        if (i < V) out[i] = f;
+      }
+    }
+    if (lev_d >= 0) {
+      const uint32_t *tab = F.table + F.lv.offset[lev_d];
+      const float scale = F.lv.scale[lev_d];
+      const uint32_t res = F.lv.res[lev_d], size = F.lv.size[lev_d];
+      float w[IA_ENC_S][3];
+      uint32_t lo[IA_ENC_S][4], hi[IA_ENC_S][4], ext[IA_ENC_S][4], meta[IA_ENC_S];
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) level_loads<1>(tab, scale, res, size, xn[k], w[k], lo[k], hi[k], ext[k], meta[k]);
+      uint32_t *out = planes + (size_t)lev_d * stride;
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) {
+        const int i = base + k * IA_ENC_THREADS;
+        const uint32_t f = level_reduce<1>(w[k], lo[k], hi[k], ext[k], meta[k]);
+        if (i < V) out[i] = f;
+      }
+    }
+  }
+}
+
+static inline bool ia_field_shardable(const FieldDev &F) {
+  const int L = F.lv.n_levels;
+  return (L == 8 || L == 16) && F.n_dense == 4 && F.hash_size != 0 && (F.hash_size & (F.hash_size - 1)) == 0;
+}
+
+static int ia_launch_encode_xcd(const float *x, int V, const int32_t *n_dev, const FieldDev &F, uint32_t *planes,
+                                size_t stride, hipStream_t s) {
+  const int tiles = (V + IA_ENC_TILE - 1) / IA_ENC_TILE;
+  const int L = F.lv.n_levels;
+  int per_xcd = (L == 16 ? tiles : 0) + (tiles + 1) / 2;
+  if (per_xcd > IA_ENC_MAX_WG_PER_XCD) per_xcd = IA_ENC_MAX_WG_PER_XCD;  // workgroups loop over their XCD's items
+  if (L == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_encode_xcd<16>), dim3(8 * per_xcd), dim3(IA_ENC_THREADS), 0, s, x, V, n_dev, F, planes, stride);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_encode_xcd<8>), dim3(8 * per_xcd), dim3(IA_ENC_THREADS), 0, s, x, V, n_dev, F, planes, stride);
+  IA_LAUNCH_CHECK("k_encode_xcd");
+  return IA_OK;
+}
+
 template <bool RELU>
 __device__ __forceinline__ half8 pack_slab(const floatx16 &acc, int sub) {
   half8 o;
@@ -310,12 +470,13 @@ __device__ __forceinline__ void save_rows(uint16_t *__restrict__ dst, const floa
 #endif
 #define IA_FIELD_WAVES (IA_FIELD_THREADS / 64)
 
-template <int L, bool SAVE, int NLDS, int NDENSE>
+template <int L, bool SAVE, int NLDS, int NDENSE, bool PLANES = false>
 __global__ __launch_bounds__(IA_FIELD_THREADS) void k_field(const float *__restrict__ x, int V,
                                                const int32_t *__restrict__ n_dev, FieldDev F,
                                                float *__restrict__ rgb, float *__restrict__ sigma,
                                                unsigned long long *prof, uint16_t *__restrict__ acts,
-                                               int lds_entries) {
+                                               int lds_entries, const uint32_t *__restrict__ planes = nullptr,
+                                               size_t plane_stride = 0) {
   constexpr int ACT_STRIDE = 2 * L + 64 + 16 + 64 + 64;
   extern __shared__ __attribute__((aligned(16))) char s_dyn[];
   half8 (*s_frag)[64] = reinterpret_cast<half8 (*)[64]>(s_dyn);
@@ -352,10 +513,15 @@ __global__ __launch_bounds__(IA_FIELD_THREADS) void k_field(const float *__restr
   const int h = lane >> 5, j = lane & 31;
   for (; tile < n_tiles; tile += tile_stride) {
     const int i = tile * 64 + lane;
-    float xn[3] = {0.f, 0.f, 0.f};
-    if (i < V) normalise(F, x, (size_t)i, xn);
     uint32_t feat[L];
-    encode_all<L, NLDS, NDENSE>(F, s_tab, xn, feat);
+    if (PLANES) {  // features were produced by k_encode_xcd (level-major planes)
+#pragma unroll
+      for (int l = 0; l < L; l++) feat[l] = i < V ? planes[(size_t)l * plane_stride + i] : 0u;
+    } else {
+      float xn[3] = {0.f, 0.f, 0.f};
+      if (i < V) normalise(F, x, (size_t)i, xn);
+      encode_all<L, NLDS, NDENSE>(F, s_tab, xn, feat);
+    }
     if (SAVE && i < V) {
       uint4 *o = reinterpret_cast<uint4 *>(acts + (size_t)i * ACT_STRIDE);
 #pragma unroll
@@ -467,6 +633,10 @@ __global__ __launch_bounds__(256) void k_hashgrid(const float *__restrict__ x, i
   }
 }
 
+#ifndef IA_SHARD_MIN
+#define IA_SHARD_MIN 8192  // below this a call is launch-latency bound: one fused kernel
+#endif
+
 int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb,
                     float *sigma, hipStream_t s, uint16_t *acts) {
   if (V <= 0) return IA_OK;
@@ -476,7 +646,8 @@ int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev 
   int n_dense = 0;
   while (n_dense < F.lv.n_levels && !F.lv.hashed[n_dense]) n_dense++;
   bool pattern = n_dense == 4 && F.hash_size != 0 && (int)F.n_dense == n_dense;
-  const int lds_entries = pattern ? (int)((F.lv.offset[2] + 3) / 4 * 4) : 0;
+  const bool sharded = F.enc_ws && (size_t)V <= F.enc_ws_samples && V >= IA_SHARD_MIN && ia_field_shardable(F);
+  const int lds_entries = (pattern && !sharded) ? (int)((F.lv.offset[2] + 3) / 4 * 4) : 0;
   pattern = pattern && (size_t)lds_entries * 4 <= 72 * 1024 && F.lv.offset[0] == 0;
   const size_t shmem = (size_t)N_FRAG * 64 * 16 + (pattern ? (size_t)lds_entries * 4 : 0);
   static bool attr_done = false;
@@ -492,14 +663,23 @@ int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev 
   ia_prof_begin(IA_PROF_FIELD, s);
   const dim3 g(blocks), b(IA_FIELD_THREADS);
   const int L16 = F.lv.n_levels == 16;
-#define IA_LF(LV, SV, NL, ND) \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<LV, SV, NL, ND>), g, b, shmem, s, x, V, n_dev, F, rgb, sigma, prof, acts, pattern ? lds_entries : 0)
-  if (pattern) {
-    if (acts) { if (L16) IA_LF(16, true, 2, 4); else IA_LF(8, true, 2, 4); }
-    else { if (L16) IA_LF(16, false, 2, 4); else IA_LF(8, false, 2, 4); }
+  const uint32_t *planes = nullptr;
+  const size_t stride = F.enc_ws_samples;
+#define IA_LF(LV, SV, NL, ND, PL) \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field<LV, SV, NL, ND, PL>), g, b, shmem, s, x, V, n_dev, F, rgb, sigma, prof, acts, \
+                     pattern ? lds_entries : 0, planes, stride)
+  if (sharded) {
+    int rc = ia_launch_encode_xcd(x, V, n_dev, F, F.enc_ws, stride, s);
+    if (rc != IA_OK) return rc;
+    planes = F.enc_ws;
+    if (acts) { if (L16) IA_LF(16, true, 0, 4, true); else IA_LF(8, true, 0, 4, true); }
+    else { if (L16) IA_LF(16, false, 0, 4, true); else IA_LF(8, false, 0, 4, true); }
+  } else if (pattern) {
+    if (acts) { if (L16) IA_LF(16, true, 2, 4, false); else IA_LF(8, true, 2, 4, false); }
+    else { if (L16) IA_LF(16, false, 2, 4, false); else IA_LF(8, false, 2, 4, false); }
   } else {
-    if (acts) { if (L16) IA_LF(16, true, 0, -1); else IA_LF(8, true, 0, -1); }
-    else { if (L16) IA_LF(16, false, 0, -1); else IA_LF(8, false, 0, -1); }
+    if (acts) { if (L16) IA_LF(16, true, 0, -1, false); else IA_LF(8, true, 0, -1, false); }
+    else { if (L16) IA_LF(16, false, 0, -1, false); else IA_LF(8, false, 0, -1, false); }
   }
 #undef IA_LF
   ia_prof_end(IA_PROF_FIELD, s);
@@ -635,6 +815,19 @@ extern "C" int ia_hashgrid_fwd(const float *x, int V, const ia_field *field, uin
                        reinterpret_cast<uint32_t *>(feat));
   IA_LAUNCH_CHECK("k_hashgrid");
   return IA_OK;
+}
+
+// Encoding only, XCD-sharded: planes [n_levels][stride] of packed half2 (level-major).
+extern "C" int ia_hashgrid_fwd_planes(const float *x, int V, const ia_field *field, uint32_t *planes, size_t stride,
+                                      void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_hashgrid_fwd_planes: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(x && planes && stride >= (size_t)V, "ia_hashgrid_fwd_planes: null pointer or stride < V");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_hashgrid_fwd_planes: bad field descriptor (%d)", rc);
+  IA_CHECK_ARG(ia_field_shardable(F), "ia_hashgrid_fwd_planes: level table is not 4 dense + 4/12 uniform hashed levels");
+  return ia_launch_encode_xcd(x, V, nullptr, F, planes, stride, (hipStream_t)stream);
 }
 
 extern "C" int ia_hash_desc_init(ia_hash_desc *o, int n_levels, int log2_hashmap_size, int base_resolution,

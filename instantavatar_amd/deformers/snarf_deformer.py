@@ -211,7 +211,7 @@ class SNARFDeformer():
         tfs = self.tfs.detach().float().contiguous()
         _lib.check(L.ia_deform_query(_lib.ptr(pts), P, None, _lib.ptr(self.deformer.voxel_J_cl), _lib.ptr(tfs),
                                      self.deformer._bones_c, k, C.byref(self.deformer.grid_desc()),
-                                     C.byref(net.field_desc()), _lib.ptr(rgb), _lib.ptr(sigma), _lib.ptr(dmax),
+                                     C.byref(net.field_desc(P * k)), _lib.ptr(rgb), _lib.ptr(sigma), _lib.ptr(dmax),
                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_deform_query")
         return rgb, sigma
 

@@ -110,8 +110,28 @@ class NeRFNGPNet(nn.Module):
             self._desc = None
         return self._half
 
-    def field_desc(self):
+    #: upper bound of the XCD-sharded encoding scratch (64 B per sample); larger calls use the
+    #: single fused kernel.  0 disables the sharded path.
+    max_encode_workspace_bytes = 1 << 30
+
+    def _reserve_encode_workspace(self, n_samples, device):
+        """Level-plane scratch of the XCD-sharded encoding (`ia_field.enc_ws`): grown on demand,
+        never shrunk (so a captured HIP graph keeps valid pointers once sizes have settled)."""
+        have = getattr(self, "_enc_ws_samples", 0)
+        if n_samples <= have or n_samples * 4 * self.n_levels > self.max_encode_workspace_bytes:
+            return
+        n = (int(n_samples) + 1023) // 1024 * 1024
+        self._enc_ws = torch.empty((self.n_levels, n), dtype=torch.int32, device=device)
+        self._enc_ws_samples = n
+        if self._desc is not None:
+            self._desc.enc_ws, self._desc.enc_ws_samples = self._enc_ws.data_ptr(), n
+
+    def field_desc(self, max_samples=0):
+        """C descriptor of the field.  `max_samples`: largest sample count (capacity) of the
+        call it is built for; reserves the sharded-encoding scratch for it."""
         enc, col = self._half_params()
+        if max_samples:
+            self._reserve_encode_workspace(max_samples, enc.device)
         if self._desc is None:
             f = _lib.Field()
             f.center[:] = self.center.detach().float().cpu().tolist()  # rare (init / bbox change) host read
@@ -130,6 +150,8 @@ class NeRFNGPNet(nn.Module):
             self._frags = torch.empty(L.ia_field_frags_bytes() // 2, dtype=torch.float16, device=enc.device)
             _lib.check(L.ia_field_prepare(C.byref(f), _lib.ptr(self._frags), _lib.stream()), "ia_field_prepare")
             f.mlp_frags = self._frags.data_ptr()
+            if getattr(self, "_enc_ws_samples", 0):
+                f.enc_ws, f.enc_ws_samples = self._enc_ws.data_ptr(), self._enc_ws_samples
             self._desc = f
         return self._desc
 
@@ -145,7 +167,7 @@ class NeRFNGPNet(nn.Module):
         V = xc.shape[0]
         rgb = torch.empty((V, 3), device=x.device)
         sigma = torch.empty(V, device=x.device)
-        _lib.check(_lib.lib().ia_field_fwd(_lib.ptr(xc), V, None, C.byref(self.field_desc()), _lib.ptr(rgb),
+        _lib.check(_lib.lib().ia_field_fwd(_lib.ptr(xc), V, None, C.byref(self.field_desc(V)), _lib.ptr(rgb),
                                            _lib.ptr(sigma), _lib.stream()), "ia_field_fwd")
         return rgb, sigma
 
@@ -157,3 +179,14 @@ class NeRFNGPNet(nn.Module):
         _lib.check(_lib.lib().ia_hashgrid_fwd(_lib.ptr(xc), xc.shape[0], C.byref(self.field_desc()), _lib.ptr(feat),
                                               _lib.stream()), "ia_hashgrid_fwd")
         return feat
+
+    def encode_planes(self, x):
+        """hash-grid features from the XCD-sharded kernel: int32 [n_levels, V] of packed half2
+        (level-major planes, what the fused field kernel consumes)."""
+        _lib.require_cuda(x)
+        xc = x.detach().reshape(-1, 3).float().contiguous()
+        V = xc.shape[0]
+        planes = torch.empty((self.n_levels, V), device=x.device, dtype=torch.int32)
+        _lib.check(_lib.lib().ia_hashgrid_fwd_planes(_lib.ptr(xc), V, C.byref(self.field_desc()), _lib.ptr(planes), V,
+                                                     _lib.stream()), "ia_hashgrid_fwd_planes")
+        return planes

@@ -119,7 +119,7 @@ class DensityGrid(torch.nn.Module):
             _lib.check(L.ia_density_grid_init(_lib.ptr(jitter), iters, G, _lib.ptr(self.aabb_tensor()),
                                               _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs),
                                               deformer.deformer._bones_c, k, C.byref(deformer.deformer.grid_desc()),
-                                              C.byref(net.field_desc()), _lib.ptr(density), _lib.ptr(self.occ_bits),
+                                              C.byref(net.field_desc(G * G * G * k)), _lib.ptr(density), _lib.ptr(self.occ_bits),
                                               _lib.ptr(out8), _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "ia_density_grid_init")
             self.density_field = out8.bool()

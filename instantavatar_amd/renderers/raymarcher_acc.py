@@ -180,7 +180,8 @@ class Raymarcher(torch.nn.Module):
             _lib.check(L.ia_render_test(_lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), R, _lib.ptr(bg),
                                         _lib.ptr(grid.occ_bits), grid.grid_size, _lib.ptr(aabb),
                                         _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs), deformer.deformer._bones_c,
-                                        k, C.byref(deformer.deformer.grid_desc()), C.byref(net.field_desc()),
+                                        k, C.byref(deformer.deformer.grid_desc()),
+                                        C.byref(net.field_desc(self.MAX_BATCH_SIZE * k)),
                                         self.MAX_SAMPLES, self.MAX_BATCH_SIZE, n_iters, resume, _lib.ptr(rgb),
                                         _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(counter),
                                         _lib.ptr(self._n_alive_dev), _lib.ptr(self._ws), self._ws.numel(),

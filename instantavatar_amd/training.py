@@ -48,7 +48,7 @@ class _FieldFn(torch.autograd.Function):
         acts = torch.empty((V, stride), device=x.device, dtype=torch.float16)
         rgb = torch.empty((V, 3), device=x.device)
         sigma = torch.empty(V, device=x.device)
-        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, C.byref(net.field_desc()), _lib.ptr(rgb), _lib.ptr(sigma),
+        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, C.byref(net.field_desc(V)), _lib.ptr(rgb), _lib.ptr(sigma),
                                         _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
         ctx.net = net
         ctx.need_dx = x.requires_grad

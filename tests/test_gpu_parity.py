@@ -140,6 +140,33 @@ def test_field_forward(oracle, gpu_world):
             assert sig_o.max() > 50 and sig_o.min() < -50  # the synthetic field is not trivial
 
 
+def test_xcd_sharded_encoding_equals_fused_kernel(gpu_world):
+    """The level-sharded encoding (one hashed level per XCD L2, x-neighbour pair loads) must
+    produce bit-identical features, and the two-pass field bit-identical rgb / sigma."""
+    model, body, fp, init, poses, tr = gpu_world
+    rng = np.random.RandomState(21)
+    bb = init["bbox"]
+    for n_levels in (16, 8):
+        net = model.net_coarse if n_levels == 16 else W.build(DEV, 64, 8)[0].net_coarse
+        for n in (1, 1023, 1025, 8192, 100003):
+            x = (rng.rand(n, 3) * (bb[1] - bb[0]) * 1.1 + bb[0] - 0.05 * (bb[1] - bb[0])).astype(np.float32)
+            xt = torch.as_tensor(x, device=DEV)
+            row = net.encode(xt).view(torch.int32)                       # [V, L] packed half2
+            planes = net.encode_planes(xt)                               # [L, V]
+            assert torch.equal(planes.t().contiguous(), row), (n_levels, n)
+            with torch.no_grad():
+                saved = net.max_encode_workspace_bytes
+                try:
+                    net.max_encode_workspace_bytes = 0
+                    net._enc_ws_samples, net._enc_ws, net._desc = 0, None, None
+                    rgb0, sig0 = net(xt, None)                           # fused single kernel
+                finally:
+                    net.max_encode_workspace_bytes = saved
+                net._desc = None
+                rgb1, sig1 = net(xt, None)                               # sharded two-pass (n >= 8192)
+            assert torch.equal(rgb0, rgb1) and torch.equal(sig0, sig1), (n_levels, n)
+
+
 def test_deform_query_fused_vs_oracle(oracle, gpu_world):
     model, body, fp, init, poses, tr = gpu_world
     _prepare(model, poses, tr, 1)

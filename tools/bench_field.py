@@ -26,5 +26,9 @@ for mode in ("uniform", "sorted"):
         with torch.no_grad():
             t_f = timeit(lambda: net(x, None))
             t_h = timeit(lambda: net.encode(x))
-        print("%-8s V=%8d  field %9.1f us  %6.2f Gsamples/s  (%.0f GB/s alg)   hashgrid-only %9.1f us %6.2f Gs/s (%.0f GB/s)" % (
-            mode, V, t_f, V / t_f * 1e-3, V / t_f * 1e-3 * 540, t_h, V / t_h * 1e-3, V / t_h * 1e-3 * (512 + 12 + 64)))
+            t_p = timeit(lambda: net.encode_planes(x))
+            net.max_encode_workspace_bytes = 0; net._enc_ws_samples = 0; net._desc = None
+            t_f0 = timeit(lambda: net(x, None))
+            net.max_encode_workspace_bytes = 1 << 30; net._desc = None
+        print("%-8s V=%8d  field sharded %8.1f us %5.2f Gs/s | fused %8.1f us %5.2f Gs/s || encode sharded %8.1f us %5.2f Gs/s (%4.0f GB/s) | fused %8.1f us %5.2f Gs/s" % (
+            mode, V, t_f, V / t_f * 1e-3, t_f0, V / t_f0 * 1e-3, t_p, V / t_p * 1e-3, V / t_p * 1e-3 * 512, t_h, V / t_h * 1e-3))
