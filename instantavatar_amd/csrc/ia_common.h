@@ -1,6 +1,7 @@
 // ia_common.h -- shared helpers for the gfx950 kernels (wave64 everywhere).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -76,7 +77,8 @@ struct OccDev {
 #define IA_PROF_N 2
 #define IA_PROF_SEARCH 0   // units[0] = (point,init) solves, units[1] = grid fetches
 #define IA_PROF_FIELD 1    // units[0] = samples evaluated
-unsigned long long *ia_prof_units(int id);
+#define IA_PROF_SHARDS 64
+unsigned long long *ia_prof_units(int id);  // [IA_PROF_SHARDS][8] words; counters 0/1 of shard s at [s*8 + {0,1}]
 void ia_prof_begin(int id, hipStream_t s);
 void ia_prof_end(int id, hipStream_t s);
 
@@ -85,6 +87,43 @@ void ia_prof_end(int id, hipStream_t s);
 // operation sequence shared with the CPU checker: contraction is switched off in
 // those functions and every `sum + x*y` is an explicit fma into the running sum.
 #define IA_DOT3(a0, b0, a1, b1, a2, b2) __builtin_fmaf((a2), (b2), __builtin_fmaf((a1), (b1), (a0) * (b0)))
+
+// ---- Fast-SNARF helpers shared by the search kernel and its callers ----------------------
+struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
+static inline int ia_make_bones(const int32_t *bone_ids, int n_init, BoneIds *b) {
+  if (!bone_ids || n_init < 1 || n_init > IA_N_INIT_MAX) return -1;
+  for (int i = 0; i < IA_N_INIT_MAX; i++) b->id[i] = i < n_init ? bone_ids[i] : 0;
+  for (int i = 0; i < n_init; i++) if (bone_ids[i] < 0 || bone_ids[i] >= IA_N_JOINTS) return -1;
+  return 0;
+}
+
+// grid_sample un-normalisation, align_corners = true (fuse_cuda_kernel_fast.cu:62-91)
+__device__ __forceinline__ float src_index(float coord, int size) {
+  coord = ((coord + 1.f) / 2) * (size - 1);
+  if (coord > (float)(INT_MAX - 1) || coord < (float)INT_MIN || !isfinite(coord)) return -100.0f;
+  return coord;
+}
+
+// true when none of the 8 trilinear corners of the fetch at normalised (gx,gy,gz) lies inside
+// the grid, i.e. the fetch returns J = 0 without touching memory
+__device__ __forceinline__ bool fetch_all_oob(const SnarfGridDev &g, float gx, float gy, float gz) {
+  const int x0 = (int)floorf(src_index(gx, g.W)), y0 = (int)floorf(src_index(gy, g.H)), z0 = (int)floorf(src_index(gz, g.D));
+  return x0 < -1 || x0 >= g.W || y0 < -1 || y0 >= g.H || z0 < -1 || z0 >= g.D;
+}
+
+// A (point x_d, init bone with transform T[4x4]) solve is TRIVIAL when the fetch at its initial
+// guess x0 = R^T (x_d - t) (fuse_cuda_kernel_fast.cu:287-293) has all 8 corners outside the
+// grid: J = 0 gives J_inv0 = 0, the update is 0, x never moves, every later fetch is zero too and
+// the residual stays -x_d -- the reference kernel ends in `diverged`, in `converged` with the
+// bounds test failing, or in ten iterations of NaN: never a valid root.
+__device__ __forceinline__ bool ia_solve_is_trivial(const SnarfGridDev &g, const float *__restrict__ T, float a0,
+                                                    float a1, float a2) {
+  const float ixd = a0 - T[3], iyd = a1 - T[7], izd = a2 - T[11];
+  const float c0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
+  const float c1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
+  const float c2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
+  return fetch_all_oob(g, g.scl[0] * (c0 + g.off[0]), g.scl[1] * (c1 + g.off[1]), g.scl[2] * (c2 + g.off[2]));
+}
 
 // ---- wave helpers -----------------------------------------------------------
 __device__ __forceinline__ int ia_lane() { return threadIdx.x & 63; }

@@ -3,7 +3,7 @@
 // device-side counters of the units they processed.  Disabled by default; when
 // disabled no event is recorded and the kernels receive a null counter pointer.
 // (Profiling mode is the only place where the library allocates device memory:
-// 32 bytes of counters.)
+// a few KB of sharded counters.)
 #include <vector>
 
 #include "ia_common.h"
@@ -14,9 +14,13 @@ struct ProfKernel {
 };
 static bool g_prof_on = false;
 static ProfKernel g_prof[IA_PROF_N];
-static unsigned long long *g_prof_units = nullptr;  // device [IA_PROF_N * 2]
+// device [IA_PROF_N][IA_PROF_SHARDS][8]: counters 0/1 of a shard share one 64-byte line; kernels add
+// to shard (blockIdx & (IA_PROF_SHARDS-1)) once per workgroup so that the accounting never
+// serialises on a single address (one word saturates at ~88 atomics/us)
+static unsigned long long *g_prof_units = nullptr;
+#define IA_PROF_WORDS (IA_PROF_N * IA_PROF_SHARDS * 8)
 
-unsigned long long *ia_prof_units(int id) { return (g_prof_on && g_prof_units) ? g_prof_units + 2 * id : nullptr; }
+unsigned long long *ia_prof_units(int id) { return (g_prof_on && g_prof_units) ? g_prof_units + (size_t)id * IA_PROF_SHARDS * 8 : nullptr; }
 
 void ia_prof_begin(int id, hipStream_t s) {
   if (!g_prof_on) return;
@@ -37,9 +41,9 @@ void ia_prof_end(int id, hipStream_t s) {
 
 extern "C" int ia_profile_enable(int on) {
   if (on && !g_prof_units) {
-    if (hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * IA_PROF_N * 2) != hipSuccess)
+    if (hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * IA_PROF_WORDS) != hipSuccess)
       return ia_set_error(IA_ERR_LAUNCH, "ia_profile_enable: hipMalloc failed");
-    (void)hipMemset(g_prof_units, 0, sizeof(unsigned long long) * IA_PROF_N * 2);
+    (void)hipMemset(g_prof_units, 0, sizeof(unsigned long long) * IA_PROF_WORDS);
   }
   g_prof_on = on != 0;
   return IA_OK;
@@ -47,7 +51,7 @@ extern "C" int ia_profile_enable(int on) {
 
 extern "C" int ia_profile_reset(void) {
   for (int i = 0; i < IA_PROF_N; i++) g_prof[i].used = 0;
-  if (g_prof_units) (void)hipMemset(g_prof_units, 0, sizeof(unsigned long long) * IA_PROF_N * 2);
+  if (g_prof_units) (void)hipMemset(g_prof_units, 0, sizeof(unsigned long long) * IA_PROF_WORDS);
   return IA_OK;
 }
 
@@ -66,7 +70,11 @@ extern "C" int ia_profile_get(int id, double *total_ms, int64_t *launches, uint6
   if (launches) *launches = (int64_t)k.used;
   if (units) {
     units[0] = units[1] = 0;
-    if (g_prof_units) (void)hipMemcpy(units, g_prof_units + 2 * id, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (g_prof_units) {
+      std::vector<unsigned long long> h((size_t)IA_PROF_SHARDS * 8);
+      (void)hipMemcpy(h.data(), g_prof_units + (size_t)id * IA_PROF_SHARDS * 8, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      for (int sh = 0; sh < IA_PROF_SHARDS; sh++) { units[0] += h[(size_t)sh * 8]; units[1] += h[(size_t)sh * 8 + 1]; }
+    }
   }
   return IA_OK;
 }

@@ -190,12 +190,11 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
 // align_corners=true (fuse_cuda_kernel_fast.cu:62-108,110-230).  J is
 // channel-last: a corner is 3 x float4.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float src_index(float coord, int size) {
-  coord = ((coord + 1.f) / 2) * (size - 1);
-  if (coord > (float)(INT_MAX - 1) || coord < (float)INT_MIN || !isfinite(coord)) return -100.0f;
-  return coord;
-}
 
+// All 24 loads of a fetch are issued before the first use: corners outside the grid (zero
+// padding) read a clamped in-range address and get weight 0 -- fma(v, 0, acc) == acc for the
+// finite table values, so the result equals the reference's "skip the corner" bit for bit --
+// which removes the per-corner control flow that would serialise eight memory round trips.
 __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const SnarfGridDev &g, float gx,
                                         float gy, float gz, float *__restrict__ out) {
   const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
@@ -208,21 +207,45 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   const bool bx0 = x0 >= 0 && x0 < g.W, bx1 = x1 >= 0 && x1 < g.W;
   const bool by0 = y0 >= 0 && y0 < g.H, by1 = y1 >= 0 && y1 < g.H;
   const bool bz0 = z0 >= 0 && z0 < g.D, bz1 = z1 >= 0 && z1 < g.D;
+  const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
+  const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
+  const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
+#ifndef IA_FETCH_GROUP
+#define IA_FETCH_GROUP 4  // corners whose loads are in flight together (two round trips, 48 data VGPRs)
+#endif
+  // accumulators as float2 pairs: the 12 FMAs of a corner become 6 v_pk_fma_f32 (IEEE fma per half)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 acc[6];
 #pragma unroll
-  for (int c = 0; c < 12; c++) out[c] = 0.f;
+  for (int c = 0; c < 6; c++) acc[c] = (f2){0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int xx = (k & 1) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 4) ? z1 : z0;
-    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
-    if (in) {
-      const float4 *p = reinterpret_cast<const float4 *>(vJ + ((size_t)(zz * g.H + yy) * g.W + xx) * 12);
-      const float4 a = p[0], b = p[1], c = p[2];
-      const float w = wgt[k];
-      const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+  for (int k0 = 0; k0 < 8; k0 += IA_FETCH_GROUP) {
+    float4 ra[IA_FETCH_GROUP], rb[IA_FETCH_GROUP], rc[IA_FETCH_GROUP];
 #pragma unroll
-      for (int q = 0; q < 12; q++) out[q] = __builtin_fmaf(v[q], w, out[q]);
+    for (int j = 0; j < IA_FETCH_GROUP; j++) {
+      const int k = k0 + j;
+      const int xx = (k & 1) ? cx1 : cx0, yy = (k & 2) ? cy1 : cy0, zz = (k & 4) ? cz1 : cz0;
+      const float4 *p = reinterpret_cast<const float4 *>(vJ + (uint32_t)((zz * g.H + yy) * g.W + xx) * 12u);
+      ra[j] = p[0]; rb[j] = p[1]; rc[j] = p[2];
+    }
+#pragma unroll
+    for (int j = 0; j < IA_FETCH_GROUP; j++) {
+      const int k = k0 + j;
+      const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
+      const float w = in ? wgt[k] : 0.f;
+      const f2 w2 = (f2){w, w};
+      const f2 v[6] = {(f2){ra[j].x, ra[j].y}, (f2){ra[j].z, ra[j].w}, (f2){rb[j].x, rb[j].y},
+                       (f2){rb[j].z, rb[j].w}, (f2){rc[j].x, rc[j].y}, (f2){rc[j].z, rc[j].w}};
+#pragma unroll
+      for (int q = 0; q < 6; q++) acc[q] = __builtin_elementwise_fma(v[q], w2, acc[q]);
+    }
+    if (IA_FETCH_GROUP < 8) {
+      asm volatile("" ::: "memory");  // the next group's loads stay below this group's FMAs
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+#pragma unroll
+  for (int c = 0; c < 6; c++) { out[2 * c] = acc[c].x; out[2 * c + 1] = acc[c].y; }
 }
 
 // fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55)
@@ -242,14 +265,7 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
   Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
 }
 
-// true when none of the 8 trilinear corners of the fetch at normalised (gx,gy,gz) lies inside
-// the grid, i.e. fetch_J would return J = 0 without touching memory
-__device__ __forceinline__ bool fetch_all_oob(const SnarfGridDev &g, float gx, float gy, float gz) {
-  const int x0 = (int)floorf(src_index(gx, g.W)), y0 = (int)floorf(src_index(gy, g.H)), z0 = (int)floorf(src_index(gz, g.D));
-  return x0 < -1 || x0 >= g.W || y0 < -1 || y0 >= g.H || z0 < -1 || z0 >= g.D;
-}
 
-struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
 
 // ---------------------------------------------------------------------------
 // a4 + a5 search kernel with LANE REFILL.
@@ -266,11 +282,23 @@ struct BoneIds { int32_t id[IA_N_INIT_MAX]; };
 // Afterwards the workgroup runs the duplicate filter and either writes the dense
 // reference layout (MODE 0) or compacts the surviving roots (MODE 1).
 // ---------------------------------------------------------------------------
-#define IA_SEARCH_NP 128       // points per workgroup
-#define IA_SEARCH_THREADS 256  // 4 waves
+// Measured on MI355X (512^2 frame, graph mode): 256 threads x 128 points 3.86 ms, 128 x 64 3.70 ms,
+// 64 x 32 3.79 ms, 64 x 64 4.07 ms, 128 x 128 4.19 ms -- two lanes per point keep enough waves in
+// flight, the smaller workgroup shortens the wait at the barrier before the filter.
+#ifndef IA_SEARCH_NP
+#define IA_SEARCH_NP 64        // points per workgroup (power of two, <= 128)
+#endif
+#ifndef IA_SEARCH_THREADS
+#define IA_SEARCH_THREADS 128  // multiple of IA_SEARCH_NP
+#endif
+#ifdef IA_SEARCH_WAVES_PER_EU
+#define IA_SEARCH_ATTR __attribute__((amdgpu_waves_per_eu(IA_SEARCH_WAVES_PER_EU, IA_SEARCH_WAVES_PER_EU)))
+#else
+#define IA_SEARCH_ATTR
+#endif
 
 template <int MODE>
-__global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
+__global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     const float *__restrict__ xd, int P, const int32_t *__restrict__ n_pts_dev,
     const float *__restrict__ vJ, const float *__restrict__ tfs, BoneIds bones, int n_init, SnarfGridDev g,
     float cvg2, float dvg2,
@@ -290,14 +318,17 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
   __shared__ int s_next;
   __shared__ int s_blockbase;
   __shared__ int s_nlive;
+  __shared__ int s_prof[2];
   __shared__ uint16_t s_list[IA_N_INIT_MAX * NP];
   if (n_pts_dev) P = min(P, *n_pts_dev);
   const int tid = threadIdx.x, lane = tid & 63;
+  // (an XCD-aware remap -- XCD x takes the x-th contiguous eighth of the point list -- was measured:
+  // the occupancy probes got 25 % slower, the slabs at the rim of the bounding box hold little live work)
   const int p0 = blockIdx.x * NP;
   if (p0 >= P) return;  // uniform per workgroup
   const int np = min(NP, P - p0);
   const int n_items = np * n_init;
-  if (tid == 0) { s_next = 0; s_nlive = 0; }
+  if (tid == 0) { s_next = 0; s_nlive = 0; s_prof[0] = 0; s_prof[1] = 0; }
   for (int e = tid; e < np * 3; e += IA_SEARCH_THREADS) (&s_xd[0][0])[e] = xd[(size_t)p0 * 3 + e];
   __syncthreads();
 
@@ -308,18 +339,14 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
   // the bounds test failing, or (1e-5 < |x_d| < 0.1) in ten iterations of NaN -- never valid.
   // Most (point, init) pairs of the occupancy probes are of this kind; they are resolved here,
   // and only the remaining items enter the queue, so the waves of the solver stay dense.
-  for (int q0 = 0; q0 < n_items; q0 += IA_SEARCH_THREADS) {
-    const int q = q0 + tid;
+  // items are (init << 7 | point): init-major, no integer division anywhere
+  static_assert((NP & (NP - 1)) == 0 && NP <= 128 && IA_SEARCH_THREADS % NP == 0, "item packing: NP = 2^k <= 128");
+  for (int init0 = 0; init0 < n_init; init0 += IA_SEARCH_THREADS / NP) {
+    const int init = init0 + tid / NP, pt = tid & (NP - 1);
+    const int q = (init << 7) | pt;
     bool keep = false;
-    if (q < n_items) {
-      const int init = q / np, pt = q - init * np;
-      const float a0 = s_xd[pt][0], a1 = s_xd[pt][1], a2 = s_xd[pt][2];
-      const float *T = tfs + bones.id[init] * 16;
-      const float ixd = a0 - T[3], iyd = a1 - T[7], izd = a2 - T[11];
-      const float c0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
-      const float c1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
-      const float c2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
-      keep = !fetch_all_oob(g, g.scl[0] * (c0 + g.off[0]), g.scl[1] * (c1 + g.off[1]), g.scl[2] * (c2 + g.off[2]));
+    if (init < n_init && pt < np) {
+      keep = !ia_solve_is_trivial(g, tfs + bones.id[init] * 16, s_xd[pt][0], s_xd[pt][1], s_xd[pt][2]);
       if (!keep) {
         s_x[init][pt][0] = 0.f; s_x[init][pt][1] = 0.f; s_x[init][pt][2] = 0.f;
         s_valid[init][pt] = 0;
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
         const int my = base + __popcll(need & ((1ull << lane) - 1ull));
         if (!active && my < n_live) {
           item = s_list[my];
-          const int init = item / np, pt = item - init * np;
+          const int init = item >> 7, pt = item & (NP - 1);
           t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
           const float *T = tfs + bones.id[init] * 16;
           // :287-293  x0 = R^T (xd - t)
@@ -379,20 +406,18 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
       fetch_J(vJ, g, ix, iy, iz, Jl);
       fetches++;
       bool done = false, ok = false;
+      // residual g(x) = J x + d - x_d at the current point (:325-332 initial, :356-367 updated)
+      const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
+      const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
+      const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
       if (first) {
-        // :302-311 J_inv0 = (J_3x3)^T ; :325-332 g(x0)
+        // :302-311 J_inv0 = (J_3x3)^T
         Ji[0] = Jl[0]; Ji[1] = Jl[4]; Ji[2] = Jl[8]; Ji[3] = Jl[1]; Ji[4] = Jl[5]; Ji[5] = Jl[9];
         Ji[6] = Jl[2]; Ji[7] = Jl[6]; Ji[8] = Jl[10];
-        gx0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3];
-        gx1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7];
-        gx2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11];
-        gx0 = gx0 - t0; gx1 = gx1 - t1; gx2 = gx2 - t2;
+        gx0 = n0; gx1 = n1; gx2 = n2;
         first = false;
       } else {
-        // :356-398 residual at the updated point, convergence / divergence tests
-        const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
-        const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
-        const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
+        // :368-398 convergence / divergence tests
         const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
         if (norm < cvg2) {
           done = true;
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
         }
       }
       if (done) {
-        const int init = item / np, pt = item - init * np;
+        const int init = item >> 7, pt = item & (NP - 1);
         s_x[init][pt][0] = ok ? xl0 : 0.f; s_x[init][pt][1] = ok ? xl1 : 0.f; s_x[init][pt][2] = ok ? xl2 : 0.f;
         s_valid[init][pt] = ok;
         if (MODE == 0 && J_inv) {
@@ -429,9 +454,14 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) void k_search(
     int f = fetches, n = solves;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); }
-    if (lane == 0) { atomicAdd(prof, (unsigned long long)n); atomicAdd(prof + 1, (unsigned long long)f); }
+    if (lane == 0) { atomicAdd(&s_prof[0], n); atomicAdd(&s_prof[1], f); }
   }
   __syncthreads();
+  if (prof && tid == 0) {  // one pair of global atomics per workgroup, on a per-shard line
+    unsigned long long *ps = prof + (size_t)(blockIdx.x & (IA_PROF_SHARDS - 1)) * 8;
+    atomicAdd(ps, (unsigned long long)s_prof[0]);
+    atomicAdd(ps + 1, (unsigned long long)s_prof[1]);
+  }
   // ---- a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4 ----
   for (int q = tid; q < n_items; q += IA_SEARCH_THREADS) {
     const int init = q / np, pt = q - init * np;
@@ -521,12 +551,6 @@ extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxe
   return IA_OK;
 }
 
-static int make_bones(const int32_t *bone_ids, int n_init, BoneIds *b) {
-  if (!bone_ids || n_init < 1 || n_init > IA_N_INIT_MAX) return -1;
-  for (int i = 0; i < IA_N_INIT_MAX; i++) b->id[i] = i < n_init ? bone_ids[i] : 0;
-  for (int i = 0; i < n_init; i++) if (bone_ids[i] < 0 || bone_ids[i] >= IA_N_JOINTS) return -1;
-  return 0;
-}
 
 extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, const float *tfs,
                                const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
@@ -536,7 +560,7 @@ extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, con
   if (P == 0) return IA_OK;
   IA_CHECK_ARG(xd && voxel_J && tfs && grid && xc && valid, "ia_snarf_search: null pointer");
   BoneIds b;
-  IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search: bad bone ids / n_init=%d", n_init);
+  IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search: bad bone ids / n_init=%d", n_init);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0,
                      (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
                      ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
@@ -558,7 +582,7 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
   if (P == 0) return IA_OK;
   IA_CHECK_ARG(xd && voxel_J && tfs && grid && cand_xc && pt_off && pt_cnt, "ia_snarf_search_compact: null pointer");
   BoneIds b;
-  IA_CHECK_ARG(make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search_compact: bad bone ids / n_init=%d", n_init);
+  IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search_compact: bad bone ids / n_init=%d", n_init);
   ia_prof_begin(IA_PROF_SEARCH, s);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0, s, xd, P,
                      n_pts_dev, voxel_J, tfs, b, n_init, ia_make_grid_dev(grid), cvg_thresh * cvg_thresh,
