@@ -177,6 +177,17 @@ int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
 int ia_field_act_stride(int n_levels);
 int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb,
                        float *sigma, uint16_t *acts, void *stream);
+/* Fused backward of both tiny MLPs (tcnn FullyFusedMLP backward; reached in the reference
+ * through autograd of ngp.py:78,81).  acts: the activation record of ia_field_fwd_train;
+ * rgb [V,3]: its colour output; d_rgb [V,3], d_sigma [V]: incoming gradients; *scale
+ * (device scalar): factor applied before gradients are rounded to half (tcnn: the fixed
+ * 1024x loss scale of DNeRF.py:58), divided out of all results.  Outputs: dfeat fp32 [V,2L]
+ * (input of ia_hashgrid_bwd) and the five weight gradients, ACCUMULATED in fp32 into
+ * g_* (tcnn layouts [out][in]; caller zero-fills).  Needs field->mlp_frags.             */
+int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb,
+                 const float *d_sigma, int V, const float *scale, const ia_field *field,
+                 float *dfeat, float *g_sig_w1, float *g_sig_w2, float *g_col_w1,
+                 float *g_col_w2, float *g_col_w3, void *stream);
 /* Hash-grid backward (tcnn kernel_grid_backward): dtable fp32 [n_entries,2]
  * += interpolation weight * dfeat [V,2L] (fp32 atomics; caller zero-fills).
  * dx: optional [V,3] gradient w.r.t. the (un-normalised) input positions

@@ -591,18 +591,49 @@ __global__ __launch_bounds__(IA_FIELD_THREADS) void k_field(const float *__restr
   }
 }
 
-// Builds the MFMA A-fragment image [N_FRAG][64 lanes][8 halves] once per weight update.
+// ---------------------------------------------------------------------------
+// Backward A-fragments (transposed weights).  The backward data path mirrors the forward chain:
+//   dY --Wc3^T--> dC2 --Wc2^T--> dC1 --Wc1^T--> d(colour input) -> dO --W2^T--> dH1 --W1^T--> dF
+// and again the C/D registers of one product are the B operand of the next, so the same
+// k-permutation kk = (p&3) + 8(p>>2) + 4h is folded into the (transposed) weight fragments.
+// ---------------------------------------------------------------------------
+#define N_FRAG_BWD 20
+#define B_C3 0   // [rb(2)]       dC2 rows, k = dY row (natural order 8h+p)
+#define B_C2 2   // [rb(2)][s(4)] dC1 rows, k = dC2 row
+#define B_C1 10  // [s(4)]        colour-input slot rows (slot t>=1 <-> out[t] = column t-1 of Wc1), k = dC1 row
+#define B_S2 14  // [rb(2)]       dH1 rows, k = dO row
+#define B_S1 16  // [s(4)]        dF rows (features), k = dH1 row
+
+template <int L>
+__device__ _Float16 frag_value_bwd(const FieldDev &F, int f, int i, int h, int p) {
+  constexpr int NF = 2 * L;
+  const int kk = (p & 3) + 8 * (p >> 2) + 4 * h;
+  if (f < B_C2) return ld_h(F.col_w3, (8 * h + p) * 64 + f * 32 + i);
+  if (f < B_C1) {
+    const int rb = (f - B_C2) >> 2, sl = (f - B_C2) & 3;
+    return ld_h(F.col_w2, (16 * sl + kk) * 64 + rb * 32 + i);
+  }
+  if (f < B_S2) {
+    const int sl = f - B_C1;
+    return (i >= 1 && i < 16) ? ld_h(F.col_w1, (16 * sl + kk) * 16 + (i - 1)) : (_Float16)0.f;
+  }
+  if (f < B_S1) return ld_h(F.sig_w2, kk * 64 + (f - B_S2) * 32 + i);
+  const int sl = f - B_S1;
+  return i < NF ? ld_h(F.sig_w1, (16 * sl + kk) * NF + i) : (_Float16)0.f;
+}
+
+// Builds the MFMA A-fragment images [N_FRAG + N_FRAG_BWD][64 lanes][8 halves] once per weight update.
 template <int L>
 __global__ __launch_bounds__(256) void k_build_frags(FieldDev F, uint16_t *__restrict__ out) {
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N_FRAG * 64 * 8; e += gridDim.x * blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (N_FRAG + N_FRAG_BWD) * 64 * 8; e += gridDim.x * blockDim.x) {
     const int f = e >> 9, l = (e >> 3) & 63, p = e & 7;
     union { uint16_t u; _Float16 h; } c;
-    c.h = frag_value<L>(F, f, l & 31, l >> 5, p);
+    c.h = f < N_FRAG ? frag_value<L>(F, f, l & 31, l >> 5, p) : frag_value_bwd<L>(F, f - N_FRAG, l & 31, l >> 5, p);
     out[e] = c.u;
   }
 }
 
-extern "C" size_t ia_field_frags_bytes(void) { return (size_t)N_FRAG * 64 * 8 * 2; }
+extern "C" size_t ia_field_frags_bytes(void) { return (size_t)(N_FRAG + N_FRAG_BWD) * 64 * 8 * 2; }
 
 extern "C" int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream) {
   IA_CHECK_ARG(frags_out, "ia_field_prepare: null output");
@@ -611,9 +642,9 @@ extern "C" int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void
   IA_CHECK_ARG(rc == 0, "ia_field_prepare: bad field descriptor (%d)", rc);
   F.frags = nullptr;
   if (F.lv.n_levels == 16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<16>), dim3(44), dim3(256), 0, (hipStream_t)stream, F, frags_out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<16>), dim3(84), dim3(256), 0, (hipStream_t)stream, F, frags_out);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<8>), dim3(44), dim3(256), 0, (hipStream_t)stream, F, frags_out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_frags<8>), dim3(84), dim3(256), 0, (hipStream_t)stream, F, frags_out);
   IA_LAUNCH_CHECK("k_build_frags");
   return IA_OK;
 }
@@ -710,6 +741,279 @@ extern "C" int ia_field_fwd_train(const float *x, int V, const ia_field *field, 
   int rc = ia_make_field_dev(field, &F);
   IA_CHECK_ARG(rc == 0, "ia_field_fwd_train: bad field descriptor (%d)", rc);
   return ia_launch_field(x, V, nullptr, F, rgb, sigma, (hipStream_t)stream, acts);
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused MLP backward (tcnn FullyFusedMLP backward for both networks): from the fp16 activation
+// record of ia_field_fwd_train and dL/d(rgb, sigma) it produces dL/d(features) [V,2L] fp32 and
+// accumulates the five weight gradients (fp32) -- one kernel instead of ten GEMM launches whose
+// reduction dimension is the sample count (K = V, M,N <= 64: a shape GEMM libraries serve badly).
+//
+// One wave owns a tile of 32 samples per step.
+//   * data path: MFMA 32x32x16 f16 chain as in the forward kernel, transposed weight fragments;
+//     ReLU masks come from the saved activations, loaded in the C/D register layout;
+//   * weight gradients dW = G A^T contract over SAMPLES, which sit across lanes in the C/D layout:
+//     gradients G and activations A are staged once per tile in LDS as [row][sample] so that an
+//     MFMA operand (row i, 8 consecutive samples) is one ds_read_b128; the 12 output tiles
+//     (192 fp32 accumulators) stay in registers over all tiles of the wave and are reduced
+//     through LDS and one round of global atomics at the end.
+// Gradients are scaled by *scale (chosen by the caller so that the largest incoming gradient is
+// 2^10) before they are rounded to half, and the scale is divided out of every fp32 result.
+// ---------------------------------------------------------------------------
+#define IA_BWD_THREADS 128
+#define IA_BWD_RS 32  // halves per staged row = the 32 samples of a tile (59 KB of stage per workgroup: two per CU)
+// staged rows
+#define R_GY 0
+#define R_GC2 16
+#define R_GC1 80
+#define R_GO 144
+#define R_GH1 160
+#define R_AC2 224
+#define R_AC1 288
+#define R_ACIN 352
+#define R_AH1 368
+#define R_AF 432
+#define R_TOTAL 464
+
+__device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// 4 consecutive rows (8g + 4h + q) of a saved activation -> 4 halves
+__device__ __forceinline__ void load4(const uint16_t *__restrict__ rec, int off, bool valid, _Float16 *o) {
+  union { uint2 u; _Float16 h[4]; } c;
+  c.u = valid ? *reinterpret_cast<const uint2 *>(rec + off) : make_uint2(0u, 0u);
+#pragma unroll
+  for (int q = 0; q < 4; q++) o[q] = c.h[q];
+}
+
+__device__ __forceinline__ half8 pack8(const _Float16 *g, int sub) {
+  half8 o;
+#pragma unroll
+  for (int p = 0; p < 8; p++) o[p] = g[8 * sub + p];
+  return o;
+}
+
+template <int L>
+__global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
+    const uint16_t *__restrict__ acts, const float *__restrict__ rgb, const float *__restrict__ d_rgb,
+    const float *__restrict__ d_sigma, int V, const float *__restrict__ scale, const uint16_t *__restrict__ frags,
+    float *__restrict__ dfeat, float *__restrict__ g_w1, float *__restrict__ g_w2, float *__restrict__ g_c1,
+    float *__restrict__ g_c2, float *__restrict__ g_c3) {
+  constexpr int NF = 2 * L, STRIDE = NF + 208, RS = IA_BWD_RS, NW = IA_BWD_THREADS / 64;
+  constexpr int O_H1 = NF, O_O = NF + 64, O_C1 = NF + 80, O_C2 = NF + 144;
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  half8 (*s_frag)[64] = reinterpret_cast<half8 (*)[64]>(s_dyn);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  _Float16 *st = reinterpret_cast<_Float16 *>(s_dyn + N_FRAG_BWD * 64 * 16) + (size_t)wave * R_TOTAL * RS;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(frags + (size_t)N_FRAG * 64 * 8);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_frag[0][0]);
+    for (int e = threadIdx.x; e < N_FRAG_BWD * 64; e += IA_BWD_THREADS) dst[e] = src[e];
+  }
+  // constant row of the colour input (identity-encoding padding, slot 15 of the 16 inputs)
+  if (h == 0) st[(R_ACIN + 15) * RS + j] = (_Float16)1.0f;
+  __syncthreads();
+  const float S = *scale, invS = 1.0f / S;
+  floatx16 aC3[2], aC2[4], aC1[2], aW2[2], aW1[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) { aC3[q] = (floatx16){0.f}; aC1[q] = (floatx16){0.f}; aW2[q] = (floatx16){0.f}; aW1[q] = (floatx16){0.f}; }
+#pragma unroll
+  for (int q = 0; q < 4; q++) aC2[q] = (floatx16){0.f};
+  const int n_tiles = (V + 31) >> 5;
+  const half8 zero8 = (half8){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+                              (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+  for (int t0 = blockIdx.x * NW; t0 < n_tiles; t0 += gridDim.x * NW) {  // uniform trip count per workgroup
+    const int tile = t0 + wave;
+    const int n = tile * 32 + j;
+    const bool valid = tile < n_tiles && n < V;
+    const uint16_t *rec = acts + (size_t)(valid ? n : 0) * STRIDE;
+    // ---- saved activations in the C/D layout (rows 8g + 4h + q <-> register 4g + q) ----
+    _Float16 c2v[2][16], c1v[2][16], h1v[2][16], ov[8], fv[16];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        load4(rec, O_C2 + b * 32 + 8 * g + 4 * h, valid, &c2v[b][4 * g]);
+        load4(rec, O_C1 + b * 32 + 8 * g + 4 * h, valid, &c1v[b][4 * g]);
+        load4(rec, O_H1 + b * 32 + 8 * g + 4 * h, valid, &h1v[b][4 * g]);
+      }
+#pragma unroll
+    for (int g = 0; g < 2; g++) load4(rec, O_O + 8 * g + 4 * h, valid, &ov[4 * g]);
+#pragma unroll
+    for (int g = 0; g < NF / 8; g++) load4(rec, 8 * g + 4 * h, valid, &fv[4 * g]);
+    // stage the activations as [row][sample]
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = b * 32 + cd_row(r, h);
+        st[(R_AC2 + row) * RS + j] = c2v[b][r];
+        st[(R_AC1 + row) * RS + j] = c1v[b][r];
+        st[(R_AH1 + row) * RS + j] = h1v[b][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int row = cd_row(r, h);              // sigma-net output row; colour input m = row - 1
+      if (row >= 1) st[(R_ACIN + row - 1) * RS + j] = ov[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NF / 2; r++) st[(R_AF + cd_row(r, h)) * RS + j] = fv[r];
+    // ---- dY = dL/drgb * sigmoid' (rows 0..2), natural k order: lanes h == 0 hold k = 0..7 ----
+    half8 by = zero8;
+    if (h == 0 && valid) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float y = rgb[(size_t)n * 3 + c];
+        by[c] = (_Float16)(d_rgb[(size_t)n * 3 + c] * y * (1.0f - y) * S);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p++) st[(R_GY + 8 * h + p) * RS + j] = by[p];
+    // ---- dC2 = Wc3^T dY, masked by C2 > 0 ----
+    _Float16 g2[2][16], g1[2][16], gh[2][16], go[8];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+      const floatx16 a = MFMA(s_frag[B_C3 + rb][lane], by, (floatx16){0.f});
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        g2[rb][r] = c2v[rb][r] > (_Float16)0.f ? (_Float16)a[r] : (_Float16)0.f;
+        st[(R_GC2 + rb * 32 + cd_row(r, h)) * RS + j] = g2[rb][r];
+      }
+    }
+    // ---- dC1 = Wc2^T dC2, masked by C1 > 0 ----
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+      floatx16 a = (floatx16){0.f};
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) a = MFMA(s_frag[B_C2 + rb * 4 + sl][lane], pack8(g2[sl >> 1], sl & 1), a);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        g1[rb][r] = c1v[rb][r] > (_Float16)0.f ? (_Float16)a[r] : (_Float16)0.f;
+        st[(R_GC1 + rb * 32 + cd_row(r, h)) * RS + j] = g1[rb][r];
+      }
+    }
+    // ---- d(colour input slots) = Wc1^T dC1; dO = [d sigma, d out[1..15]] ----
+    {
+      floatx16 a = (floatx16){0.f};
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) a = MFMA(s_frag[B_C1 + sl][lane], pack8(g1[sl >> 1], sl & 1), a);
+#pragma unroll
+      for (int r = 0; r < 8; r++) go[r] = (_Float16)a[r];
+      if (h == 0) go[0] = valid ? (_Float16)(d_sigma[n] * S) : (_Float16)0.f;  // row 0 = sigma
+#pragma unroll
+      for (int r = 0; r < 8; r++) st[(R_GO + cd_row(r, h)) * RS + j] = go[r];
+    }
+    // ---- dH1 = W2^T dO, masked by H1 > 0 ----
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+      const floatx16 a = MFMA(s_frag[B_S2 + rb][lane], pack8(go, 0), (floatx16){0.f});
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        gh[rb][r] = h1v[rb][r] > (_Float16)0.f ? (_Float16)a[r] : (_Float16)0.f;
+        st[(R_GH1 + rb * 32 + cd_row(r, h)) * RS + j] = gh[rb][r];
+      }
+    }
+    // ---- dF = W1^T dH1 -> global fp32 [V][NF] ----
+    {
+      floatx16 a = (floatx16){0.f};
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) a = MFMA(s_frag[B_S1 + sl][lane], pack8(gh[sl >> 1], sl & 1), a);
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < NF / 8; g++)
+          *reinterpret_cast<float4 *>(dfeat + (size_t)n * NF + 8 * g + 4 * h) =
+              make_float4(a[4 * g] * invS, a[4 * g + 1] * invS, a[4 * g + 2] * invS, a[4 * g + 3] * invS);
+      }
+    }
+    __syncthreads();  // staged rows visible to the whole wave (lanes read other lanes' rows)
+    // ---- weight gradients: dW[m][p] += sum_samples G[m][n] A[p][n] ----
+    const int i = j;
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+      const int ko = 16 * sl + 8 * h;
+      auto row8 = [&](int row) { return *reinterpret_cast<const half8 *>(st + (size_t)row * RS + ko); };
+      const half8 gY = i < 16 ? row8(R_GY + i) : zero8, gO = i < 16 ? row8(R_GO + i) : zero8;
+      const half8 aCin = i < 16 ? row8(R_ACIN + i) : zero8, aF = i < NF ? row8(R_AF + i) : zero8;
+      half8 gC2[2], gC1[2], gH1[2], aC2r[2], aC1r[2], aH1r[2];
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        gC2[b] = row8(R_GC2 + b * 32 + i); gC1[b] = row8(R_GC1 + b * 32 + i); gH1[b] = row8(R_GH1 + b * 32 + i);
+        aC2r[b] = row8(R_AC2 + b * 32 + i); aC1r[b] = row8(R_AC1 + b * 32 + i); aH1r[b] = row8(R_AH1 + b * 32 + i);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        aC3[b] = MFMA(gY, aC2r[b], aC3[b]);       // dWc3 [16][64]
+        aW2[b] = MFMA(gO, aH1r[b], aW2[b]);       // dW2  [16][64]
+        aC1[b] = MFMA(gC1[b], aCin, aC1[b]);      // dWc1 [64][16]
+        aW1[b] = MFMA(gH1[b], aF, aW1[b]);        // dW1  [64][NF]
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) aC2[b * 2 + pb] = MFMA(gC2[b], aC1r[pb], aC2[b * 2 + pb]);  // dWc2 [64][64]
+      }
+    }
+    __syncthreads();  // operands consumed before the next tile overwrites the stage
+  }
+  // ---- reduce the waves of the workgroup in LDS, then one round of global atomics ----
+  float *red = reinterpret_cast<float *>(s_dyn + N_FRAG_BWD * 64 * 16);  // stage area reused
+  constexpr int N_W1 = 64 * NF, N_W2 = 1024, N_C1 = 1024, N_C2 = 4096, N_C3 = 1024;
+  constexpr int O_W1 = 0, O_W2 = O_W1 + N_W1, O_C1g = O_W2 + N_W2, O_C2g = O_C1g + N_C1, O_C3g = O_C2g + N_C2,
+                N_ALL = O_C3g + N_C3;
+  for (int e = threadIdx.x; e < N_ALL; e += IA_BWD_THREADS) red[e] = 0.f;
+  __syncthreads();
+  const int col = j;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int row = cd_row(r, h);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      if (row < 16) {
+        atomicAdd(&red[O_C3g + row * 64 + b * 32 + col], aC3[b][r]);
+        atomicAdd(&red[O_W2 + row * 64 + b * 32 + col], aW2[b][r]);
+      }
+      if (col < 16) atomicAdd(&red[O_C1g + (b * 32 + row) * 16 + col], aC1[b][r]);
+      if (col < NF) atomicAdd(&red[O_W1 + (b * 32 + row) * NF + col], aW1[b][r]);
+#pragma unroll
+      for (int pb = 0; pb < 2; pb++) atomicAdd(&red[O_C2g + (b * 32 + row) * 64 + pb * 32 + col], aC2[b * 2 + pb][r]);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N_ALL; e += IA_BWD_THREADS) {
+    const float v = red[e] * invS;
+    if (v == 0.f) continue;
+    float *dst = e < O_W2 ? g_w1 + (e - O_W1) : e < O_C1g ? g_w2 + (e - O_W2) : e < O_C2g ? g_c1 + (e - O_C1g)
+                 : e < O_C3g ? g_c2 + (e - O_C2g) : g_c3 + (e - O_C3g);
+    unsafeAtomicAdd(dst, v);
+  }
+}
+
+extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb, const float *d_sigma, int V,
+                            const float *scale, const ia_field *field, float *dfeat, float *g_sig_w1,
+                            float *g_sig_w2, float *g_col_w1, float *g_col_w2, float *g_col_w3, void *stream) {
+  IA_CHECK_ARG(V >= 0, "ia_field_bwd: V < 0");
+  if (V == 0) return IA_OK;
+  IA_CHECK_ARG(acts && rgb && d_rgb && d_sigma && scale && dfeat && g_sig_w1 && g_sig_w2 && g_col_w1 && g_col_w2 && g_col_w3,
+               "ia_field_bwd: null pointer");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_field_bwd: bad field descriptor (%d)", rc);
+  IA_CHECK_ARG(F.frags, "ia_field_bwd: field.mlp_frags is required (ia_field_prepare)");
+  const size_t shmem = (size_t)N_FRAG_BWD * 64 * 16 + (size_t)(IA_BWD_THREADS / 64) * R_TOTAL * IA_BWD_RS * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int tiles = (V + 31) / 32, per = IA_BWD_THREADS / 64;
+  int blocks = (tiles + per - 1) / per;
+  if (blocks > 512) blocks = 512;  // two workgroups per CU; waves keep their 192 accumulators over all their tiles
+  if (F.lv.n_levels == 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<16>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
+                       d_rgb, d_sigma, V, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<8>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
+                       d_rgb, d_sigma, V, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+  IA_LAUNCH_CHECK("k_field_bwd");
+  return IA_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -61,47 +61,69 @@ class _FieldFn(torch.autograd.Function):
         xc, acts, rgb = ctx.saved_tensors
         V = xc.shape[0]
         nf = 2 * net.n_levels
-        enc_h, col_h = net._half_params()
-        # MLP backward as fp16 GEMMs with fp32 accumulation (hipBLASLt MFMA kernels): the saved
-        # activations are fp16 already; incoming gradients are rescaled per call so that their
-        # largest magnitude sits at 2^10 before the cast (tcnn relies on a fixed 1024x loss scale,
-        # DNeRF.py:58) and the scale is divided out of every product in fp32.
-        h = torch.float16
-        W1h, W2h = enc_h[:net.sig_w1_size].view(64, nf), enc_h[net.sig_w1_size:net.sig_w1_size + 1024].view(16, 64)
-        Wc1h, Wc2h, Wc3h = col_h[:1024].view(64, 16), col_h[1024:5120].view(64, 64), col_h[5120:6144].view(16, 64)
-        feat, h1, o16 = acts[:, :nf], acts[:, nf:nf + 64], acts[:, nf + 64:nf + 80]
-        c1, c2 = acts[:, nf + 80:nf + 144], acts[:, nf + 144:nf + 208]
-        cin = torch.cat([o16[:, 1:], torch.ones_like(o16[:, :1])], dim=1)  # colour input: out[1:16] + padding 1
-        d_rgb = d_rgb.reshape(V, 3).float()
-        d_sigma = d_sigma.reshape(V).float()
-        dY32 = torch.zeros((V, 16), device=xc.device)
-        dY32[:, :3] = d_rgb * rgb * (1 - rgb)  # sigmoid'
-        amax = torch.maximum(dY32.abs().max(), d_sigma.abs().max()).clamp(min=1e-30)
-        S = 1024.0 / amax                      # device scalar, no host sync
-        dY = (dY32 * S).to(h)
-        mm = torch.matmul                       # data path: K <= 64, fp16 in/out, fp32 accumulate
-        dWc3 = _mm_f32(dY.t(), c2)              # weight gradients: K = V samples -> fp32 output
-        dC2 = mm(dY, Wc3h) * (c2 > 0)
-        dWc2 = _mm_f32(dC2.t(), c1)
-        dC1 = mm(dC2, Wc2h) * (c1 > 0)
-        dWc1 = _mm_f32(dC1.t(), cin)
-        dcin = mm(dC1, Wc1h)
-        dO = torch.cat([(d_sigma * S).to(h)[:, None], dcin[:, :15]], dim=1)
-        dW2 = _mm_f32(dO.t(), h1)
-        dH1 = mm(dO, W2h) * (h1 > 0)
-        dW1 = _mm_f32(dH1.t(), feat)
-        inv = 1.0 / S
-        dfeat = (_mm_f32(dH1, W1h) * inv).contiguous()
-        dW1, dW2, dWc1, dWc2, dWc3 = [t * inv for t in (dW1, dW2, dWc1, dWc2, dWc3)]
+        d_rgb = d_rgb.reshape(V, 3).float().contiguous()
+        d_sigma = d_sigma.reshape(V).float().contiguous()
+        # gradients are rescaled per call so that their largest magnitude sits at 2^10 before the
+        # cast to half (tcnn relies on a fixed 1024x loss scale, DNeRF.py:58); device scalar, no sync
+        amax = torch.maximum((d_rgb * rgb * (1 - rgb)).abs().max(), d_sigma.abs().max()).clamp(min=1e-30)
+        S = (1024.0 / amax).reshape(1)
         g_enc = torch.zeros_like(net.encoder.params)
-        g_enc[:net.sig_w1_size] = dW1.reshape(-1)
-        g_enc[net.sig_w1_size:net.sig_w1_size + 1024] = dW2.reshape(-1)
-        dtable = g_enc[net.sig_w1_size + 1024:]
+        g_col = torch.zeros_like(net.color_net.params)
+        n1 = net.sig_w1_size
+        if FUSED_MLP_BACKWARD:
+            dfeat = torch.empty((V, nf), device=xc.device)
+            base_e, base_c = g_enc.data_ptr(), g_col.data_ptr()
+            _lib.check(_lib.lib().ia_field_bwd(_lib.ptr(acts), _lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V,
+                                               _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
+                                               base_e + 4 * n1, base_c, base_c + 4 * 1024, base_c + 4 * 5120,
+                                               _lib.stream()), "ia_field_bwd")
+        else:
+            dfeat = _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col)
+        dtable = g_enc[n1 + 1024:]
         dx = torch.empty((V, 3), device=xc.device) if ctx.need_dx else None
         _lib.check(_lib.lib().ia_hashgrid_bwd(_lib.ptr(xc), V, C.byref(net.field_desc()), _lib.ptr(dfeat),
                                               dtable.data_ptr(), _lib.ptr(dx), _lib.stream()), "ia_hashgrid_bwd")
-        g_col = torch.cat([dWc1.reshape(-1), dWc2.reshape(-1), dWc3.reshape(-1)])
         return dx, g_enc, g_col, None
+
+
+#: MLP backward through the fused MFMA kernel (`ia_field_bwd`).  False = the GEMM formulation
+#: below (kept as the reference the fused kernel is tested against).
+FUSED_MLP_BACKWARD = True
+
+
+def _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col):
+    """The same backward as ten fp16 GEMMs with fp32 accumulation (hipBLASLt): weight gradients
+    are [<=64 x V] x [V x <=64] products, the shape the fused kernel exists to avoid."""
+    V = acts.shape[0]
+    nf = 2 * net.n_levels
+    enc_h, col_h = net._half_params()
+    h = torch.float16
+    W1h, W2h = enc_h[:net.sig_w1_size].view(64, nf), enc_h[net.sig_w1_size:net.sig_w1_size + 1024].view(16, 64)
+    Wc1h, Wc2h, Wc3h = col_h[:1024].view(64, 16), col_h[1024:5120].view(64, 64), col_h[5120:6144].view(16, 64)
+    feat, h1, o16 = acts[:, :nf], acts[:, nf:nf + 64], acts[:, nf + 64:nf + 80]
+    c1, c2 = acts[:, nf + 80:nf + 144], acts[:, nf + 144:nf + 208]
+    cin = torch.cat([o16[:, 1:], torch.ones_like(o16[:, :1])], dim=1)  # colour input: out[1:16] + padding 1
+    dY32 = torch.zeros((V, 16), device=acts.device)
+    dY32[:, :3] = d_rgb * rgb * (1 - rgb)  # sigmoid'
+    dY = (dY32 * S).to(h)
+    mm = torch.matmul                       # data path: K <= 64, fp16 in/out, fp32 accumulate
+    dWc3 = _mm_f32(dY.t(), c2)              # weight gradients: K = V samples -> fp32 output
+    dC2 = mm(dY, Wc3h) * (c2 > 0)
+    dWc2 = _mm_f32(dC2.t(), c1)
+    dC1 = mm(dC2, Wc2h) * (c1 > 0)
+    dWc1 = _mm_f32(dC1.t(), cin)
+    dcin = mm(dC1, Wc1h)
+    dO = torch.cat([(d_sigma * S).to(h)[:, None], dcin[:, :15]], dim=1)
+    dW2 = _mm_f32(dO.t(), h1)
+    dH1 = mm(dO, W2h) * (h1 > 0)
+    dW1 = _mm_f32(dH1.t(), feat)
+    inv = 1.0 / S
+    dfeat = (_mm_f32(dH1, W1h) * inv).contiguous()
+    n1 = net.sig_w1_size
+    g_enc[:n1] = (dW1 * inv).reshape(-1)
+    g_enc[n1:n1 + 1024] = (dW2 * inv).reshape(-1)
+    g_col.copy_(torch.cat([(dWc1 * inv).reshape(-1), (dWc2 * inv).reshape(-1), (dWc3 * inv).reshape(-1)]))
+    return dfeat
 
 
 def field_autograd(net, x):

@@ -96,6 +96,41 @@ def test_field_backward_matches_torch_reference(gw):
     assert _cos(g_x, x2.grad) > 0.995
 
 
+def test_fused_mlp_backward_equals_gemm_formulation(gw):
+    """ia_field_bwd (one MFMA kernel) against the same backward written as ten fp16 GEMMs with fp32
+    accumulation: identical roundings of the intermediate gradients, so only the summation order
+    of the fp32 accumulators differs."""
+    from instantavatar_amd import training
+    model = gw[0]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bb = model.deformer.bbox
+    nets = [model.net_coarse, W.build(DEV, 64, 8)[0].net_coarse]
+    for net in nets:
+        for V in (1, 31, 33, 4097, 50001):
+            x = (torch.rand((V, 3), device=DEV, generator=g) * (bb[1] - bb[0]) + bb[0]).requires_grad_(True)
+            wr = torch.rand((V, 3), device=DEV, generator=g) - 0.3
+            ws = (torch.rand(V, device=DEV, generator=g) - 0.5) * 0.01
+            res = []
+            for fused in (True, False):
+                training.FUSED_MLP_BACKWARD = fused
+                try:
+                    for p in net.parameters():
+                        p.grad = None
+                    x.grad = None
+                    rgb, sigma = field_autograd(net, x)
+                    ((rgb * wr).sum() + (sigma * ws).sum()).backward()
+                    res.append((net.encoder.params.grad.clone(), net.color_net.params.grad.clone(), x.grad.clone()))
+                finally:
+                    training.FUSED_MLP_BACKWARD = True
+            (ge_f, gc_f, gx_f), (ge_g, gc_g, gx_g) = res
+            nw = net.sig_w1_size + 1024
+            for a, b, name in ((ge_f[:nw], ge_g[:nw], "sigma-net weights"), (gc_f, gc_g, "colour-net weights"),
+                               (ge_f[nw:], ge_g[nw:], "hash table"), (gx_f, gx_g, "input")):
+                err = (a - b).norm() / (b.norm() + 1e-30)
+                assert err < 2e-3, (net.n_levels, V, name, float(err))
+            assert torch.isfinite(ge_f).all() and torch.isfinite(gc_f).all()
+
+
 def test_training_step_learns(gw):
     """One frame, 4096 random rays: loss must be finite, every parameter tensor must receive
     gradient, and a few Adam steps on a fixed batch must reduce the loss."""
