@@ -177,6 +177,15 @@ int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
 int ia_field_act_stride(int n_levels);
 int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb,
                        float *sigma, uint16_t *acts, void *stream);
+/* NeRFLoss (instant_avatar/utils/loss.py:53-77), value and gradient in one pass:
+ * out5 (zero-filled by the caller) = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density};
+ * d_rgb [n_rays,3], d_alpha [n_rays], d_weight [n_weights] = d loss / d input.
+ * weight: the dense weight_coarse tensor [n_rays x MAX_SAMPLES] (raymarcher_acc.py:181-186). */
+int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
+                 const float *tgt_alpha, const float *weight, int n_rays, long long n_weights,
+                 float w_rgb, float w_alpha, float w_reg, float *out5, float *d_rgb,
+                 float *d_alpha, float *d_weight, void *stream);
+
 /* Fused backward of both tiny MLPs (tcnn FullyFusedMLP backward; reached in the reference
  * through autograd of ngp.py:78,81).  acts: the activation record of ia_field_fwd_train;
  * rgb [V,3]: its colour output; d_rgb [V,3], d_sigma [V]: incoming gradients; *scale

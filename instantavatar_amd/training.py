@@ -130,16 +130,50 @@ def field_autograd(net, x):
     return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net)
 
 
-class NeRFLoss(torch.nn.Module):
-    """instant_avatar/utils/loss.py:53-77"""
+class _NeRFLossFn(torch.autograd.Function):
+    """Value + gradient of NeRFLoss from one HIP kernel (`ia_nerf_loss`)."""
 
-    def __init__(self, opt=None):
+    @staticmethod
+    def forward(ctx, rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg):
+        shapes = rgb.shape, alpha.shape, weight.shape
+        r, a, w = (t.detach().reshape(-1).float().contiguous() for t in (rgb, alpha, weight))
+        tr, ta = tgt_rgb.detach().reshape(-1).float().contiguous(), tgt_alpha.detach().reshape(-1).float().contiguous()
+        out = torch.zeros(5, device=r.device)
+        d_r, d_a, d_w = torch.empty_like(r), torch.empty_like(a), torch.empty_like(w)
+        _lib.check(_lib.lib().ia_nerf_loss(_lib.ptr(r), _lib.ptr(tr), _lib.ptr(a), _lib.ptr(ta), _lib.ptr(w), a.numel(),
+                                           w.numel(), w_rgb, w_alpha, w_reg, _lib.ptr(out), _lib.ptr(d_r), _lib.ptr(d_a),
+                                           _lib.ptr(d_w), _lib.stream()), "ia_nerf_loss")
+        ctx.save_for_backward(d_r, d_a, d_w)
+        ctx.shapes = shapes
+        ctx.mark_non_differentiable(out)
+        return out[0], out  # the differentiable scalar + the five reported values
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        d_r, d_a, d_w = ctx.saved_tensors
+        s = ctx.shapes
+        return (d_r * g).reshape(s[0]), (d_a * g).reshape(s[1]), (d_w * g).reshape(s[2]), None, None, None, None, None
+
+
+class NeRFLoss(torch.nn.Module):
+    """instant_avatar/utils/loss.py:53-77.  On the GPU the loss and its gradient come from one
+    HIP kernel; `fused=False` evaluates the same expression with torch ops (the reference the
+    kernel is tested against)."""
+
+    def __init__(self, opt=None, fused=True):
         super().__init__()
         self.w_rgb = _opt.get(opt, "w_rgb", 1.0)
         self.w_alpha = _opt.get(opt, "w_alpha", 0.1)
         self.w_reg = _opt.get(opt, "w_reg", 0.1)
+        self.fused = fused
 
     def forward(self, predicts, targets):
+        if self.fused and predicts["rgb_coarse"].is_cuda:
+            loss, parts = _NeRFLossFn.apply(predicts["rgb_coarse"], predicts["alpha_coarse"], predicts["weight_coarse"],
+                                            targets["rgb"], targets["alpha"], float(self.w_rgb), float(self.w_alpha),
+                                            float(self.w_reg))
+            return {"mse_loss": parts[1], "loss_alpha_coarse": parts[2], "reg_alpha": parts[3], "reg_density": parts[4],
+                    "loss": loss}
         OFFSET = 0.313262
         ent = lambda v: (-torch.log(torch.exp(-v) + torch.exp(v - 1))).mean() + OFFSET
         losses = {"mse_loss": F.mse_loss(predicts["rgb_coarse"], targets["rgb"], reduction="mean"),

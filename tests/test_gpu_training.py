@@ -131,6 +131,29 @@ def test_fused_mlp_backward_equals_gemm_formulation(gw):
             assert torch.isfinite(ge_f).all() and torch.isfinite(gc_f).all()
 
 
+def test_fused_loss_kernel_matches_torch_expression():
+    """ia_nerf_loss: the five reported values and the three gradients against the torch-op
+    evaluation of loss.py:53-77 (same fp32 functions, different summation order)."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for n, s in ((1, 1), (4096, 256), (1000, 7)):
+        pred = {"rgb_coarse": torch.rand((1, n, 3), device=DEV, generator=g).requires_grad_(True),
+                "alpha_coarse": torch.rand((1, n), device=DEV, generator=g).requires_grad_(True),
+                "weight_coarse": (torch.rand((1, n, s), device=DEV, generator=g) ** 4).requires_grad_(True)}
+        tgt = {"rgb": torch.rand((1, n, 3), device=DEV, generator=g), "alpha": (torch.rand((1, n), device=DEV, generator=g) > 0.5).float()}
+        outs = []
+        for fused in (True, False):
+            for t in pred.values():
+                t.grad = None
+            losses = NeRFLoss(fused=fused)(pred, tgt)
+            (losses["loss"] * 3.0).backward()
+            outs.append(({k: float(v) for k, v in losses.items()}, {k: t.grad.clone() for k, t in pred.items()}))
+        (lf, gf), (lt, gt) = outs
+        for k in lt:
+            assert abs(lf[k] - lt[k]) <= 2e-5 * max(1.0, abs(lt[k])), (n, s, k, lf[k], lt[k])
+        for k in gt:
+            assert torch.allclose(gf[k], gt[k], rtol=1e-4, atol=1e-9), (n, s, k)
+
+
 def test_training_step_learns(gw):
     """One frame, 4096 random rays: loss must be finite, every parameter tensor must receive
     gradient, and a few Adam steps on a fixed batch must reduce the loss."""
