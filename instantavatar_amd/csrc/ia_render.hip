@@ -889,20 +889,32 @@ extern "C" int ia_transform_rays_w2s(const float *rays_o, const float *rays_d, c
 // raymarch_train + jitter + sample compaction (raymarcher_acc.py:153-159):
 // every ray marches all `max_samples` slots; occupied slots become compact samples
 // (contiguous per ray, in slot order) with z = t + jitter * dt and p = z * d + o.
-__global__ __launch_bounds__(256) void k_march_train_compact(
+// One WAVE per ray (a training batch has only a few thousand rays: a thread per ray would occupy
+// 16 of 256 CUs and walk 2 x 256 dependent steps).  Lane l owns the IA_MT_SPL consecutive steps
+// [l*SPL, (l+1)*SPL); it first replays the reference's running sum t += dt up to its first step (so
+// every sample depth has exactly the bits of the sequential loop), tests its steps against the
+// occupancy bits, and the slot / sample indices come from two wave prefix sums.
+#define IA_MT_RAYS 8  // rays (waves) per workgroup: one global atomic per workgroup
+__global__ __launch_bounds__(64 * IA_MT_RAYS) void k_march_train_compact(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
     const float *__restrict__ fars, int n_rays, const uint32_t *__restrict__ bits, OccDev occ, int max_samples,
     const float *__restrict__ jitter, float *__restrict__ s_pts, float *__restrict__ s_z,
     int32_t *__restrict__ s_slot, int32_t *__restrict__ ray_off, int32_t *__restrict__ ray_cnt,
     int32_t *__restrict__ n_samples, int sample_cap) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if ((n - ia_lane()) >= n_rays) return;
+  constexpr int SPL_MAX = 8;
+  __shared__ int s_tot[IA_MT_RAYS];
+  __shared__ int s_base[IA_MT_RAYS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * IA_MT_RAYS + wave;
   const bool live = n < n_rays;
+  const int spl = (max_samples + 2 + 63) / 64;  // the loop runs max_samples (+-1) steps
   MarchRay r;
-  int cnt = 0;
-  float t0 = 0.f, dt = 0.f;
+  float tk[SPL_MAX];
+  bool occf[SPL_MAX];
+  int c = 0;
+  float dt = 0.f;
   if (live) {
-    t0 = nears[n];
+    const float t0 = nears[n];
     dt = (fars[n] - t0) / max_samples;  // step_size (raymarcher_acc.py:147)
     r.ox = rays_o[(size_t)n * 3]; r.oy = rays_o[(size_t)n * 3 + 1]; r.oz = rays_o[(size_t)n * 3 + 2];
     r.dx = rays_d[(size_t)n * 3]; r.dy = rays_d[(size_t)n * 3 + 1]; r.dz = rays_d[(size_t)n * 3 + 2];
@@ -910,39 +922,64 @@ __global__ __launch_bounds__(256) void k_march_train_compact(
     r.sx = occ.G / (occ.mx[0] - occ.mn[0]); r.sy = occ.G / (occ.mx[1] - occ.mn[1]); r.sz = occ.G / (occ.mx[2] - occ.mn[2]);
     r.far = fars[n]; r.dt = dt;
     float t = t0;
-    while (t < r.far && cnt < max_samples) {
+    for (int k = 0; k < lane * spl; k++) t += dt;  // the sequential sum of the reference loop
+#pragma unroll
+    for (int q = 0; q < SPL_MAX; q++) {
+      tk[q] = t;
       float x, y, z;
-      if (march_occupied(r, bits, occ.G, t, x, y, z)) cnt++;  // a slot is consumed even if its depth is <= 0
+      occf[q] = q < spl && t < r.far && march_occupied(r, bits, occ.G, t, x, y, z);
+      c += occf[q] ? 1 : 0;
       t += dt;
     }
+  } else {
+#pragma unroll
+    for (int q = 0; q < SPL_MAX; q++) { tk[q] = 0.f; occf[q] = false; }
   }
-  int total;
-  const int excl = ia_wave_excl_scan(cnt, total);
-  int base = 0;
-  if (ia_lane() == 0 && total > 0) base = atomicAdd(n_samples, total);
-  base = __shfl(base, 0, 64) + excl;
+  // slots: every occupied step consumes one, the loop stops after max_samples of them
+  int tot_c;
+  const int excl_c = ia_wave_excl_scan(c, tot_c);
+  int kcnt = 0;
+#pragma unroll
+  for (int q = 0, sl = excl_c; q < SPL_MAX; q++) {
+    if (occf[q]) {
+      if (sl >= max_samples) occf[q] = false;  // never created by the reference
+      sl++;
+    }
+    kcnt += (occf[q] && tk[q] > 0.f) ? 1 : 0;  // slots with depth <= 0 are masked out (z_vals > 0)
+  }
+  int tot_k;
+  const int excl_k = ia_wave_excl_scan(kcnt, tot_k);
+  const int alloc = min(tot_c, max_samples);
+  if (lane == 0) s_tot[wave] = live ? alloc : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < IA_MT_RAYS; w++) { s_base[w] = tot; tot += s_tot[w]; }
+    const int b = tot > 0 ? atomicAdd(n_samples, tot) : 0;
+    for (int w = 0; w < IA_MT_RAYS; w++) s_base[w] += b;
+  }
+  __syncthreads();
   if (!live) return;
-  ray_off[n] = base;
-  int s = 0, kept = 0;
-  float t = t0;
-  while (t < r.far && s < cnt) {
-    float x, y, z;
-    if (march_occupied(r, bits, occ.G, t, x, y, z)) {
-      if (t > 0.f) {  // slots with depth <= 0 are masked out by the reference (z_vals > 0)
+  const int base = s_base[wave];
+  if (lane == 0) { ray_off[n] = base; ray_cnt[n] = tot_k; }
+  int sl = excl_c, kept = excl_k;
+#pragma unroll
+  for (int q = 0; q < SPL_MAX; q++) {
+    if (occf[q]) {
+      const float t = tk[q];
+      if (t > 0.f) {
         const int o = base + kept;
         if (o < sample_cap) {
-          const float zj = t + (jitter ? jitter[(size_t)n * max_samples + s] : 0.5f) * dt;
+          const float zj = t + (jitter ? jitter[(size_t)n * max_samples + sl] : 0.5f) * dt;
           s_z[o] = zj;
-          s_slot[o] = s;  // position in the reference's dense [n_rays, max_samples] layout
+          s_slot[o] = sl;  // position in the reference's dense [n_rays, max_samples] layout
           s_pts[(size_t)o * 3] = zj * r.dx + r.ox; s_pts[(size_t)o * 3 + 1] = zj * r.dy + r.oy; s_pts[(size_t)o * 3 + 2] = zj * r.dz + r.oz;
         }
         kept++;
       }
-      s++;
+      sl++;
     }
-    t += dt;
   }
-  ray_cnt[n] = kept;
 }
 
 // candidate max for training: invalid slots carry -1e5 (snarf_deformer.py:147), no
@@ -959,7 +996,11 @@ __device__ __forceinline__ void cand_max_train(const float *__restrict__ cand_si
 }
 
 // composite() of raymarcher_acc.py:25-36 + render_train tail (:161-186) over compact samples.
-__global__ __launch_bounds__(256) void k_composite_train_fwd(
+// One WAVE per ray: lane l owns a run of consecutive samples; the transmittance
+// T_k = prod_{j<k} (1 - alpha_j + 1e-10) is a wave prefix product of the per-lane products (torch's
+// cumprod is a parallel scan as well: the association order is not part of the reference).
+#define IA_CT_RAYS 4
+__global__ __launch_bounds__(64 * IA_CT_RAYS) void k_composite_train_fwd(
     const float *__restrict__ cand_rgb, const float *__restrict__ cand_sigma, const int32_t *__restrict__ pt_off,
     const uint8_t *__restrict__ pt_cnt, int n_init, const int32_t *__restrict__ ray_off,
     const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z, const float *__restrict__ nears,
@@ -967,33 +1008,64 @@ __global__ __launch_bounds__(256) void k_composite_train_fwd(
     const float *__restrict__ bg, float *__restrict__ color, float *__restrict__ depth, float *__restrict__ alpha_out,
     float *__restrict__ weights_dense, const int32_t *__restrict__ s_slot, int32_t *__restrict__ s_arg,
     float *__restrict__ s_sigma, float *__restrict__ s_alpha, float *__restrict__ s_T) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= n_rays) return;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * IA_CT_RAYS + (threadIdx.x >> 6);
+  if (n >= n_rays) return;  // uniform per wave
   const int off = ray_off[n], cnt = ray_cnt[n];
   const float dt = (fars[n] - nears[n]) / max_samples;
-  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, asum = 0.f;  // weights_dense is zero-filled by the caller
-  for (int k = 0; k < cnt; k++) {
+  const int per = (cnt + 63) >> 6, k0 = min(lane * per, cnt), k1 = min(k0 + per, cnt);
+  // pass 1: sigma / alpha of the lane's samples and the product of their (1 - alpha + 1e-10)
+  float prod = 1.f;
+  for (int k = k0; k < k1; k++) {
     const int s = off + k;
     float sg; int arg;
     cand_max_train(cand_sigma, pt_off[s], pt_cnt[s], n_init, sg, arg);
     if (noise) sg += noise_scale * noise[s];               // raymarcher_acc.py:166-167
     const float tau = fmaxf(sg, 0.f) * dt;                 // relu(sigma) * dists
     const float a = 1.0f - expf(-tau);
+    s_arg[s] = arg; s_sigma[s] = sg; s_alpha[s] = a;
+    prod *= (1.0f - a + 1e-10f);
+  }
+  float incl = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float y = __shfl_up(incl, o, 64);
+    if (lane >= o) incl = y * incl;
+  }
+  float T = __shfl_up(incl, 1, 64);
+  if (lane == 0) T = 1.f;
+  const float T_end = __shfl(incl, 63, 64);
+  // pass 2: weights and the per-ray sums
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, asum = 0.f;  // weights_dense is zero-filled by the caller
+  for (int k = k0; k < k1; k++) {
+    const int s = off + k;
+    const float a = s_alpha[s];
+    const int arg = s_arg[s];
     const float w = a * T;
-    s_arg[s] = arg; s_sigma[s] = sg; s_alpha[s] = a; s_T[s] = T;
+    s_T[s] = T;
     if (arg >= 0) { c0 += w * cand_rgb[(size_t)arg * 3]; c1 += w * cand_rgb[(size_t)arg * 3 + 1]; c2 += w * cand_rgb[(size_t)arg * 3 + 2]; }
     dep += w * s_z[s];
     asum += w;
     weights_dense[(size_t)n * max_samples + s_slot[s]] = w;
     T = T * (1.0f - a + 1e-10f);                           // cumprod(1 - alpha + 1e-10)
   }
-  const float b0 = bg ? bg[(size_t)n * 3] : 1.f, b1 = bg ? bg[(size_t)n * 3 + 1] : 1.f, b2 = bg ? bg[(size_t)n * 3 + 2] : 1.f;
-  color[(size_t)n * 3] = c0 + T * b0; color[(size_t)n * 3 + 1] = c1 + T * b1; color[(size_t)n * 3 + 2] = c2 + T * b2;
-  depth[n] = dep;
-  alpha_out[n] = asum;   // alpha_coarse = weights.sum(-1) (:184)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64);
+    dep += __shfl_xor(dep, o, 64); asum += __shfl_xor(asum, o, 64);
+  }
+  if (lane == 0) {
+    const float b0 = bg ? bg[(size_t)n * 3] : 1.f, b1 = bg ? bg[(size_t)n * 3 + 1] : 1.f, b2 = bg ? bg[(size_t)n * 3 + 2] : 1.f;
+    color[(size_t)n * 3] = c0 + T_end * b0; color[(size_t)n * 3 + 1] = c1 + T_end * b1; color[(size_t)n * 3 + 2] = c2 + T_end * b2;
+    depth[n] = dep;
+    alpha_out[n] = asum;   // alpha_coarse = weights.sum(-1) (:184)
+  }
 }
 
-__global__ __launch_bounds__(256) void k_composite_train_bwd(
+// Backward: gT_k = gw_k a_k + gT_{k+1} (1 - a_k + 1e-10) is an affine recurrence running from the
+// last sample to the first; each lane composes the affine map of its run, a reverse wave scan of
+// (slope, offset) pairs yields the value entering every run, then the lane walks its run.
+__global__ __launch_bounds__(64 * IA_CT_RAYS) void k_composite_train_bwd(
     const float *__restrict__ d_color, const float *__restrict__ d_depth, const float *__restrict__ d_alpha,
     const float *__restrict__ d_weights, const float *__restrict__ cand_rgb, const int32_t *__restrict__ ray_off,
     const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z, const float *__restrict__ nears,
@@ -1001,8 +1073,9 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(
     const int32_t *__restrict__ s_slot, const int32_t *__restrict__ s_arg, const float *__restrict__ s_sigma,
     const float *__restrict__ s_alpha, const float *__restrict__ s_T, float *__restrict__ d_cand_rgb,
     float *__restrict__ d_cand_sigma) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= n_rays) return;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * IA_CT_RAYS + (threadIdx.x >> 6);
+  if (n >= n_rays) return;  // uniform per wave
   const int off = ray_off[n], cnt = ray_cnt[n];
   if (cnt == 0) return;
   const float dt = (fars[n] - nears[n]) / max_samples;
@@ -1010,14 +1083,36 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(
               dc2 = d_color ? d_color[(size_t)n * 3 + 2] : 0.f;
   const float dd = d_depth ? d_depth[n] : 0.f, da = d_alpha ? d_alpha[n] : 0.f;
   const float b0 = bg ? bg[(size_t)n * 3] : 1.f, b1 = bg ? bg[(size_t)n * 3 + 1] : 1.f, b2 = bg ? bg[(size_t)n * 3 + 2] : 1.f;
-  float gT = dc0 * b0 + dc1 * b1 + dc2 * b2;  // dL/dT_end
-  for (int k = cnt - 1; k >= 0; k--) {
+  const float gT_end = dc0 * b0 + dc1 * b1 + dc2 * b2;  // dL/dT_end
+  const int per = (cnt + 63) >> 6, k0 = min(lane * per, cnt), k1 = min(k0 + per, cnt);
+  auto gw_of = [&](int s, int arg) {
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (arg >= 0) { r0 = cand_rgb[(size_t)arg * 3]; r1 = cand_rgb[(size_t)arg * 3 + 1]; r2 = cand_rgb[(size_t)arg * 3 + 2]; }
+    return dc0 * r0 + dc1 * r1 + dc2 * r2 + dd * s_z[s] + da + (d_weights ? d_weights[(size_t)n * max_samples + s_slot[s]] : 0.f);
+  };
+  // affine map of the lane's run: gT_out = B + M * gT_in (gT_in enters from the later samples)
+  float M = 1.f, B = 0.f;
+  for (int k = k1 - 1; k >= k0; k--) {
+    const int s = off + k;
+    const float a = s_alpha[s], m = 1.0f - a + 1e-10f, b = gw_of(s, s_arg[s]) * a;
+    B = b + m * B;
+    M = m * M;
+  }
+  // suffix composition S_l = F_l o F_{l+1} o ... o F_63
+  float SM = M, SB = B;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float m2 = __shfl_down(SM, o, 64), b2s = __shfl_down(SB, o, 64);
+    if (lane + o < 64) { SB = SB + SM * b2s; SM = SM * m2; }
+  }
+  float inM = __shfl_down(SM, 1, 64), inB = __shfl_down(SB, 1, 64);
+  if (lane == 63) { inM = 1.f; inB = 0.f; }
+  float gT = inB + inM * gT_end;
+  for (int k = k1 - 1; k >= k0; k--) {
     const int s = off + k;
     const float a = s_alpha[s], T = s_T[s];
     const int arg = s_arg[s];
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (arg >= 0) { r0 = cand_rgb[(size_t)arg * 3]; r1 = cand_rgb[(size_t)arg * 3 + 1]; r2 = cand_rgb[(size_t)arg * 3 + 2]; }
-    const float gw = dc0 * r0 + dc1 * r1 + dc2 * r2 + dd * s_z[s] + da + (d_weights ? d_weights[(size_t)n * max_samples + s_slot[s]] : 0.f);
+    const float gw = gw_of(s, arg);
     const float w = a * T;
     const float g_alpha = gw * T - gT * T;
     gT = gw * a + gT * (1.0f - a + 1e-10f);
@@ -1034,14 +1129,14 @@ extern "C" int ia_march_train_compact(const float *rays_o, const float *rays_d, 
                                       const float *jitter, float *s_pts, float *s_z, int32_t *s_slot,
                                       int32_t *ray_off, int32_t *ray_cnt, int32_t *n_samples, int sample_cap,
                                       void *stream) {
-  IA_CHECK_ARG(n_rays >= 0 && max_samples > 0, "ia_march_train_compact: bad sizes");
+  IA_CHECK_ARG(n_rays >= 0 && max_samples > 0 && max_samples + 2 <= 64 * 8, "ia_march_train_compact: bad sizes (max_samples <= 510)");
   IA_CHECK_ARG(n_samples, "ia_march_train_compact: n_samples is null");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, s, n_samples, 0, 1);
   if (n_rays == 0) return IA_OK;
   IA_CHECK_ARG(rays_o && rays_d && nears && fars && occ_bits && occ && s_pts && s_z && s_slot && ray_off && ray_cnt,
                "ia_march_train_compact: null pointer");
-  hipLaunchKernelGGL(k_march_train_compact, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, s, rays_o, rays_d, nears, fars,
+  hipLaunchKernelGGL(k_march_train_compact, dim3(ia_div_up(n_rays, IA_MT_RAYS)), dim3(64 * IA_MT_RAYS), 0, s, rays_o, rays_d, nears, fars,
                      n_rays, occ_bits, make_occ(occ), max_samples, jitter, s_pts, s_z, s_slot, ray_off, ray_cnt,
                      n_samples, sample_cap);
   IA_LAUNCH_CHECK("k_march_train_compact");
@@ -1059,7 +1154,7 @@ extern "C" int ia_composite_train_fwd(const float *cand_rgb, const float *cand_s
   if (n_rays == 0) return IA_OK;
   IA_CHECK_ARG(pt_off && pt_cnt && ray_off && ray_cnt && s_z && nears && fars && color && depth && alpha &&
                weights_dense && s_slot && s_arg && s_sigma && s_alpha && s_T, "ia_composite_train_fwd: null pointer");
-  hipLaunchKernelGGL(k_composite_train_fwd, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, cand_rgb,
+  hipLaunchKernelGGL(k_composite_train_fwd, dim3(ia_div_up(n_rays, IA_CT_RAYS)), dim3(64 * IA_CT_RAYS), 0, (hipStream_t)stream, cand_rgb,
                      cand_sigma, pt_off, pt_cnt, n_init, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, noise,
                      noise_scale, bg, color, depth, alpha, weights_dense, s_slot, s_arg, s_sigma, s_alpha, s_T);
   IA_LAUNCH_CHECK("k_composite_train_fwd");
@@ -1076,7 +1171,7 @@ extern "C" int ia_composite_train_bwd(const float *d_color, const float *d_depth
   if (n_rays == 0) return IA_OK;
   IA_CHECK_ARG(ray_off && ray_cnt && s_z && nears && fars && s_slot && s_arg && s_sigma && s_alpha && s_T && d_cand_rgb &&
                d_cand_sigma, "ia_composite_train_bwd: null pointer");
-  hipLaunchKernelGGL(k_composite_train_bwd, dim3(ia_div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, d_color,
+  hipLaunchKernelGGL(k_composite_train_bwd, dim3(ia_div_up(n_rays, IA_CT_RAYS)), dim3(64 * IA_CT_RAYS), 0, (hipStream_t)stream, d_color,
                      d_depth, d_alpha, d_weights, cand_rgb, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, bg,
                      s_slot, s_arg, s_sigma, s_alpha, s_T, d_cand_rgb, d_cand_sigma);
   IA_LAUNCH_CHECK("k_composite_train_bwd");
