@@ -175,8 +175,8 @@ int ia_field_fwd(const float *x, int V, const int32_t *n_dev,
  * outputs plus the fp16 activation record per sample, ia_field_act_stride()
  * halves: [features 2L | h1 64 | sigma-net out 16 | c1 64 | c2 64].          */
 int ia_field_act_stride(int n_levels);
-int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb,
-                       float *sigma, uint16_t *acts, void *stream);
+int ia_field_fwd_train(const float *x, int V, const int32_t *n_dev, const ia_field *field,
+                       float *rgb, float *sigma, uint16_t *acts, void *stream);
 /* NeRFLoss (instant_avatar/utils/loss.py:53-77), value and gradient in one pass:
  * out5 (zero-filled by the caller) = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density};
  * d_rgb [n_rays,3], d_alpha [n_rays], d_weight [n_weights] = d loss / d input.
@@ -194,15 +194,16 @@ int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
  * (input of ia_hashgrid_bwd) and the five weight gradients, ACCUMULATED in fp32 into
  * g_* (tcnn layouts [out][in]; caller zero-fills).  Needs field->mlp_frags.             */
 int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb,
-                 const float *d_sigma, int V, const float *scale, const ia_field *field,
+                 const float *d_sigma, int V, const int32_t *n_dev, const float *scale,
+                 const ia_field *field,
                  float *dfeat, float *g_sig_w1, float *g_sig_w2, float *g_col_w1,
                  float *g_col_w2, float *g_col_w3, void *stream);
 /* Hash-grid backward (tcnn kernel_grid_backward): dtable fp32 [n_entries,2]
  * += interpolation weight * dfeat [V,2L] (fp32 atomics; caller zero-fills).
  * dx: optional [V,3] gradient w.r.t. the (un-normalised) input positions
  * (tcnn kernel_grid_backward_input), needed when SMPL poses are optimised.   */
-int ia_hashgrid_bwd(const float *x, int V, const ia_field *field, const float *dfeat,
-                    float *dtable, float *dx, void *stream);
+int ia_hashgrid_bwd(const float *x, int V, const int32_t *n_dev, const ia_field *field,
+                    const float *dfeat, float *dtable, float *dx, void *stream);
 size_t ia_field_frags_bytes(void);
 int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream);
 /* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */
@@ -331,7 +332,8 @@ int ia_transform_rays_w2s(const float *rays_o, const float *rays_d,
  *   [n_rays,max_samples] as torch.rand_like draws it at :156, NULL = 0.5) + compaction:
  *   s_pts [cap,3], s_z [cap], s_slot [cap] (slot in the dense layout), ray_off/ray_cnt
  *   [n_rays], n_samples (device int32, zeroed inside).
- * ia_composite_train_fwd: per sample max over its candidates (invalid = -1e5),
+ * ia_composite_train_fwd: per sample max over its candidates (invalid = -1e5; cand_cap =
+ *   length of the candidate arrays, candidates past it were dropped by the search),
  *   optional sigma noise, alpha = 1-exp(-relu(sigma)*dt), T = cumprod(1-alpha+1e-10);
  *   outputs color [n,3] (+T*bg), depth, alpha (= sum w), weights_dense [n,max_samples]
  *   (zero-filled by the caller; only occupied slots are written);
@@ -343,8 +345,8 @@ int ia_march_train_compact(const float *rays_o, const float *rays_d, const float
                            const ia_occ_grid *occ, int max_samples, const float *jitter,
                            float *s_pts, float *s_z, int32_t *s_slot, int32_t *ray_off,
                            int32_t *ray_cnt, int32_t *n_samples, int sample_cap, void *stream);
-int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *pt_off,
-                           const uint8_t *pt_cnt, int n_init, const int32_t *ray_off,
+int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, int cand_cap,
+                           const int32_t *pt_off, const uint8_t *pt_cnt, int n_init, const int32_t *ray_off,
                            const int32_t *ray_cnt, const float *s_z, const float *nears,
                            const float *fars, int n_rays, int max_samples, const float *noise,
                            float noise_scale, const float *bg, float *color, float *depth,

@@ -54,12 +54,12 @@ _SIGS = {
                                           _VP, C.c_int, _VP]),
     "ia_field_fwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP]),
     "ia_field_act_stride": (C.c_int, [C.c_int]),
-    "ia_field_fwd_train": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP, _VP, _VP]),
-    "ia_hashgrid_bwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP, _VP, _VP]),
+    "ia_field_fwd_train": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
+    "ia_hashgrid_bwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),
     "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
     "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 5),
-    "ia_field_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(Field)] + [_VP] * 7),
+    "ia_field_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, C.POINTER(Field)] + [_VP] * 7),
     "ia_hashgrid_fwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP]),
     "ia_hashgrid_fwd_planes": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, C.c_size_t, _VP]),
     "ia_candidate_max": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int, C.c_float, C.c_int, _VP, _VP, _VP]),
@@ -83,7 +83,7 @@ _SIGS = {
     "ia_transform_rays_w2s": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     "ia_march_train_compact": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(OccGrid), C.c_int, _VP, _VP, _VP,
                                          _VP, _VP, _VP, _VP, C.c_int, _VP]),
-    "ia_composite_train_fwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP,
+    "ia_composite_train_fwd": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP,
                                          C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ia_composite_train_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP,
                                          _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

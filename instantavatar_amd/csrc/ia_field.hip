@@ -732,15 +732,15 @@ extern "C" int ia_field_fwd(const float *x, int V, const int32_t *n_dev, const i
 // Training-mode forward: additionally writes the fp16 activation record per sample.
 extern "C" int ia_field_act_stride(int n_levels) { return 2 * n_levels + 64 + 16 + 64 + 64; }
 
-extern "C" int ia_field_fwd_train(const float *x, int V, const ia_field *field, float *rgb, float *sigma,
-                                  uint16_t *acts, void *stream) {
+extern "C" int ia_field_fwd_train(const float *x, int V, const int32_t *n_dev, const ia_field *field, float *rgb,
+                                  float *sigma, uint16_t *acts, void *stream) {
   IA_CHECK_ARG(V >= 0, "ia_field_fwd_train: V < 0");
   if (V == 0) return IA_OK;
   IA_CHECK_ARG(x && rgb && sigma && acts, "ia_field_fwd_train: null pointer");
   FieldDev F;
   int rc = ia_make_field_dev(field, &F);
   IA_CHECK_ARG(rc == 0, "ia_field_fwd_train: bad field descriptor (%d)", rc);
-  return ia_launch_field(x, V, nullptr, F, rgb, sigma, (hipStream_t)stream, acts);
+  return ia_launch_field(x, V, n_dev, F, rgb, sigma, (hipStream_t)stream, acts);
 }
 
 
@@ -796,13 +796,14 @@ __device__ __forceinline__ half8 pack8(const _Float16 *g, int sub) {
 template <int L>
 __global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
     const uint16_t *__restrict__ acts, const float *__restrict__ rgb, const float *__restrict__ d_rgb,
-    const float *__restrict__ d_sigma, int V, const float *__restrict__ scale, const uint16_t *__restrict__ frags,
-    float *__restrict__ dfeat, float *__restrict__ g_w1, float *__restrict__ g_w2, float *__restrict__ g_c1,
+    const float *__restrict__ d_sigma, int V, const int32_t *__restrict__ n_dev, const float *__restrict__ scale,
+    const uint16_t *__restrict__ frags, float *__restrict__ dfeat, float *__restrict__ g_w1, float *__restrict__ g_w2, float *__restrict__ g_c1,
     float *__restrict__ g_c2, float *__restrict__ g_c3) {
   constexpr int NF = 2 * L, STRIDE = NF + 208, RS = IA_BWD_RS, NW = IA_BWD_THREADS / 64;
   constexpr int O_H1 = NF, O_O = NF + 64, O_C1 = NF + 80, O_C2 = NF + 144;
   extern __shared__ __attribute__((aligned(16))) char s_dyn[];
   half8 (*s_frag)[64] = reinterpret_cast<half8 (*)[64]>(s_dyn);
+  if (n_dev) V = min(V, *n_dev);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   _Float16 *st = reinterpret_cast<_Float16 *>(s_dyn + N_FRAG_BWD * 64 * 16) + (size_t)wave * R_TOTAL * RS;
   {
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
 }
 
 extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb, const float *d_sigma, int V,
-                            const float *scale, const ia_field *field, float *dfeat, float *g_sig_w1,
+                            const int32_t *n_dev, const float *scale, const ia_field *field, float *dfeat, float *g_sig_w1,
                             float *g_sig_w2, float *g_col_w1, float *g_col_w2, float *g_col_w3, void *stream) {
   IA_CHECK_ARG(V >= 0, "ia_field_bwd: V < 0");
   if (V == 0) return IA_OK;
@@ -1008,10 +1009,10 @@ extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float 
   if (blocks > 512) blocks = 512;  // two workgroups per CU; waves keep their 192 accumulators over all their tiles
   if (F.lv.n_levels == 16)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<16>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
-                       d_rgb, d_sigma, V, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<8>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
-                       d_rgb, d_sigma, V, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
   IA_LAUNCH_CHECK("k_field_bwd");
   return IA_OK;
 }
@@ -1023,9 +1024,11 @@ extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float 
 // One lane = one sample; the level loop is wave-uniform.
 // ---------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ x, int V, FieldDev F,
+__global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ x, int V,
+                                                      const int32_t *__restrict__ n_dev, FieldDev F,
                                                       const float *__restrict__ dfeat,
                                                       float *__restrict__ dtable, float *__restrict__ dx) {
+  if (n_dev) V = min(V, *n_dev);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     float xn[3];
     normalise(F, x, (size_t)i, xn);
@@ -1084,8 +1087,8 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
   }
 }
 
-extern "C" int ia_hashgrid_bwd(const float *x, int V, const ia_field *field, const float *dfeat, float *dtable,
-                               float *dx, void *stream) {
+extern "C" int ia_hashgrid_bwd(const float *x, int V, const int32_t *n_dev, const ia_field *field, const float *dfeat,
+                               float *dtable, float *dx, void *stream) {
   IA_CHECK_ARG(V >= 0, "ia_hashgrid_bwd: V < 0");
   if (V == 0) return IA_OK;
   IA_CHECK_ARG(x && dfeat && dtable, "ia_hashgrid_bwd: null pointer");
@@ -1095,9 +1098,9 @@ extern "C" int ia_hashgrid_bwd(const float *x, int V, const ia_field *field, con
   int blocks = (V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (F.lv.n_levels == 16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F, dfeat, dtable, dx);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, F, dfeat, dtable, dx);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx);
   IA_LAUNCH_CHECK("k_hashgrid_bwd");
   return IA_OK;
 }

@@ -1001,13 +1001,14 @@ __device__ __forceinline__ void cand_max_train(const float *__restrict__ cand_si
 // cumprod is a parallel scan as well: the association order is not part of the reference).
 #define IA_CT_RAYS 4
 __global__ __launch_bounds__(64 * IA_CT_RAYS) void k_composite_train_fwd(
-    const float *__restrict__ cand_rgb, const float *__restrict__ cand_sigma, const int32_t *__restrict__ pt_off,
-    const uint8_t *__restrict__ pt_cnt, int n_init, const int32_t *__restrict__ ray_off,
-    const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z, const float *__restrict__ nears,
-    const float *__restrict__ fars, int n_rays, int max_samples, const float *__restrict__ noise, float noise_scale,
-    const float *__restrict__ bg, float *__restrict__ color, float *__restrict__ depth, float *__restrict__ alpha_out,
-    float *__restrict__ weights_dense, const int32_t *__restrict__ s_slot, int32_t *__restrict__ s_arg,
-    float *__restrict__ s_sigma, float *__restrict__ s_alpha, float *__restrict__ s_T) {
+    const float *__restrict__ cand_rgb, const float *__restrict__ cand_sigma, int cand_cap,
+    const int32_t *__restrict__ pt_off, const uint8_t *__restrict__ pt_cnt, int n_init,
+    const int32_t *__restrict__ ray_off, const int32_t *__restrict__ ray_cnt, const float *__restrict__ s_z,
+    const float *__restrict__ nears, const float *__restrict__ fars, int n_rays, int max_samples,
+    const float *__restrict__ noise, float noise_scale, const float *__restrict__ bg, float *__restrict__ color,
+    float *__restrict__ depth, float *__restrict__ alpha_out, float *__restrict__ weights_dense,
+    const int32_t *__restrict__ s_slot, int32_t *__restrict__ s_arg, float *__restrict__ s_sigma,
+    float *__restrict__ s_alpha, float *__restrict__ s_T) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * IA_CT_RAYS + (threadIdx.x >> 6);
   if (n >= n_rays) return;  // uniform per wave
@@ -1019,7 +1020,9 @@ __global__ __launch_bounds__(64 * IA_CT_RAYS) void k_composite_train_fwd(
   for (int k = k0; k < k1; k++) {
     const int s = off + k;
     float sg; int arg;
-    cand_max_train(cand_sigma, pt_off[s], pt_cnt[s], n_init, sg, arg);
+    // (candidates past the capacity of the candidate arrays were dropped by the search: never read)
+    const int po = pt_off[s], pc = max(0, min((int)pt_cnt[s], cand_cap - po));
+    cand_max_train(cand_sigma, po, pc, n_init, sg, arg);
     if (noise) sg += noise_scale * noise[s];               // raymarcher_acc.py:166-167
     const float tau = fmaxf(sg, 0.f) * dt;                 // relu(sigma) * dists
     const float a = 1.0f - expf(-tau);
@@ -1143,8 +1146,8 @@ extern "C" int ia_march_train_compact(const float *rays_o, const float *rays_d, 
   return IA_OK;
 }
 
-extern "C" int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *pt_off,
-                                      const uint8_t *pt_cnt, int n_init, const int32_t *ray_off, const int32_t *ray_cnt,
+extern "C" int ia_composite_train_fwd(const float *cand_rgb, const float *cand_sigma, int cand_cap,
+                                      const int32_t *pt_off, const uint8_t *pt_cnt, int n_init, const int32_t *ray_off, const int32_t *ray_cnt,
                                       const float *s_z, const float *nears, const float *fars, int n_rays,
                                       int max_samples, const float *noise, float noise_scale, const float *bg,
                                       float *color, float *depth, float *alpha, float *weights_dense,
@@ -1155,7 +1158,7 @@ extern "C" int ia_composite_train_fwd(const float *cand_rgb, const float *cand_s
   IA_CHECK_ARG(pt_off && pt_cnt && ray_off && ray_cnt && s_z && nears && fars && color && depth && alpha &&
                weights_dense && s_slot && s_arg && s_sigma && s_alpha && s_T, "ia_composite_train_fwd: null pointer");
   hipLaunchKernelGGL(k_composite_train_fwd, dim3(ia_div_up(n_rays, IA_CT_RAYS)), dim3(64 * IA_CT_RAYS), 0, (hipStream_t)stream, cand_rgb,
-                     cand_sigma, pt_off, pt_cnt, n_init, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, noise,
+                     cand_sigma, cand_cap, pt_off, pt_cnt, n_init, ray_off, ray_cnt, s_z, nears, fars, n_rays, max_samples, noise,
                      noise_scale, bg, color, depth, alpha, weights_dense, s_slot, s_arg, s_sigma, s_alpha, s_T);
   IA_LAUNCH_CHECK("k_composite_train_fwd");
   return IA_OK;

@@ -68,7 +68,8 @@ class _CompositeTrainFn(torch.autograd.Function):
         weights = torch.zeros((n, S), device=dev)  # the kernel writes the occupied slots only
         sv = dict(arg=torch.empty(cap, dtype=torch.int32, device=dev), sigma=torch.empty(cap, device=dev),
                   alpha=torch.empty(cap, device=dev), T=torch.empty(cap, device=dev))
-        _lib.check(L.ia_composite_train_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), _lib.ptr(st["pt_off"]), _lib.ptr(st["pt_cnt"]),
+        _lib.check(L.ia_composite_train_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), cand_sigma.shape[0],
+                                            _lib.ptr(st["pt_off"]), _lib.ptr(st["pt_cnt"]),
                                             st["n_init"], _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]), _lib.ptr(st["s_z"]),
                                             _lib.ptr(st["near"]), _lib.ptr(st["far"]), n, S, _lib.ptr(st["noise"]), st["noise_scale"],
                                             _lib.ptr(st["bg"]), _lib.ptr(color), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(weights),
@@ -260,8 +261,8 @@ class Raymarcher(torch.nn.Module):
     def render_train_fused(self, rays, deformer, net, noise, bg_color):
         """render_train (raymarcher_acc.py:140-186) over COMPACT samples: march + jitter +
         compaction, candidate search + compaction, field under autograd on the surviving
-        candidates, compositing forward/backward as two kernels.  One 8-byte host read per
-        step (sample / candidate counts size the autograd graph)."""
+        candidates, compositing forward/backward as two kernels.  No host synchronisation: all
+        counts stay on the device."""
         L = _lib.lib()
         dev = rays.o.device
         o = rays.o.reshape(-1, 3).float().contiguous()
@@ -282,14 +283,19 @@ class Raymarcher(torch.nn.Module):
                                                 _lib.ptr(st["s_slot"]), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]),
                                                 _lib.ptr(st["n_samples"]), cap, _lib.stream()), "ia_march_train_compact")
             sc = deformer.search_compact(st["s_pts"], n_pts_dev=st["n_samples"])
-        n_samples, n_cand = torch.cat([st["n_samples"], sc["n_cand"]]).tolist()      # the one host read
-        st.update(pt_off=sc["pt_off"], pt_cnt=sc["pt_cnt"], n_init=len(deformer.deformer.init_bones),
+        # No host read: the field runs on a capacity-sized candidate buffer with the device-side
+        # count (kernels clamp to it).  The counts of step i are copied to pinned memory and looked
+        # at during step i+1: a step whose candidates exceeded the capacity (they were dropped) is
+        # counted in `train_overflow` and the capacity grows for the following steps.
+        self._train_counts_check()
+        k = len(deformer.deformer.init_bones)
+        cand_cap = min(cap * k, self.train_cand_capacity)
+        st.update(pt_off=sc["pt_off"], pt_cnt=sc["pt_cnt"], n_init=k,
                   bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
-                  noise=torch.randn(max(n_samples, 1), device=dev) if noise > 0 else None, noise_scale=float(noise))
-        if n_cand > 0:
-            rgb_c, sig_c = net(sc["cand_xc"][:n_cand], None)
-        else:
-            rgb_c, sig_c = torch.zeros((1, 3), device=dev, requires_grad=True), torch.zeros(1, device=dev, requires_grad=True)
+                  noise=torch.randn(cap, device=dev) if noise > 0 else None, noise_scale=float(noise))
+        from ..training import field_autograd
+        rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cand_cap], n_dev=sc["n_cand"])
+        self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)
         color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
         return {
             "rgb_coarse": color.reshape(rays.o.shape),
@@ -297,6 +303,30 @@ class Raymarcher(torch.nn.Module):
             "alpha_coarse": alpha.reshape(rays.near.shape),
             "weight_coarse": weights.reshape(*rays.near.shape, -1),
         }
+
+    #: capacity (candidates) of the training field call; 2^20 x 480 B of activations = 0.5 GB
+    train_cand_capacity = 1 << 20
+    train_overflow = 0
+
+    def _train_counts_post(self, n_samples, n_cand, cand_cap):
+        if not hasattr(self, "_tc_host"):
+            self._tc_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._tc_host.copy_(torch.cat([n_samples, n_cand]), non_blocking=True)
+        self._tc_event = torch.cuda.Event()
+        self._tc_event.record()
+        self._tc_cap = cand_cap
+
+    def _train_counts_check(self):
+        """Deferred look at the previous step's counts (no stall: that step has long finished)."""
+        ev = getattr(self, "_tc_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._tc_event = None
+        self.last_train_counts = (int(self._tc_host[0]), int(self._tc_host[1]))
+        if self.last_train_counts[1] > self._tc_cap:
+            self.train_overflow += 1
+            self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_train_counts[1])
 
     def _occ_desc_cached(self, grid):
         key = id(grid.aabb)

@@ -40,18 +40,22 @@ def _mm_f32(a, b):
 
 class _FieldFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, enc_params, col_params, net):
+    def forward(ctx, x, enc_params, col_params, net, n_dev):
+        """n_dev: optional device int32[1] live count -- x is then a capacity-sized buffer whose
+        tail is never read; outputs past the count are zero."""
         L = _lib.lib()
         xc = x.detach().reshape(-1, 3).float().contiguous()
         V = xc.shape[0]
         stride = L.ia_field_act_stride(net.n_levels)
         acts = torch.empty((V, stride), device=x.device, dtype=torch.float16)
-        rgb = torch.empty((V, 3), device=x.device)
-        sigma = torch.empty(V, device=x.device)
-        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, C.byref(net.field_desc(V)), _lib.ptr(rgb), _lib.ptr(sigma),
-                                        _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
+        alloc = torch.zeros if n_dev is not None else torch.empty
+        rgb = alloc((V, 3), device=x.device)
+        sigma = alloc(V, device=x.device)
+        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, _lib.ptr(n_dev), C.byref(net.field_desc(V)), _lib.ptr(rgb),
+                                        _lib.ptr(sigma), _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
         ctx.net = net
         ctx.need_dx = x.requires_grad
+        ctx.n_dev = n_dev
         ctx.save_for_backward(xc, acts, rgb)
         return rgb, sigma
 
@@ -74,16 +78,17 @@ class _FieldFn(torch.autograd.Function):
             dfeat = torch.empty((V, nf), device=xc.device)
             base_e, base_c = g_enc.data_ptr(), g_col.data_ptr()
             _lib.check(_lib.lib().ia_field_bwd(_lib.ptr(acts), _lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V,
-                                               _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
+                                               _lib.ptr(ctx.n_dev), _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
                                                base_e + 4 * n1, base_c, base_c + 4 * 1024, base_c + 4 * 5120,
                                                _lib.stream()), "ia_field_bwd")
         else:
             dfeat = _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col)
         dtable = g_enc[n1 + 1024:]
-        dx = torch.empty((V, 3), device=xc.device) if ctx.need_dx else None
-        _lib.check(_lib.lib().ia_hashgrid_bwd(_lib.ptr(xc), V, C.byref(net.field_desc()), _lib.ptr(dfeat),
-                                              dtable.data_ptr(), _lib.ptr(dx), _lib.stream()), "ia_hashgrid_bwd")
-        return dx, g_enc, g_col, None
+        dx = (torch.zeros if ctx.n_dev is not None else torch.empty)((V, 3), device=xc.device) if ctx.need_dx else None
+        _lib.check(_lib.lib().ia_hashgrid_bwd(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
+                                              _lib.ptr(dfeat), dtable.data_ptr(), _lib.ptr(dx), _lib.stream()),
+                   "ia_hashgrid_bwd")
+        return dx, g_enc, g_col, None, None
 
 
 #: MLP backward through the fused MFMA kernel (`ia_field_bwd`).  False = the GEMM formulation
@@ -126,8 +131,8 @@ def _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col):
     return dfeat
 
 
-def field_autograd(net, x):
-    return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net)
+def field_autograd(net, x, n_dev=None):
+    return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net, n_dev)
 
 
 class _NeRFLossFn(torch.autograd.Function):
