@@ -128,6 +128,42 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
+def hashgrid_roofline(model, dev, n=1 << 20, reps=20):
+    """The hash-grid lookup in isolation (north_star: fraction of the HBM roofline on the hash-grid
+    lookup): the XCD-sharded encoding kernel on 2^20 uniformly random points of the field's bounding
+    box, timed with events on the launch stream.  Algorithmic bytes = 512 B per sample."""
+    net = model.net_coarse
+    bb = model.deformer.bbox
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand((n, 3), device=dev, generator=g) * (bb[1] - bb[0]) + bb[0]
+    with torch.no_grad():
+        for _ in range(3):
+            net.encode_planes(x)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            net.encode_planes(x)
+        b.record()
+        torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    gbs = n * 512 / (us * 1e-6) / 1e9
+    out = {"kernel": "k_encode_xcd", "samples": n, "avg_launch_us": us, "Gsamples_per_s": n / us * 1e-3, "bound": "hbm",
+           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "note": ("the 26 MB fp16 table is served from the per-XCD L2s (one hashed level per XCD): the binding limit is the "
+                    "L2 request rate, 8 XCD x 16 channels x 2.1 GHz = 269 G requests/s; see l2_* (profiles/r01_pmc_encode.json)")}
+    pj = os.path.join(ROOT, "profiles", "r01_pmc_encode.json")
+    if os.path.exists(pj):
+        try:
+            c = json.load(open(pj))["k_encode_xcd<16>"]
+            req = c["l2_read_requests_per_sample"]
+            out.update(l2_hit_rate=c["l2_hit_rate"], l2_read_requests_per_sample=req,
+                       l2_request_rate_frac=req * n / (us * 1e-6) / 269e9,
+                       traffic=c["fabric_fetch_bytes_per_launch_x2_corrected"])
+        except Exception:
+            pass
+    return out
+
+
 def main():
     args = parse()
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,7 +295,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "note": ("algorithmic bytes: k_search = 384 B per trilinear fetch of the 25 MB transform grid (L2 / Infinity-Cache "
                          "resident, so achieved can exceed the HBM peak; `traffic` is what reached the fabric); "
-                         "k_field = 540 B per sample (512 B hash-table gathers)"),
+                         "k_field (encode + MLP kernels) = 540 B per sample (512 B hash-table gathers).  The fetch pattern of "
+                         "k_search measured in isolation (tools/ubench/records.hip, 24 x 16-byte loads per lane and fetch): "
+                         "35.7 G fetches/s with L1-resident cells, 23.8 G/s L2-resident, 11.0 G/s from the fabric"),
+                "fetches_per_s": ks["units"][1] / (ks["ms"] * 1e-3) if ks["ms"] > 0 else 0.0,
+                "fetch_pattern_ceiling_per_s": {"l1_resident": 35.7e9, "l2_resident": 23.8e9, "fabric": 11.0e9},
                 "avg_launch_us": per_launch_ms * 1e3, "launches": k["launches"],
                 "algorithmic_bytes_per_launch": k["bytes"] / max(k["launches"], 1),
                 "other": {n: {"avg_launch_us": v["ms"] * 1e3 / max(v["launches"], 1), "launches": v["launches"],
@@ -285,6 +325,8 @@ def main():
     }
     if roof is not None:
         result["roofline"] = roof
+    if rank == 0 and prof:
+        result["hashgrid_lookup"] = hashgrid_roofline(model, dev)
     if args.train_steps > 0:
         result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res)
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:

@@ -83,8 +83,8 @@ extern "C" int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float 
   IA_CHECK_ARG(rgb && tgt_rgb && alpha && tgt_alpha && out5 && d_rgb && d_alpha && (n_weights == 0 || (weight && d_weight)),
                "ia_nerf_loss: null pointer");
   long long work = n_weights > 3LL * n_rays ? n_weights : 3LL * n_rays;
-  long long blocks = (work + 1023) / 1024;  // ~4 elements per thread
-  if (blocks > 2048) blocks = 2048;
+  long long blocks = (work + 1023) / 1024;  // ~4 elements per thread ...
+  if (blocks > 256) blocks = 256;           // ... but few workgroups: each ends in five atomics on the same words
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_nerf_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rgb, tgt_rgb, alpha, tgt_alpha,
                      weight, n_rays, n_weights, w_rgb, w_alpha, w_reg, out5, d_rgb, d_alpha, d_weight);

@@ -1,5 +1,5 @@
 """Turns `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` counter_collection CSVs of a bench.py run
-into HBM traffic per launch for the two dominant kernels -> profiles/r01_pmc_traffic.json
+into HBM traffic per launch for the two dominant kernel stages (k_search; k_field = k_encode_xcd + k_field) -> profiles/r01_pmc_traffic.json
 (read by bench.py to fill roofline.traffic).
 
 Units and corrections as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE / WRITE_SIZE are in
@@ -21,14 +21,16 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"].split("(")[0]
-        k = "k_search" if "k_search" in k else "k_field" if "k_field" in k else None
+        enc = "k_encode_xcd" in k  # first half of the field stage: bytes count, launches do not
+        k = "k_search" if "k_search" in k else "k_field" if ("k_field" in k or enc) else None
         if k is None:
             continue
         tot[k] += float(r["Counter_Value"])
         key = (k, r["Dispatch_Id"])
         if key not in seen:
             seen.add(key)
-            n[k] += 1
+            if not enc:
+                n[k] += 1
     return {k: (tot[k], n[k]) for k in tot}
 
 
