@@ -290,6 +290,9 @@ int ia_deform_query(const float *pts, int P, const int32_t *n_pts_dev,
  * the deformed voxels (ia_precompute's bbox).  Outputs occ_bits / occ_bool /
  * density [G^3].                                                             */
 size_t ia_density_init_workspace_bytes(int G, int n_init);
+/* Larger workspace that lets ia_density_grid_init probe all `iters` jittered sets in one
+ * search / field launch (same result; 0 = not available for these sizes).                  */
+size_t ia_density_init_workspace_bytes_batched(int G, int n_init, int iters);
 int ia_density_grid_init(const float *jitter, int iters, int G,
                          const float *aabb, const float *voxel_J,
                          const float *tfs, const int32_t *bone_ids, int n_init,

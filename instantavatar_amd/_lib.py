@@ -74,6 +74,7 @@ _SIGS = {
     "ia_deform_query": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                   C.POINTER(SnarfGrid), C.POINTER(Field), _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_density_init_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ia_density_init_workspace_bytes_batched": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ia_density_grid_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                        C.POINTER(SnarfGrid), C.POINTER(Field), _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -375,19 +375,20 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, int n) {
 
 // probe points of DensityGrid.initialize (density_grid.py:100):
 // coords = (idx/G + rand/G) * (aabb1 - aabb0) + aabb0
-__global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G,
+__global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G, int iters,
                                                       const float *__restrict__ aabb,
                                                       float *__restrict__ pts, int32_t *__restrict__ n_cand) {
   const int n = G * G * G;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *n_cand = 0;  // candidate counter of the following search
-  if (i >= n) return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // probe set p / n, cell p % n; jitter is [iters][n][3]
+  if (p == 0) *n_cand = 0;  // candidate counter of the following search
+  if (p >= n * iters) return;
+  const int i = p % n;
   const int idx[3] = {i / (G * G), i / G % G, i % G};
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     const float c0 = (float)idx[d] / (float)G;
-    const float c = c0 + jitter[(size_t)i * 3 + d] / (float)G;
-    pts[(size_t)i * 3 + d] = c * (aabb[3 + d] - aabb[d]) + aabb[d];
+    const float c = c0 + jitter[(size_t)p * 3 + d] / (float)G;
+    pts[(size_t)p * 3 + d] = c * (aabb[3 + d] - aabb[d]) + aabb[d];
   }
 }
 
@@ -774,6 +775,32 @@ extern "C" size_t ia_density_init_workspace_bytes(int G, int n_init) {
   return ia_align((size_t)n * 12) + query_ws_bytes(n, n_init) + ia_occupancy_workspace_bytes(G) + 4096;
 }
 
+// workspace for probing all `iters` jittered point sets in ONE search / field launch
+extern "C" size_t ia_density_init_workspace_bytes_batched(int G, int n_init, int iters) {
+  const size_t n = (size_t)G * G * G * (size_t)(iters > 0 ? iters : 1);
+  if (n * (size_t)n_init > 0x7fffffffu) return 0;  // does not fit the 32-bit candidate indices: not available
+  return ia_align(n * 12) + query_ws_bytes((int)n, n_init) + ia_occupancy_workspace_bytes(G) + 4096;
+}
+
+// max over the probe sets of the per-point candidate max (density_grid.py:98-102: density starts at
+// 0 and is torch.maximum-ed with every set -- max is order independent)
+__global__ __launch_bounds__(256) void k_probe_max(const float *__restrict__ cand_rgb,
+                                                   const float *__restrict__ cand_sigma,
+                                                   const int32_t *__restrict__ pt_off,
+                                                   const uint8_t *__restrict__ pt_cnt, int n, int iters, int n_init,
+                                                   float *__restrict__ density) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = 0.f;
+  for (int it = 0; it < iters; it++) {
+    const size_t p = (size_t)it * n + i;
+    float sg, c[3];
+    cand_max(cand_rgb, cand_sigma, pt_off[p], pt_cnt[p], n_init, 0.f, true, sg, c);
+    m = fmaxf(m, sg);
+  }
+  density[i] = m;
+}
+
 extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const float *aabb,
                                     const float *voxel_J, const float *tfs, const int32_t *bone_ids, int n_init,
                                     const ia_snarf_grid *grid, const ia_field *field, float *density,
@@ -786,14 +813,30 @@ extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const
   IA_CHECK_ARG(rc == 0, "ia_density_grid_init: bad field descriptor (%d)", rc);
   hipStream_t s = (hipStream_t)stream;
   const int n = G * G * G;
+  const dim3 grd(ia_div_up(n, 256)), blk(256);
+  const size_t need_batched = ia_density_init_workspace_bytes_batched(G, n_init, iters);
+  if (need_batched && ws_bytes >= need_batched) {
+    // The probe sets are independent: one launch over iters x G^3 points instead of `iters` launches
+    // whose sparse tails (most probe points lie in empty space) cannot overlap.
+    const int n_all = n * iters;
+    WsCarver w(ws, ws_bytes);
+    float *pts = w.take<float>((size_t)n_all * 3);
+    QueryWs q = carve_query(w, n_all, n_init);
+    void *occ_ws = w.take<char>(ia_occupancy_workspace_bytes(G));
+    hipLaunchKernelGGL(k_probe_points, dim3(ia_div_up(n_all, 256)), blk, 0, s, jitter, G, iters, aabb, pts, q.n_cand);
+    rc = query_impl(pts, n_all, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, iters, n_init, density);
+    IA_LAUNCH_CHECK("density_grid_init");
+    return ia_occupancy_from_density(density, G, occ_bits, occ_bool, occ_ws, ia_occupancy_workspace_bytes(G), s);
+  }
   WsCarver w(ws, ws_bytes);
   float *pts = w.take<float>((size_t)n * 3);
   QueryWs q = carve_query(w, n, n_init);
   void *occ_ws = w.take<char>(ia_occupancy_workspace_bytes(G));
-  const dim3 grd(ia_div_up(n, 256)), blk(256);
   hipLaunchKernelGGL(k_fill_f32, grd, blk, 0, s, density, 0.f, n);  // density_grid.py:98
   for (int it = 0; it < iters; it++) {
-    hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, aabb, pts, q.n_cand);
+    hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, 1, aabb, pts, q.n_cand);
     rc = query_impl(pts, n, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_candidate_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n,

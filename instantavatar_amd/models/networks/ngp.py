@@ -112,7 +112,7 @@ class NeRFNGPNet(nn.Module):
 
     #: upper bound of the XCD-sharded encoding scratch (64 B per sample); larger calls use the
     #: single fused kernel.  0 disables the sharded path.
-    max_encode_workspace_bytes = 1 << 30
+    max_encode_workspace_bytes = 2 << 30
 
     def _reserve_encode_workspace(self, n_samples, device):
         """Level-plane scratch of the XCD-sharded encoding (`ia_field.enc_ws`): grown on demand,

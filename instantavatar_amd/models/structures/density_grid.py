@@ -112,14 +112,16 @@ class DensityGrid(torch.nn.Module):
         if isinstance(deformer, SNARFDeformer) and isinstance(net, NeRFNGPNet):
             L = _lib.lib()
             k = len(deformer.deformer.init_bones)
-            ws = self._workspace(L.ia_density_init_workspace_bytes(G, k))
+            # all probe sets in one launch when the sizes allow (288 GB of HBM: ~1 GB of scratch)
+            ws = self._workspace(max(L.ia_density_init_workspace_bytes(G, k),
+                                     L.ia_density_init_workspace_bytes_batched(G, k, iters)))
             density = torch.empty((G, G, G), device=dev)
             out8 = torch.empty((G, G, G), dtype=torch.uint8, device=dev)
             tfs = deformer.tfs.detach().float().contiguous()
             _lib.check(L.ia_density_grid_init(_lib.ptr(jitter), iters, G, _lib.ptr(self.aabb_tensor()),
                                               _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs),
                                               deformer.deformer._bones_c, k, C.byref(deformer.deformer.grid_desc()),
-                                              C.byref(net.field_desc(G * G * G * k)), _lib.ptr(density), _lib.ptr(self.occ_bits),
+                                              C.byref(net.field_desc(G * G * G * k * iters)), _lib.ptr(density), _lib.ptr(self.occ_bits),
                                               _lib.ptr(out8), _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "ia_density_grid_init")
             self.density_field = out8.bool()
