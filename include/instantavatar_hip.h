@@ -106,6 +106,23 @@ int ia_smpl_tfs(const float *joints_rest, const int32_t *parents,
                 const float *pose, const float *transl, const float *tfs_inv_t,
                 float *tfs, float *w2s, float *A, void *stream);
 
+/* ---- SMPLDeformer (nearest-vertex deformer plugin) ------------------
+ * Replaces SMPLDeformer.deform (deformers/smpl_deformer.py:86-110) incl. the pytorch3d
+ * knn_points call (K = 1): for every point the nearest of the n_verts posed SMPL vertices
+ * (verts [n_verts,3], SMPL-root frame), valid = dist^2 < threshold^2, pts_cano = T_inv[nearest]
+ * applied to the point (T_inv [n_verts,4,4], smpl_deformer.py:66-75).  idx: optional.       */
+int ia_smpl_nn_deform(const float *pts, int P, const int32_t *n_pts_dev, const float *verts,
+                      const float *T_inv, int n_verts, float threshold, float *pts_cano,
+                      uint8_t *valid, int32_t *idx, void *stream);
+/* Fused deform_test / deform_train (smpl_deformer.py:112-131): the field is evaluated on the
+ * valid points only; invalid points get sigma = fill (0 at test, -1e5 in training), rgb = 0;
+ * nan_to_num != 0 zeroes non-finite field outputs.  rgb may be NULL.                        */
+size_t ia_smpl_query_workspace_bytes(int P);
+int ia_smpl_deform_query(const float *pts, int P, const int32_t *n_pts_dev, const float *verts,
+                         const float *T_inv, int n_verts, float threshold, const ia_field *field,
+                         float fill, int nan_to_num, float *rgb, float *sigma, void *ws,
+                         size_t ws_bytes, void *stream);
+
 /* ---- a20: skinning-weight voxelisation (one-time) ---------------------------
  * Replaces query_weights_smpl (fast_snarf/deformer_torch.py:225-244) including the
  * pytorch3d knn_points call (third_parties/pytorch3d/ops.py:123): for every voxel

@@ -58,6 +58,10 @@ _SIGS = {
     "ia_hashgrid_bwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),
     "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
+    "ia_smpl_nn_deform": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP]),
+    "ia_smpl_query_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ia_smpl_deform_query": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, C.POINTER(Field), C.c_float,
+                                       C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 5),
     "ia_field_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, C.POINTER(Field)] + [_VP] * 7),
     "ia_hashgrid_fwd": (C.c_int, [_VP, C.c_int, C.POINTER(Field), _VP, _VP]),

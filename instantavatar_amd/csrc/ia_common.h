@@ -66,6 +66,22 @@ struct FieldDev {
   uint32_t n_dense, hash_base, hash_size;
 };
 int ia_make_field_dev(const ia_field *f, FieldDev *out);
+// field stage (encoding + MLPs) on V samples (n_dev: optional device-side live count); acts: training record or null
+int ia_launch_field(const float *x, int V, const int32_t *n_dev, const FieldDev &F, float *rgb, float *sigma,
+                    hipStream_t s, uint16_t *acts);
+
+// carves typed, 256-byte aligned pieces out of a caller-provided workspace
+struct WsCarver {
+  char *base; size_t off, cap;
+  WsCarver(void *p, size_t c) : base((char *)p), off(0), cap(c) {}
+  template <typename T> T *take(size_t n) {
+    T *r = (T *)(base + off);
+    off += ia_align(n * sizeof(T));
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
 
 struct OccDev {
   int G;

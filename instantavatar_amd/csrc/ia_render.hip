@@ -602,17 +602,6 @@ static OccDev make_occ(const ia_occ_grid *o) {
   return d;
 }
 
-struct WsCarver {
-  char *base; size_t off, cap;
-  WsCarver(void *p, size_t c) : base((char *)p), off(0), cap(c) {}
-  template <typename T> T *take(size_t n) {
-    T *r = (T *)(base + off);
-    off += ia_align(n * sizeof(T));
-    return r;
-  }
-  bool ok() const { return off <= cap; }
-};
-
 extern "C" int ia_raymarch_test(const float *rays_o, const float *rays_d, float *nears, const float *fars,
                                 const int64_t *alive, int n_alive, const uint32_t *occ_bits,
                                 const ia_occ_grid *occ, const float *step_size, int N_steps, float *pts,

@@ -1,0 +1,129 @@
+// ia_smpl_nn.hip -- SMPLDeformer (instant_avatar/deformers/smpl_deformer.py:86-131): the deformer
+// plugin that maps a point to canonical space with the inverse transform of its NEAREST SMPL vertex
+// (pytorch3d knn_points, K = 1) when that vertex is closer than `threshold`.
+//
+// Exact 1-NN by brute force: 6 890 vertices are 83 KB -- the whole vertex set is staged in LDS
+// once per workgroup (all lanes of a wave read the SAME vertex: an LDS broadcast, no bank
+// conflicts), every thread keeps the running minimum of its own point.  Squared distance in the
+// checker's operation order (dx*dx, fma dy, fma dz), first minimum wins.  Optional compaction of
+// the valid points (ballot + block scan + one global atomic) feeds the field kernels directly, so
+// deform_test / deform_train run without the reference's boolean-mask gathers and `.any()` syncs.
+#include "ia_common.h"
+
+#define IA_NN_THREADS 256
+
+__global__ __launch_bounds__(IA_NN_THREADS) void k_smpl_nn(
+    const float *__restrict__ pts, int P, const int32_t *__restrict__ n_pts_dev, const float *__restrict__ verts,
+    const float *__restrict__ T_inv, int NV, float thr2, float *__restrict__ pts_cano, uint8_t *__restrict__ valid,
+    int32_t *__restrict__ idx_out,
+    // compaction (optional): canonical positions of the valid points, per-point offset / count (0|1)
+    float *__restrict__ cand_xc, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
+    int32_t *__restrict__ n_cand) {
+  extern __shared__ __attribute__((aligned(16))) float s_v[];  // [NV][3]
+  __shared__ int s_wtot[IA_NN_THREADS / 64];
+  __shared__ int s_base;
+  if (n_pts_dev) P = min(P, *n_pts_dev);
+  if ((int)(blockIdx.x * IA_NN_THREADS) >= P) return;  // uniform per workgroup
+  for (int e = threadIdx.x; e < NV * 3; e += IA_NN_THREADS) s_v[e] = verts[e];
+  __syncthreads();
+  const int i = blockIdx.x * IA_NN_THREADS + threadIdx.x;
+  const bool live = i < P;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (live) { px = pts[(size_t)i * 3]; py = pts[(size_t)i * 3 + 1]; pz = pts[(size_t)i * 3 + 2]; }
+  float best = INFINITY;
+  int bi = 0;
+#pragma unroll 4
+  for (int v = 0; v < NV; v++) {
+    const float dx = px - s_v[v * 3], dy = py - s_v[v * 3 + 1], dz = pz - s_v[v * 3 + 2];
+    const float dist = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    if (dist < best) { best = dist; bi = v; }
+  }
+  const float *T = T_inv + (size_t)bi * 16;
+  float c[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) c[r] = IA_DOT3(T[r * 4], px, T[r * 4 + 1], py, T[r * 4 + 2], pz) + T[r * 4 + 3];
+  const bool ok = live && best < thr2;
+  if (live) {
+    if (pts_cano) { pts_cano[(size_t)i * 3] = c[0]; pts_cano[(size_t)i * 3 + 1] = c[1]; pts_cano[(size_t)i * 3 + 2] = c[2]; }
+    if (valid) valid[i] = ok;
+    if (idx_out) idx_out[i] = bi;
+  }
+  if (!cand_xc) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) s_wtot[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < IA_NN_THREADS / 64; w++) { const int t = s_wtot[w]; s_wtot[w] = tot; tot += t; }
+    s_base = tot > 0 ? atomicAdd(n_cand, tot) : 0;
+  }
+  __syncthreads();
+  if (!live) return;
+  const int o = s_base + s_wtot[wave] + __popcll(m & ((1ull << lane) - 1ull));
+  pt_off[i] = o;
+  pt_cnt[i] = ok ? 1 : 0;
+  if (ok) { cand_xc[(size_t)o * 3] = c[0]; cand_xc[(size_t)o * 3 + 1] = c[1]; cand_xc[(size_t)o * 3 + 2] = c[2]; }
+}
+
+static int launch_nn(const float *pts, int P, const int32_t *n_pts_dev, const float *verts, const float *T_inv, int NV,
+                     float threshold, float *pts_cano, uint8_t *valid, int32_t *idx, float *cand_xc, int32_t *pt_off,
+                     uint8_t *pt_cnt, int32_t *n_cand, hipStream_t s) {
+  const size_t shmem = (size_t)NV * 12;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smpl_nn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_smpl_nn, dim3(ia_div_up(P, IA_NN_THREADS)), dim3(IA_NN_THREADS), shmem, s, pts, P, n_pts_dev, verts,
+                     T_inv, NV, threshold * threshold, pts_cano, valid, idx, cand_xc, pt_off, pt_cnt, n_cand);
+  IA_LAUNCH_CHECK("k_smpl_nn");
+  return IA_OK;
+}
+
+extern "C" int ia_smpl_nn_deform(const float *pts, int P, const int32_t *n_pts_dev, const float *verts,
+                                 const float *T_inv, int n_verts, float threshold, float *pts_cano, uint8_t *valid,
+                                 int32_t *idx, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_smpl_nn_deform: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pts && verts && T_inv && pts_cano && valid, "ia_smpl_nn_deform: null pointer");
+  IA_CHECK_ARG(n_verts > 0 && (size_t)n_verts * 12 <= 160 * 1024 - 4096, "ia_smpl_nn_deform: %d vertices do not fit LDS", n_verts);
+  return launch_nn(pts, P, n_pts_dev, verts, T_inv, n_verts, threshold, pts_cano, valid, idx, nullptr, nullptr, nullptr,
+                   nullptr, (hipStream_t)stream);
+}
+
+// fused deform_test / deform_train of the SMPLDeformer: NN + transform + compaction -> field on the
+// valid points -> per-point result (invalid: sigma = fill, rgb = 0)
+extern "C" size_t ia_smpl_query_workspace_bytes(int P) {
+  const size_t p = (size_t)(P > 0 ? P : 1);
+  return ia_align(256) + ia_align(p * 4) + ia_align(p) + 2 * ia_align(p * 12) + ia_align(p * 4) + 1024;
+}
+
+extern "C" int ia_smpl_deform_query(const float *pts, int P, const int32_t *n_pts_dev, const float *verts,
+                                    const float *T_inv, int n_verts, float threshold, const ia_field *field,
+                                    float fill, int nan_to_num, float *rgb, float *sigma, void *ws, size_t ws_bytes,
+                                    void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_smpl_deform_query: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pts && verts && T_inv && sigma && ws, "ia_smpl_deform_query: null pointer");
+  IA_CHECK_ARG(n_verts > 0 && (size_t)n_verts * 12 <= 160 * 1024 - 4096, "ia_smpl_deform_query: %d vertices do not fit LDS", n_verts);
+  if (ws_bytes < ia_smpl_query_workspace_bytes(P)) return ia_set_error(IA_ERR_WORKSPACE, "ia_smpl_deform_query: workspace too small");
+  FieldDev F;
+  int rc = ia_make_field_dev(field, &F);
+  IA_CHECK_ARG(rc == 0, "ia_smpl_deform_query: bad field descriptor (%d)", rc);
+  hipStream_t s = (hipStream_t)stream;
+  WsCarver w(ws, ws_bytes);
+  int32_t *n_cand = w.take<int32_t>(64);
+  int32_t *pt_off = w.take<int32_t>(P);
+  uint8_t *pt_cnt = w.take<uint8_t>(P);
+  float *cand_xc = w.take<float>((size_t)P * 3);
+  float *cand_rgb = w.take<float>((size_t)P * 3);
+  float *cand_sigma = w.take<float>(P);
+  (void)hipMemsetAsync(n_cand, 0, 4, s);
+  rc = launch_nn(pts, P, n_pts_dev, verts, T_inv, n_verts, threshold, nullptr, nullptr, nullptr, cand_xc, pt_off, pt_cnt,
+                 n_cand, s);
+  if (rc) return rc;
+  rc = ia_launch_field(cand_xc, P, n_cand, F, cand_rgb, cand_sigma, s, nullptr);
+  if (rc) return rc;
+  return ia_candidate_max(cand_rgb, cand_sigma, pt_off, pt_cnt, P, n_pts_dev, 1, fill, nan_to_num, rgb, sigma, stream);
+}

@@ -26,6 +26,8 @@ class SMPLOutput:  # smplx/utils.py:59 (fields used on the path)
     body_pose: Optional[torch.Tensor] = None
     A: Optional[torch.Tensor] = None
     T: Optional[torch.Tensor] = None
+    shape_offsets: Optional[torch.Tensor] = None
+    pose_offsets: Optional[torch.Tensor] = None
 
 
 def batch_rodrigues(rot_vecs):
@@ -131,10 +133,13 @@ class SMPL(nn.Module):
         Jt, A = batch_rigid_transform(rot, J, self.parents)
         verts = None
         T = None
+        shape_offsets = pose_offsets = None
         if return_verts:
             ident = torch.eye(3, dtype=betas.dtype, device=betas.device)
             pose_feature = (rot[:, 1:] - ident).view(B, -1)
-            v_posed = v_shaped + torch.matmul(pose_feature, self.posedirs).view(B, -1, 3)
+            pose_offsets = torch.matmul(pose_feature, self.posedirs).view(B, -1, 3)      # lbs.py:211-222
+            shape_offsets = v_shaped - self.v_template                                    # lbs.py:185-187
+            v_posed = v_shaped + pose_offsets
             W = self.lbs_weights.unsqueeze(0).expand(B, -1, -1)
             T = torch.matmul(W, A.view(B, 24, 16)).view(B, -1, 4, 4)
             vh = torch.cat([v_posed, torch.ones_like(v_posed[..., :1])], dim=2)
@@ -148,4 +153,4 @@ class SMPL(nn.Module):
                 T = T.clone()
                 T[..., :3, 3] += transl.unsqueeze(1)
         return SMPLOutput(vertices=verts, joints=Jt, betas=betas, global_orient=global_orient,
-                          body_pose=body_pose, A=A, T=T)
+                          body_pose=body_pose, A=A, T=T, shape_offsets=shape_offsets, pose_offsets=pose_offsets)

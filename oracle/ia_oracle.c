@@ -747,4 +747,31 @@ void orc_query_weights_smpl(const float *pts, long N, const float *verts,
   free(mean);
 }
 
+/* ------------------------------------------------------------------------ */
+/* SMPLDeformer.deform (deformers/smpl_deformer.py:86-110): nearest SMPL      */
+/* vertex (pytorch3d knn_points, K = 1: squared distance summed over x,y,z,   */
+/* first minimum wins), valid = dist^2 < threshold^2 (fp32), and the point    */
+/* moved by that vertex's inverse transform T_inv [Vn,4,4].                   */
+/* ------------------------------------------------------------------------ */
+void orc_smpl_nn_deform(const float *pts, long P, const float *verts, int Vn,
+                        const float *T_inv, float threshold, float *pts_cano,
+                        uint8_t *valid, int32_t *idx_out) {
+  const float thr2 = threshold * threshold;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < P; i++) {
+    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    float best = INFINITY; int bi = 0;
+    for (int v = 0; v < Vn; v++) {
+      const float dx = px - verts[v * 3], dy = py - verts[v * 3 + 1], dz = pz - verts[v * 3 + 2];
+      const float dist = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (dist < best) { best = dist; bi = v; }
+    }
+    const float *T = T_inv + (long)bi * 16;
+    for (int r = 0; r < 3; r++)
+      pts_cano[i * 3 + r] = fmaf(T[r * 4 + 2], pz, fmaf(T[r * 4 + 1], py, T[r * 4] * px)) + T[r * 4 + 3];
+    valid[i] = best < thr2;
+    if (idx_out) idx_out[i] = bi;
+  }
+}
+
 int orc_version(void) { return 1; }

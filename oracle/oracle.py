@@ -135,6 +135,9 @@ def smpl_forward(body, betas, body_pose, global_orient=None, transl=None, want_v
         T = (body["lbs_weights"] @ A.reshape(24, 16)).reshape(-1, 4, 4)
         vh = np.concatenate([v_posed, np.ones((len(v_posed), 1), np.float32)], 1)
         out["vertices"] = np.einsum("vij,vj->vi", T, vh)[:, :3].astype(np.float32)
+        out["T"] = T.astype(np.float32)
+        out["shape_offsets"] = (v_shaped - body["v_template"]).astype(np.float32)       # lbs.py:185-187
+        out["pose_offsets"] = (v_posed - v_shaped).astype(np.float32)                    # lbs.py:211-222
     if transl is not None:  # body_models.py:353-360
         t = _f32(transl).reshape(3)
         out["A"] = A.copy()
@@ -142,6 +145,8 @@ def smpl_forward(body, betas, body_pose, global_orient=None, transl=None, want_v
         out["joints"] = Jt + t
         if want_verts:
             out["vertices"] = out["vertices"] + t
+            out["T"] = out["T"].copy()
+            out["T"][:, :3, 3] += t
     return out
 
 
@@ -343,3 +348,56 @@ def render_image_fast(world, rays_o, rays_d, jitter, G=64, **kw):
     out = render_test(o, d, near, far, occ, aabb, lambda p: deform_query(p, world, True), **kw)
     out.update(occ=occ, aabb=aabb, density=density)
     return out
+
+
+# ---- SMPLDeformer (deformers/smpl_deformer.py) -------------------------------------------------
+def get_bbox_from_smpl(vs, factor=1.2):
+    """smpl_deformer.py:7-18"""
+    mn, mx = vs.min(0), vs.max(0)
+    c = (mx + mn) / 2
+    s = ((mx - mn) / 2).max() * np.float32(factor)
+    return np.stack([c - s, c + s]).astype(np.float32)
+
+
+def smpl_deformer_prepare(body, betas, body_pose, global_orient, transl):
+    """SMPLDeformer.initialize + prepare_deformer (smpl_deformer.py:32-77): returns T_inv [Vn,4,4],
+    vertices in the SMPL-root frame [Vn,3], w2s [4,4], canonical bbox."""
+    pose_t = np.zeros((1, 69), np.float32)
+    pose_t[:, 2] = np.pi / 6
+    pose_t[:, 5] = -np.pi / 6
+    st = smpl_forward(body, betas, pose_t)
+    so = smpl_forward(body, betas, body_pose, global_orient, transl)
+    s2w = so["A"][0].astype(np.float32)
+    w2s = np.linalg.inv(s2w).astype(np.float32)
+    T_inv = np.linalg.inv(so["T"].astype(np.float32)) @ s2w[None]
+    T_inv[:, :3, 3] += st["pose_offsets"] - so["pose_offsets"]
+    T_inv[:, :3, 3] += st["shape_offsets"] - so["shape_offsets"]
+    T_inv = (st["T"].astype(np.float32) @ T_inv).astype(np.float32)
+    verts = (so["vertices"] @ w2s[:3, :3].T + w2s[:3, 3]).astype(np.float32)
+    return dict(T_inv=np.ascontiguousarray(T_inv), vertices=np.ascontiguousarray(verts), w2s=w2s,
+                bbox=get_bbox_from_smpl(st["vertices"]))
+
+
+def smpl_nn_deform(pts, verts, T_inv, threshold=0.05):
+    """SMPLDeformer.deform -> (pts_cano [P,3], valid [P] bool, idx [P])."""
+    pts = _f32(pts).reshape(-1, 3)
+    P = len(pts)
+    cano = np.empty((P, 3), np.float32); valid = np.empty(P, np.uint8); idx = np.empty(P, np.int32)
+    lib().orc_smpl_nn_deform(_p(pts), C.c_long(P), _p(_f32(verts)), C.c_int(len(verts)), _p(_f32(T_inv)),
+                             C.c_float(threshold), _p(cano), _p(valid), _p(idx))
+    return cano, valid.astype(bool), idx
+
+
+def smpl_deform_query(pts, prep, field, eval_mode=True, threshold=0.05):
+    """SMPLDeformer.deform_test / deform_train (smpl_deformer.py:112-131)."""
+    cano, valid, _ = smpl_nn_deform(pts, prep["vertices"], prep["T_inv"], threshold)
+    rgb = np.zeros((len(cano), 3), np.float32)
+    sigma = np.zeros(len(cano), np.float32) if eval_mode else np.full(len(cano), -1e5, np.float32)
+    if valid.any():
+        r, s = field_fwd(field, cano[valid])
+        rgb[valid], sigma[valid] = r, s
+        if not eval_mode:
+            bad = ~(np.isfinite(rgb).all(-1) & np.isfinite(sigma))
+            rgb[bad] = 0
+            sigma[bad] = -1e5
+    return rgb, sigma

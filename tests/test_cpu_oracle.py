@@ -195,3 +195,28 @@ def test_render_frame_small(oracle, small_world):
     bg = np.zeros((len(ro), 3), np.float32)
     out2 = oracle.render_test(o, d, near, far, out["occ"], out["aabb"], lambda p: oracle.deform_query(p, world, True), bg=bg)
     assert np.abs((out["rgb"] - out2["rgb"]) - (1 - out["alpha"])[:, None]).max() < 1e-6
+
+
+def test_smpl_deformer_oracle_properties(oracle):
+    """SMPLDeformer restatement (smpl_deformer.py:32-110): T_inv of vertex v maps the posed vertex v
+    (SMPL-root frame) onto the template vertex v; the nearest-vertex search equals numpy brute force."""
+    body = syn.make_body(42)
+    poses, tr = syn.procedural_pose_track(8)
+    pose, transl = poses[3], tr[3]
+    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), pose[3:], pose[:3], transl)
+    pose_t = np.zeros((1, 69), np.float32)
+    pose_t[:, 2], pose_t[:, 5] = np.pi / 6, -np.pi / 6
+    tmpl = oracle.smpl_forward(body, np.zeros(10, np.float32), pose_t)["vertices"]
+    v = prep["vertices"]
+    back = np.einsum("vij,vj->vi", prep["T_inv"][:, :3, :3], v) + prep["T_inv"][:, :3, 3]
+    assert np.abs(back - tmpl).max() < 2e-5
+    rng = np.random.RandomState(4)
+    pts = (v[rng.randint(0, len(v), 3000)] + rng.randn(3000, 3).astype(np.float32) * 0.04).astype(np.float32)
+    cano, valid, idx = oracle.smpl_nn_deform(pts, v, prep["T_inv"], 0.05)
+    d2 = ((pts[:, None, :] - v[None]) ** 2).sum(-1)
+    assert (d2.argmin(1) == idx).mean() > 0.999          # ties / last-bit order only
+    near = np.abs(d2.min(1) - 0.05 ** 2) > 1e-6
+    assert ((d2.min(1) < 0.05 ** 2) == valid)[near].all()
+    assert 0.2 < valid.mean() < 0.95
+    ref = np.einsum("pij,pj->pi", prep["T_inv"][idx, :3, :3], pts) + prep["T_inv"][idx, :3, 3]
+    assert np.abs(cano - ref).max() < 1e-5

@@ -28,3 +28,30 @@ def oracle_world(orc, body, fp, init, pose72, transl):
 
 def poses(n=4):
     return syn.procedural_pose_track(max(n, 8))
+
+
+@functools.lru_cache(maxsize=2)
+def build_smpl_deformer_world(device, n_levels=16):
+    """The second deformer plugin (SMPLDeformer) wired like `build`: synthetic body, a field whose
+    density follows the capsule body in the deformer's TEMPLATE pose, NeRFNGPNet + Raymarcher."""
+    from instantavatar_amd.deformers.smpl_deformer import SMPLDeformer
+    from instantavatar_amd.deformers.smplx import SMPL
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    from instantavatar_amd.pipeline import AvatarModel
+    from instantavatar_amd.renderers.raymarcher_acc import Raymarcher
+    body = syn.make_body(42)
+    smpl = SMPL.from_dict(body).to(device)
+    deformer = SMPLDeformer(None, "neutral", threshold=0.05, k=1, body_model=smpl)
+    betas = torch.zeros(1, 10, device=device)
+    deformer.initialize(betas, device)
+    deformer.initialized = True
+    pose_t = torch.zeros((1, 69), device=device)
+    pose_t[:, 2], pose_t[:, 5] = torch.pi / 6, -torch.pi / 6
+    cano = smpl(betas=betas, body_pose=pose_t, return_verts=False).joints[0].cpu().numpy()
+    fp = syn.make_field(cano, deformer.bbox.cpu().numpy(), seed=42, n_levels=n_levels)
+    net = NeRFNGPNet(dict(center=[0, -0.3, 0], scale=[2.5, 2.5, 2.5]), n_levels=n_levels).to(device)
+    net.load_field_dict(fp)
+    net.initialize(deformer.bbox)
+    renderer = Raymarcher(256, 291600).to(device)
+    renderer.initialize(1)
+    return AvatarModel(deformer, net, renderer).to(device), body, fp
