@@ -1,0 +1,46 @@
+"""Checkpoint I/O in the layout pytorch_lightning writes for DNeRFModel (train.py:15-21): a dict with
+`state_dict` (keys `net_coarse.encoder.params`, `net_coarse.color_net.params`, `net_coarse.center`,
+`net_coarse.scale`, `renderer.density_grid_{train,test}.*`, ... -- SURVEY.md section 5), `global_step`
+and `epoch`.  Keys of modules that are not on the hot path (e.g. `SMPLParamEmbedding`, LPIPS) are
+reported and ignored on load."""
+import torch
+
+
+def save_checkpoint(model, path, optimizer=None, epoch=0):
+    ckpt = {"state_dict": model.state_dict(), "global_step": int(getattr(model, "global_step", 0)), "epoch": int(epoch)}
+    if optimizer is not None:
+        ckpt["optimizer_states"] = [optimizer.state_dict()]
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True):
+    """Returns (missing, unexpected).  The tcnn parameter vectors must have the tcnn-v1.6 layout this
+    package restates ([MLP weights..., grid]); a size mismatch raises."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    own = model.state_dict()
+    take = {}
+    unexpected = []
+    for k, v in sd.items():
+        if k in own:
+            if tuple(own[k].shape) != tuple(v.shape):
+                raise ValueError("checkpoint tensor %s has shape %s, expected %s" % (k, tuple(v.shape), tuple(own[k].shape)))
+            take[k] = v
+        else:
+            unexpected.append(k)
+    missing = [k for k in own if k not in take]
+    on_path = [k for k in missing if k.startswith("net_coarse.") and k.endswith("params")]
+    if strict_path_keys and on_path:
+        raise KeyError("checkpoint lacks the field parameters: %s" % on_path)
+    model.load_state_dict(take, strict=False)
+    net = getattr(model, "net_coarse", None)
+    if net is not None:
+        if hasattr(net, "mark_updated"):
+            net.mark_updated()
+    for g in ("density_grid_train", "density_grid_test"):
+        grid = getattr(getattr(model, "renderer", None), g, None)
+        if grid is not None and hasattr(grid, "pack_bits") and grid.density_field.is_cuda:
+            grid.pack_bits()  # the kernels read the bit-packed mirror of density_field
+    model.global_step = int(ckpt.get("global_step", 0)) if isinstance(ckpt, dict) else 0
+    return missing, unexpected

@@ -220,3 +220,39 @@ def test_smpl_deformer_oracle_properties(oracle):
     assert 0.2 < valid.mean() < 0.95
     ref = np.einsum("pij,pj->pi", prep["T_inv"][idx, :3, :3], pts) + prep["T_inv"][idx, :3, 3]
     assert np.abs(cano - ref).max() < 1e-5
+
+
+def test_driver_config_and_checkpoint_io(tmp_path):
+    """Hydra-free config loading (confs/ groups, ${...} interpolation, _target_ instantiation) and the
+    Lightning-layout checkpoint round trip of the PL-free drivers."""
+    from instantavatar_amd.drivers import checkpoint as ck, config as cfg
+    from instantavatar_amd.pipeline import AvatarModel
+    confs = os.path.join(ROOT, "confs")
+    d = cfg.load_group(confs, "deformer", "fast_snarf", {"dataset": {"gender": "female"}, "train": {"precision": 32}})
+    assert d["gender"] == "female" and d["opt"]["precision"] == 32 and d["opt"]["resolution"] == 128
+    assert cfg.resolve("out/${a.b}/x${a.c}", {"a": {"b": "s", "c": 3}}) == "out/s/x3"
+    net = cfg.instantiate(cfg.load_group(confs, "network", "ngp", {}))
+    ren = cfg.instantiate(cfg.load_group(confs, "renderer", "raymarcher_acc", {}))
+    assert type(net).__name__ == "NeRFNGPNet" and ren.MAX_BATCH_SIZE == 291600
+    ren.initialize(1)
+    model = AvatarModel(None, net, ren)
+    model.global_step = 1234
+    with torch.no_grad():
+        net.encoder.params[:100] = torch.arange(100.0)
+    path = ck.save_checkpoint(model, str(tmp_path / "last.ckpt"), epoch=3)
+    sd = torch.load(path, weights_only=False)
+    assert set(sd) >= {"state_dict", "global_step", "epoch"} and sd["global_step"] == 1234
+    assert "net_coarse.encoder.params" in sd["state_dict"] and "net_coarse.color_net.params" in sd["state_dict"]
+    sd["state_dict"]["loss_fn.lpips.net.weight"] = torch.zeros(3)         # a module that is not on the path
+    torch.save(sd, path)
+    net2 = cfg.instantiate(cfg.load_group(confs, "network", "ngp", {}))
+    ren2 = cfg.instantiate(cfg.load_group(confs, "renderer", "raymarcher_acc", {}))
+    ren2.initialize(1)
+    model2 = AvatarModel(None, net2, ren2)
+    missing, unexpected = ck.load_checkpoint(model2, path)
+    assert unexpected == ["loss_fn.lpips.net.weight"] and not missing and model2.global_step == 1234
+    assert torch.equal(net2.encoder.params[:100], torch.arange(100.0))
+    sd["state_dict"]["net_coarse.color_net.params"] = torch.zeros(5)
+    torch.save(sd, path)
+    with pytest.raises(ValueError):
+        ck.load_checkpoint(model2, path)

