@@ -118,38 +118,48 @@ __global__ void k_bbox_init(float *bbox) {
   else if (threadIdx.x < 6) bbox[threadIdx.x] = __int_as_float(0xff800000);
 }
 
+#ifndef IA_PRE_VPT
+#define IA_PRE_VPT 4  // consecutive voxels (along W) per thread: 1, 2 or 4 (measured 173 / 185 / 95 us)
+#endif
+template <int VPT> struct PreVec;
+template <> struct PreVec<1> { typedef float type; };
+template <> struct PreVec<2> { typedef float2 type; };
+template <> struct PreVec<4> { typedef float4 type; };
+
+template <int VPT>
 __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ voxel_w,
                                                     const float *__restrict__ tfs,
                                                     float *__restrict__ voxel_J,
                                                     float *__restrict__ voxel_d,
                                                     float *__restrict__ bbox, SnarfGridDev g) {
-  // 4 consecutive voxels (along W) per thread: one 16-byte load per joint plane and
-  // 192 contiguous bytes of output per thread.  W % 4 == 0 is checked by the host.
+  // VPT consecutive voxels (along W) per thread: one (4*VPT)-byte load per joint plane and 48*VPT
+  // contiguous bytes of output per thread.  W % VPT == 0 is checked by the host.
+  typedef typename PreVec<VPT>::type vec_t;
   const int n = g.D * g.H * g.W;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += gridDim.x * blockDim.x) {
-    const int index0 = q * 4;
-    float J[4][12];
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n / VPT; q += gridDim.x * blockDim.x) {
+    const int index0 = q * VPT;
+    float J[VPT][12];
 #pragma unroll
-    for (int v = 0; v < 4; v++)
+    for (int v = 0; v < VPT; v++)
 #pragma unroll
       for (int c = 0; c < 12; c++) J[v][c] = 0.f;
     // precompute.cu:51-59: J[c] accumulates over j in joint order
     // (requesting all 24 planes before the first use was measured: 193 VGPRs, 98 -> 115 us)
 #pragma unroll 2
     for (int j = 0; j < 24; j++) {
-      const float4 w4 = *reinterpret_cast<const float4 *>(voxel_w + (size_t)j * n + index0);
-      const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+      union { vec_t v; float f[VPT]; } w;
+      w.v = *reinterpret_cast<const vec_t *>(voxel_w + (size_t)j * n + index0);
 #pragma unroll
       for (int c = 0; c < 12; c++) {
         const float t = tfs[j * 16 + c];
 #pragma unroll
-        for (int v = 0; v < 4; v++) J[v][c] = __builtin_fmaf(w[v], t, J[v][c]);
+        for (int v = 0; v < VPT; v++) J[v][c] = __builtin_fmaf(w.f[v], t, J[v][c]);
       }
     }
     float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index0 * 12);
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < VPT; v++) {
       o[3 * v + 0] = make_float4(J[v][0], J[v][1], J[v][2], J[v][3]);
       o[3 * v + 1] = make_float4(J[v][4], J[v][5], J[v][6], J[v][7]);
       o[3 * v + 2] = make_float4(J[v][8], J[v][9], J[v][10], J[v][11]);
@@ -159,9 +169,9 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
     // precompute.cu:42-47
     const float cy = (((float)idx_h) / (g.H - 1) * 2 - 1) / g.scl[1] - g.off[1];
     const float cz = (((float)idx_d) / (g.D - 1) * 2 - 1) / g.scl[2] - g.off[2];
-    float xi[3][4];
+    float xi[3][VPT];
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < VPT; v++) {
       const float cx = (((float)(idx_w0 + v)) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];
       // precompute.cu:66-70
 #pragma unroll
@@ -174,7 +184,8 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
     if (voxel_d) {
 #pragma unroll
       for (int i0 = 0; i0 < 3; i0++)
-        *reinterpret_cast<float4 *>(voxel_d + (size_t)i0 * n + index0) = make_float4(xi[i0][0], xi[i0][1], xi[i0][2], xi[i0][3]);
+#pragma unroll
+        for (int v = 0; v < VPT; v++) voxel_d[(size_t)i0 * n + index0 + v] = xi[i0][v];
     }
   }
   if (bbox) {
@@ -545,8 +556,9 @@ extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxe
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)grid->D * grid->H * grid->W;
   if (bbox) { hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox); IA_LAUNCH_CHECK("k_bbox_init"); }
-  const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_precompute, dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
+  const long nt = n / IA_PRE_VPT;
+  const int blocks = (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
                      ia_make_grid_dev(grid));
   IA_LAUNCH_CHECK("k_precompute");
   return IA_OK;
