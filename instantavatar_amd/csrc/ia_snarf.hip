@@ -332,6 +332,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   __shared__ int s_nlive;
   __shared__ int s_prof[2];
   __shared__ uint16_t s_list[IA_N_INIT_MAX * NP];
+  __shared__ float s_T[IA_N_INIT_MAX][12];  // rows 0..2 of the init bones' transforms (same indexing as the 4x4)
   if (n_pts_dev) P = min(P, *n_pts_dev);
   const int tid = threadIdx.x, lane = tid & 63;
   // (an XCD-aware remap -- XCD x takes the x-th contiguous eighth of the point list -- was measured:
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   const int n_items = np * n_init;
   if (tid == 0) { s_next = 0; s_nlive = 0; s_prof[0] = 0; s_prof[1] = 0; }
   for (int e = tid; e < np * 3; e += IA_SEARCH_THREADS) (&s_xd[0][0])[e] = xd[(size_t)p0 * 3 + e];
+  for (int e = tid; e < n_init * 12; e += IA_SEARCH_THREADS) s_T[e / 12][e % 12] = tfs[bones.id[e / 12] * 16 + e % 12];
   __syncthreads();
 
   // ---- classification -------------------------------------------------------------------
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     const int q = (init << 7) | pt;
     bool keep = false;
     if (init < n_init && pt < np) {
-      keep = !ia_solve_is_trivial(g, tfs + bones.id[init] * 16, s_xd[pt][0], s_xd[pt][1], s_xd[pt][2]);
+      keep = !ia_solve_is_trivial(g, s_T[init], s_xd[pt][0], s_xd[pt][1], s_xd[pt][2]);
       if (!keep) {
         s_x[init][pt][0] = 0.f; s_x[init][pt][1] = 0.f; s_x[init][pt][2] = 0.f;
         s_valid[init][pt] = 0;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
           item = s_list[my];
           const int init = item >> 7, pt = item & (NP - 1);
           t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
-          const float *T = tfs + bones.id[init] * 16;
+          const float *T = s_T[init];
           // :287-293  x0 = R^T (xd - t)
           const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
           xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
@@ -475,8 +477,9 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     atomicAdd(ps + 1, (unsigned long long)s_prof[1]);
   }
   // ---- a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4 ----
-  for (int q = tid; q < n_items; q += IA_SEARCH_THREADS) {
-    const int init = q / np, pt = q - init * np;
+  for (int init0 = 0; init0 < n_init; init0 += IA_SEARCH_THREADS / NP) {
+    const int init = init0 + tid / NP, pt = tid & (NP - 1);
+    if (init >= n_init || pt >= np) continue;
     bool keep = s_valid[init][pt];
     if (keep) {
       const float x0 = s_x[init][pt][0], x1 = s_x[init][pt][1], x2 = s_x[init][pt][2];
@@ -518,9 +521,9 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     pt_cnt[p0 + tid] = (uint8_t)cnt;
   }
   __syncthreads();
-  for (int q = tid; q < n_items; q += IA_SEARCH_THREADS) {
-    const int init = q / np, pt = q - init * np;
-    if (!s_keep[init][pt]) continue;
+  for (int init0 = 0; init0 < n_init; init0 += IA_SEARCH_THREADS / NP) {
+    const int init = init0 + tid / NP, pt = tid & (NP - 1);
+    if (init >= n_init || pt >= np || !s_keep[init][pt]) continue;
     int rank = 0;
     for (int j = 0; j < init; j++) rank += s_keep[j][pt];
     const int o = s_base[pt] + rank;
