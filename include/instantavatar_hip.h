@@ -209,12 +209,14 @@ int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
  * (device scalar): factor applied before gradients are rounded to half (tcnn: the fixed
  * 1024x loss scale of DNeRF.py:58), divided out of all results.  Outputs: dfeat fp32 [V,2L]
  * (input of ia_hashgrid_bwd) and the five weight gradients, ACCUMULATED in fp32 into
- * g_* (tcnn layouts [out][in]; caller zero-fills).  Needs field->mlp_frags.             */
+ * g_* (tcnn layouts [out][in]; caller zero-fills) -- per-workgroup partial sums in `ws`, added
+ * up in a fixed order: no atomics, bitwise reproducible.  Needs field->mlp_frags.          */
+size_t ia_field_bwd_workspace_bytes(int V, int n_levels);
 int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb,
                  const float *d_sigma, int V, const int32_t *n_dev, const float *scale,
-                 const ia_field *field,
-                 float *dfeat, float *g_sig_w1, float *g_sig_w2, float *g_col_w1,
-                 float *g_col_w2, float *g_col_w3, void *stream);
+                 const ia_field *field, float *dfeat, float *g_sig_w1, float *g_sig_w2,
+                 float *g_col_w1, float *g_col_w2, float *g_col_w3, void *ws, size_t ws_bytes,
+                 void *stream);
 /* Hash-grid backward (tcnn kernel_grid_backward): dtable fp32 [n_entries,2]
  * += interpolation weight * dfeat [V,2L] (fp32 atomics; caller zero-fills).
  * dx: optional [V,3] gradient w.r.t. the (un-normalised) input positions

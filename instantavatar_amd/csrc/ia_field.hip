@@ -797,8 +797,7 @@ template <int L>
 __global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
     const uint16_t *__restrict__ acts, const float *__restrict__ rgb, const float *__restrict__ d_rgb,
     const float *__restrict__ d_sigma, int V, const int32_t *__restrict__ n_dev, const float *__restrict__ scale,
-    const uint16_t *__restrict__ frags, float *__restrict__ dfeat, float *__restrict__ g_w1, float *__restrict__ g_w2, float *__restrict__ g_c1,
-    float *__restrict__ g_c2, float *__restrict__ g_c3) {
+    const uint16_t *__restrict__ frags, float *__restrict__ dfeat, float *__restrict__ partial) {
   constexpr int NF = 2 * L, STRIDE = NF + 208, RS = IA_BWD_RS, NW = IA_BWD_THREADS / 64;
   constexpr int O_H1 = NF, O_O = NF + 64, O_C1 = NF + 80, O_C2 = NF + 144;
   extern __shared__ __attribute__((aligned(16))) char s_dyn[];
@@ -977,18 +976,43 @@ __global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < N_ALL; e += IA_BWD_THREADS) {
-    const float v = red[e] * invS;
-    if (v == 0.f) continue;
-    float *dst = e < O_W2 ? g_w1 + (e - O_W1) : e < O_C1g ? g_w2 + (e - O_W2) : e < O_C2g ? g_c1 + (e - O_C1g)
-                 : e < O_C3g ? g_c2 + (e - O_C2g) : g_c3 + (e - O_C3g);
-    unsafeAtomicAdd(dst, v);
-  }
+  // per-workgroup partial sums (scaled gradients); k_field_bwd_reduce adds them up in workgroup order:
+  // no global atomics, bitwise reproducible weight gradients
+  for (int e = threadIdx.x; e < N_ALL; e += IA_BWD_THREADS) partial[(size_t)blockIdx.x * N_ALL + e] = red[e];
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_field_bwd_reduce(const float *__restrict__ partial, int n_blocks,
+                                                          const float *__restrict__ scale, float *__restrict__ g_w1,
+                                                          float *__restrict__ g_w2, float *__restrict__ g_c1,
+                                                          float *__restrict__ g_c2, float *__restrict__ g_c3) {
+  constexpr int NF = 2 * L;
+  constexpr int N_W1 = 64 * NF, N_W2 = 1024, N_C1 = 1024, N_C2 = 4096, N_C3 = 1024;
+  constexpr int O_W2 = N_W1, O_C1g = O_W2 + N_W2, O_C2g = O_C1g + N_C1, O_C3g = O_C2g + N_C2, N_ALL = O_C3g + N_C3;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N_ALL) return;
+  float acc = 0.f;
+  for (int b = 0; b < n_blocks; b++) acc += partial[(size_t)b * N_ALL + e];
+  float *dst = e < O_W2 ? g_w1 + e : e < O_C1g ? g_w2 + (e - O_W2) : e < O_C2g ? g_c1 + (e - O_C1g)
+               : e < O_C3g ? g_c2 + (e - O_C2g) : g_c3 + (e - O_C3g);
+  *dst += acc * (1.0f / *scale);
+}
+
+static int ia_field_bwd_nblocks(int V) {
+  const int n_tiles = (V + 31) / 32, per = IA_BWD_THREADS / 64;
+  int nb = (n_tiles + per - 1) / per;
+  if (nb > 512) nb = 512;  // two workgroups per CU; waves keep their 192 accumulators over all their tiles
+  return nb < 1 ? 1 : nb;
+}
+
+extern "C" size_t ia_field_bwd_workspace_bytes(int V, int n_levels) {
+  return (size_t)ia_field_bwd_nblocks(V) * (size_t)(64 * 2 * n_levels + 1024 + 1024 + 4096 + 1024) * sizeof(float);
 }
 
 extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb, const float *d_sigma, int V,
                             const int32_t *n_dev, const float *scale, const ia_field *field, float *dfeat, float *g_sig_w1,
-                            float *g_sig_w2, float *g_col_w1, float *g_col_w2, float *g_col_w3, void *stream) {
+                            float *g_sig_w2, float *g_col_w1, float *g_col_w2, float *g_col_w3, void *ws, size_t ws_bytes,
+                            void *stream) {
   IA_CHECK_ARG(V >= 0, "ia_field_bwd: V < 0");
   if (V == 0) return IA_OK;
   IA_CHECK_ARG(acts && rgb && d_rgb && d_sigma && scale && dfeat && g_sig_w1 && g_sig_w2 && g_col_w1 && g_col_w2 && g_col_w3,
@@ -1004,15 +1028,22 @@ extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float 
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const int tiles = (V + 31) / 32, per = IA_BWD_THREADS / 64;
-  int blocks = (tiles + per - 1) / per;
-  if (blocks > 512) blocks = 512;  // two workgroups per CU; waves keep their 192 accumulators over all their tiles
-  if (F.lv.n_levels == 16)
+  const int blocks = ia_field_bwd_nblocks(V);
+  IA_CHECK_ARG(ws != nullptr, "ia_field_bwd: null workspace");
+  if (ws_bytes < ia_field_bwd_workspace_bytes(V, F.lv.n_levels)) return ia_set_error(IA_ERR_WORKSPACE, "ia_field_bwd: workspace too small");
+  float *partial = static_cast<float *>(ws);
+  const int n_all = 64 * 2 * F.lv.n_levels + 1024 + 1024 + 4096 + 1024;
+  if (F.lv.n_levels == 16) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<16>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
-                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
-  else
+                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, partial);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<16>), dim3(ia_div_up(n_all, 256)), dim3(256), 0, (hipStream_t)stream,
+                       partial, blocks, scale, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+  } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<8>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
-                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+                       d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, partial);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<8>), dim3(ia_div_up(n_all, 256)), dim3(256), 0, (hipStream_t)stream,
+                       partial, blocks, scale, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
+  }
   IA_LAUNCH_CHECK("k_field_bwd");
   return IA_OK;
 }

@@ -77,10 +77,12 @@ class _FieldFn(torch.autograd.Function):
         if FUSED_MLP_BACKWARD:
             dfeat = torch.empty((V, nf), device=xc.device)
             base_e, base_c = g_enc.data_ptr(), g_col.data_ptr()
-            _lib.check(_lib.lib().ia_field_bwd(_lib.ptr(acts), _lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V,
-                                               _lib.ptr(ctx.n_dev), _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
-                                               base_e + 4 * n1, base_c, base_c + 4 * 1024, base_c + 4 * 5120,
-                                               _lib.stream()), "ia_field_bwd")
+            L = _lib.lib()
+            ws = torch.empty(int(L.ia_field_bwd_workspace_bytes(V, net.n_levels)), dtype=torch.uint8, device=xc.device)
+            _lib.check(L.ia_field_bwd(_lib.ptr(acts), _lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V,
+                                      _lib.ptr(ctx.n_dev), _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
+                                      base_e + 4 * n1, base_c, base_c + 4 * 1024, base_c + 4 * 5120, _lib.ptr(ws), ws.numel(),
+                                      _lib.stream()), "ia_field_bwd")
         else:
             dfeat = _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col)
         dtable = g_enc[n1 + 1024:]
