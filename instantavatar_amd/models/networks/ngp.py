@@ -126,6 +126,16 @@ class NeRFNGPNet(nn.Module):
         if self._desc is not None:
             self._desc.enc_ws, self._desc.enc_ws_samples = self._enc_ws.data_ptr(), n
 
+    def _center_scale_host(self):
+        """Host copies of center / scale for the C descriptor.  Read back only when the tensors changed
+        (initialize / checkpoint load): the descriptor is rebuilt after every optimizer step and a
+        device read there would synchronise the training loop once per step."""
+        key = (self.center.data_ptr(), self.center._version, self.scale.data_ptr(), self.scale._version)
+        if getattr(self, "_cs_key", None) != key:
+            self._cs_host = (self.center.detach().float().cpu().tolist(), self.scale.detach().float().cpu().tolist())
+            self._cs_key = key
+        return self._cs_host
+
     def field_desc(self, max_samples=0):
         """C descriptor of the field.  `max_samples`: largest sample count (capacity) of the
         call it is built for; reserves the sharded-encoding scratch for it."""
@@ -134,8 +144,7 @@ class NeRFNGPNet(nn.Module):
             self._reserve_encode_workspace(max_samples, enc.device)
         if self._desc is None:
             f = _lib.Field()
-            f.center[:] = self.center.detach().float().cpu().tolist()  # rare (init / bbox change) host read
-            f.scale[:] = self.scale.detach().float().cpu().tolist()
+            f.center[:], f.scale[:] = self._center_scale_host()
             f.hash = self.hash_desc
             e, c = enc.data_ptr(), col.data_ptr()
             f.sig_w1 = e
