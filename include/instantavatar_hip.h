@@ -383,9 +383,10 @@ int ia_composite_train_bwd(const float *d_color, const float *d_depth, const flo
                            float *d_cand_sigma, void *stream);
 
 /* deform_train's max over candidates (snarf_deformer.py:147-158): index of the
- * winning candidate per point, -1 when an invalid slot (sigma = -1e5) wins.    */
-int ia_candidate_argmax(const float *cand_sigma, const int32_t *pt_off, const uint8_t *pt_cnt,
-                        int P, int n_init, int32_t *arg, void *stream);
+ * winning candidate per point, -1 when an invalid slot (sigma = -1e5) wins;
+ * cand_cap = length of cand_sigma (candidates past it were dropped).          */
+int ia_candidate_argmax(const float *cand_sigma, int cand_cap, const int32_t *pt_off,
+                        const uint8_t *pt_cnt, int P, int n_init, int32_t *arg, void *stream);
 
 /* ---- measurement hooks (bench.py only) --------------------------------------
  * When enabled, every launch of the Broyden-search kernel (id 0) and of the

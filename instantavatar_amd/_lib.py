@@ -93,7 +93,7 @@ _SIGS = {
                                          C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ia_composite_train_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP,
                                          _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "ia_candidate_argmax": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
+    "ia_candidate_argmax": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
     "ia_profile_enable": (C.c_int, [C.c_int]),
     "ia_profile_reset": (C.c_int, []),
     "ia_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),

@@ -1213,25 +1213,27 @@ extern "C" int ia_composite_train_bwd(const float *d_color, const float *d_depth
   return IA_OK;
 }
 
-// arg-max candidate per point for the training path (fill = -1e5 wins -> -1)
-__global__ __launch_bounds__(256) void k_candidate_argmax(const float *__restrict__ cand_sigma,
+// arg-max candidate per point for the training path (fill = -1e5 wins -> -1); candidates past
+// cand_cap (the length of cand_sigma) were dropped by the compaction and are not read
+__global__ __launch_bounds__(256) void k_candidate_argmax(const float *__restrict__ cand_sigma, int cand_cap,
                                                           const int32_t *__restrict__ pt_off,
                                                           const uint8_t *__restrict__ pt_cnt, int P, int n_init,
                                                           int32_t *__restrict__ arg) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   float sg; int a;
-  cand_max_train(cand_sigma, pt_off[p], pt_cnt[p], n_init, sg, a);
+  const int po = pt_off[p], pc = max(0, min((int)pt_cnt[p], cand_cap - po));
+  cand_max_train(cand_sigma, po, pc, n_init, sg, a);
   arg[p] = a;
 }
 
-extern "C" int ia_candidate_argmax(const float *cand_sigma, const int32_t *pt_off, const uint8_t *pt_cnt, int P,
-                                   int n_init, int32_t *arg, void *stream) {
+extern "C" int ia_candidate_argmax(const float *cand_sigma, int cand_cap, const int32_t *pt_off, const uint8_t *pt_cnt,
+                                   int P, int n_init, int32_t *arg, void *stream) {
   IA_CHECK_ARG(P >= 0, "ia_candidate_argmax: P < 0");
   if (P == 0) return IA_OK;
   IA_CHECK_ARG(pt_off && pt_cnt && arg, "ia_candidate_argmax: null pointer");
-  hipLaunchKernelGGL(k_candidate_argmax, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_sigma, pt_off,
-                     pt_cnt, P, n_init, arg);
+  hipLaunchKernelGGL(k_candidate_argmax, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_sigma, cand_cap,
+                     pt_off, pt_cnt, P, n_init, arg);
   IA_LAUNCH_CHECK("k_candidate_argmax");
   return IA_OK;
 }

@@ -56,6 +56,9 @@ def _abs_path(p):
 
 
 class SNARFDeformer():
+    #: capacity (candidates) of one training-mode field call (`query_train_fused`)
+    train_cand_capacity = 1 << 20
+
     def __init__(self, model_path, gender, opt, body_model=None) -> None:
         # body_model: optional pre-built SMPL (e.g. SMPL.from_dict(synthetic.make_body()))
         self.body_model = body_model if body_model is not None else SMPL(_abs_path(model_path), gender=gender)
@@ -234,19 +237,19 @@ class SNARFDeformer():
 
     def query_train_fused(self, pts, net):
         """deform_train (snarf_deformer.py:143-159) without the dense [P,13,*] temporaries:
-        compacted candidates -> field under autograd -> arg-max gather.  One 4-byte host
-        read (the candidate count sizes the autograd graph)."""
+        compacted candidates -> field under autograd -> arg-max gather.  No host synchronisation."""
         P = pts.shape[0]
         k = len(self.deformer.init_bones)
         sc = self.search_compact(pts)
-        n_cand = int(sc["n_cand"].item())
         dev = pts.device
-        if n_cand == 0:
-            return torch.zeros((P, 3), device=dev), torch.full((P,), -1e5, device=dev)
-        rgb_c, sig_c = net(sc["cand_xc"][:n_cand], None)
+        # no host read: the field runs on a capacity-sized candidate buffer with the device-side count
+        # (candidates past the capacity are dropped by the compaction; cf. Raymarcher.render_train_fused)
+        cap = min(P * k, self.train_cand_capacity)
+        from ..training import field_autograd
+        rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cap], n_dev=sc["n_cand"])
         arg = torch.empty(P, dtype=torch.int32, device=dev)
         sig_d = sig_c.detach().float().contiguous()
-        _lib.check(_lib.lib().ia_candidate_argmax(_lib.ptr(sig_d), _lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), P, k,
+        _lib.check(_lib.lib().ia_candidate_argmax(_lib.ptr(sig_d), cap, _lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), P, k,
                                                   _lib.ptr(arg), _lib.stream()), "ia_candidate_argmax")
         has = arg >= 0
         idx = arg.clamp(min=0).long()

@@ -227,7 +227,8 @@ def update_density_grid(model, world_size=1):
         from .parallel import reduce_density_cache
         reduce_density_cache(grid.density_cached, world_size)
         grid._postprocess(grid.density_cached)
-    reg = N * density[~valid].mean()
+    inv = (~valid).to(density.dtype)   # mean over the cells outside the grid, without a boolean-mask gather (host sync)
+    reg = N * (density * inv).sum() / inv.sum().clamp(min=1.0)
     if model.global_step < 500:
         reg = reg + 0.5 * density.mean()
     return reg
