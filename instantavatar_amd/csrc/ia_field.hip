@@ -981,6 +981,9 @@ __global__ __launch_bounds__(IA_BWD_THREADS) void k_field_bwd(
   for (int e = threadIdx.x; e < N_ALL; e += IA_BWD_THREADS) partial[(size_t)blockIdx.x * N_ALL + e] = red[e];
 }
 
+// 256 threads = 32 gradient elements x 8 slices of the workgroup range: every thread adds up its slice
+// (independent loads, 8 in flight), the slices are combined through LDS in slice order -> the sum
+// order is fixed, the result bitwise reproducible.
 template <int L>
 __global__ __launch_bounds__(256) void k_field_bwd_reduce(const float *__restrict__ partial, int n_blocks,
                                                           const float *__restrict__ scale, float *__restrict__ g_w1,
@@ -989,13 +992,22 @@ __global__ __launch_bounds__(256) void k_field_bwd_reduce(const float *__restric
   constexpr int NF = 2 * L;
   constexpr int N_W1 = 64 * NF, N_W2 = 1024, N_C1 = 1024, N_C2 = 4096, N_C3 = 1024;
   constexpr int O_W2 = N_W1, O_C1g = O_W2 + N_W2, O_C2g = O_C1g + N_C1, O_C3g = O_C2g + N_C2, N_ALL = O_C3g + N_C3;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N_ALL) return;
+  __shared__ float s_part[8][32];
+  const int el = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;  // N_ALL is a multiple of 32
+  const int per = (n_blocks + 7) / 8, b0 = slice * per, b1 = min(b0 + per, n_blocks);
   float acc = 0.f;
-  for (int b = 0; b < n_blocks; b++) acc += partial[(size_t)b * N_ALL + e];
+#pragma unroll 8
+  for (int b = b0; b < b1; b++) acc += partial[(size_t)b * N_ALL + e];
+  s_part[slice][el] = acc;
+  __syncthreads();
+  if (slice != 0) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) tot += s_part[k][el];
   float *dst = e < O_W2 ? g_w1 + e : e < O_C1g ? g_w2 + (e - O_W2) : e < O_C2g ? g_c1 + (e - O_C1g)
                : e < O_C3g ? g_c2 + (e - O_C2g) : g_c3 + (e - O_C3g);
-  *dst += acc * (1.0f / *scale);
+  *dst += tot * (1.0f / *scale);
 }
 
 static int ia_field_bwd_nblocks(int V) {
@@ -1036,12 +1048,12 @@ extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float 
   if (F.lv.n_levels == 16) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<16>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
                        d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, partial);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<16>), dim3(ia_div_up(n_all, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<16>), dim3(n_all / 32), dim3(256), 0, (hipStream_t)stream,
                        partial, blocks, scale, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd<8>), dim3(blocks), dim3(IA_BWD_THREADS), shmem, (hipStream_t)stream, acts, rgb,
                        d_rgb, d_sigma, V, n_dev, scale, F.frags, dfeat, partial);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<8>), dim3(ia_div_up(n_all, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_field_bwd_reduce<8>), dim3(n_all / 32), dim3(256), 0, (hipStream_t)stream,
                        partial, blocks, scale, g_sig_w1, g_sig_w2, g_col_w1, g_col_w2, g_col_w3);
   }
   IA_LAUNCH_CHECK("k_field_bwd");
