@@ -375,19 +375,22 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, int n) {
 
 // probe points of DensityGrid.initialize (density_grid.py:100):
 // coords = (idx/G + rand/G) * (aabb1 - aabb0) + aabb0
+// Batched probes are laid out CELL-major: probe p is jitter set p % iters of cell p / iters, so the
+// `iters` jittered points of one cell are neighbours in the point list (same workgroup, adjacent
+// lanes): their solves start within one cell of each other and share transform-grid lines in L1.
 __global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G, int iters,
                                                       const float *__restrict__ aabb,
                                                       float *__restrict__ pts, int32_t *__restrict__ n_cand) {
   const int n = G * G * G;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // probe set p / n, cell p % n; jitter is [iters][n][3]
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // jitter is [iters][n cells][3]
   if (p == 0) *n_cand = 0;  // candidate counter of the following search
   if (p >= n * iters) return;
-  const int i = p % n;
+  const int i = p / iters, it = p - i * iters;
   const int idx[3] = {i / (G * G), i / G % G, i % G};
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     const float c0 = (float)idx[d] / (float)G;
-    const float c = c0 + jitter[(size_t)p * 3 + d] / (float)G;
+    const float c = c0 + jitter[((size_t)it * n + i) * 3 + d] / (float)G;
     pts[(size_t)p * 3 + d] = c * (aabb[3 + d] - aabb[d]) + aabb[d];
   }
 }
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(256) void k_probe_max(const float *__restrict__ can
   if (i >= n) return;
   float m = 0.f;
   for (int it = 0; it < iters; it++) {
-    const size_t p = (size_t)it * n + i;
+    const size_t p = (size_t)i * iters + it;  // cell-major probe order (k_probe_points)
     float sg, c[3];
     cand_max(cand_rgb, cand_sigma, pt_off[p], pt_cnt[p], n_init, 0.f, true, sg, c);
     m = fmaxf(m, sg);
