@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--spinup-ms", type=float, default=600.0, help="untimed GPU clock spin-up before the warm-up steps")
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying the captured HIP "
-                    "graph (eager is host-bound: 4.2-5.2 ms/frame depending on host jitter vs a stable 4.2 ms replayed)")
+                    "graph (eager: ~110 launches per frame from Python, a few hundred microseconds slower and jittery)")
     ap.add_argument("--train-steps", type=int, default=100, help="training iterations timed after the render loop (0 = skip)")
     return ap.parse_args()
 
