@@ -125,8 +125,8 @@ def main(argv=None):
             rgb, _, alpha, _ = renderer(seq.batch(i))
             img = torch.cat([rgb, alpha[..., None]], dim=-1)[0]
             frames.append((img.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())     # animate.py:109-113
-    bad = renderer.finish()
-    for i in range(len(frames) if bad else 0):  # frames whose loop needed more iterations than captured
+    renderer.finish()
+    for i in renderer.incomplete_calls:  # frames whose loop needed more iterations than the graph holds
         rgb, _, alpha, _ = model.render_image_fast(seq.batch(i), size)
         frames[i] = (torch.cat([rgb, alpha[..., None]], dim=-1)[0].clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
     for i, f in enumerate(frames):

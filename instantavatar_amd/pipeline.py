@@ -76,16 +76,20 @@ class GraphedRenderer:
         self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._ev = None
         self.incomplete = 0
+        self.calls = 0
+        self.incomplete_calls = []   # indices (0-based call numbers) of the frames that must be re-rendered
 
     def _check_previous(self):
         if self._ev is not None:
             self._ev.synchronize()
             if int(self._host[0]) > 0:
                 self.incomplete += 1
+                self.incomplete_calls.append(self.calls - 1)
             self._ev = None
 
     def __call__(self, batch):
         self._check_previous()
+        self.calls += 1
         for k in ("global_orient", "body_pose", "transl", "near", "far"):
             self.static[k].copy_(batch[k], non_blocking=True)
         self.graph.replay()
