@@ -69,7 +69,9 @@ class GraphedRenderer:
         self.graph = torch.cuda.CUDAGraph()
         r._graph_capture = True
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: other threads of the process (e.g. the RCCL watchdog of a multi-GPU job)
+            # may touch the runtime while this thread captures
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = model.render_image_fast(self.static, img_size)
         finally:
             r._graph_capture = False
