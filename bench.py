@@ -315,6 +315,9 @@ def main():
                          "35.7 G fetches/s with L1-resident cells, 23.8 G/s L2-resident, 11.0 G/s from the fabric"),
                 "fetches_per_s": ks["units"][1] / (ks["ms"] * 1e-3) if ks["ms"] > 0 else 0.0,
                 "fetch_pattern_ceiling_per_s": {"l1_resident": 35.7e9, "l2_resident": 23.8e9, "fabric": 11.0e9},
+                # the fraction that says something about the kernel: fetch rate vs the measured ceiling of its own
+                # access pattern with cache-resident cells (`frac` above exceeds 1 because nothing comes from HBM)
+                "frac_of_fetch_ceiling": (ks["units"][1] / (ks["ms"] * 1e-3) / 35.7e9) if ks["ms"] > 0 else 0.0,
                 "avg_launch_us": per_launch_ms * 1e3, "launches": k["launches"],
                 "algorithmic_bytes_per_launch": k["bytes"] / max(k["launches"], 1),
                 "other": {n: {"avg_launch_us": v["ms"] * 1e3 / max(v["launches"], 1), "launches": v["launches"],
