@@ -66,6 +66,9 @@ class AnimateSequence:
 def build_model(args, device):
     if args.synthetic:
         model, _, _ = build_synthetic_model(device)
+        if args.ckpt:  # synthetic body, trained weights (e.g. written by drivers.train --synthetic)
+            missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device)
+            print("checkpoint %s loaded (step %d)" % (args.ckpt, model.global_step))
         return model, np.zeros(10, np.float32)
     deformer, net, renderer = cfg.build_plugins(args.confs, args.deformer, args.network, args.renderer, gender=args.gender,
                                                 deformer_kwargs=dict(model_path=args.smpl_dir))

@@ -1,0 +1,88 @@
+"""`train.py` without Lightning / Hydra, for the part of it that lies on the hot path: the optimisation
+loop of DNeRFModel.training_step (DNeRF.py:112-161) over per-frame ray batches, with Lightning-layout
+checkpoints.  Real datasets (image loading, patch / edge samplers: SURVEY.md 8f rank 4) are not part
+of this package; the loop takes any iterable of batches with the reference's keys (`rays_o`, `rays_d`,
+`near`, `far`, `rgb`, `alpha`, `bg_color`, SMPL parameters).  `--synthetic` supplies one: targets rendered
+from the synthetic field, 4 096 random rays of a random frame per step (what bench.py times).
+
+    python -m instantavatar_amd.drivers.train --synthetic --steps 200 --ckpt /tmp/avatar/last.ckpt
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+from .. import synthetic
+from ..pipeline import build_synthetic_model, make_batch
+from ..training import NeRFLoss, configure_optimizer, training_step
+from . import checkpoint as ckpt_io
+
+
+def synthetic_batches(device, teacher, res=256, n_frames=8, n_rays=4096, seed=1234):
+    """Endless iterator of training batches: frames rendered once by `teacher`, random rays per step."""
+    poses, tr = synthetic.procedural_pose_track(max(n_frames, 8))
+    targets = []
+    with torch.no_grad():
+        for f in range(n_frames):
+            b = make_batch(device, res, poses[f], tr[f])
+            rgb, _, alpha, _ = teacher.render_image_fast(b, (res, res))
+            targets.append((b, rgb.reshape(1, -1, 3), alpha.reshape(1, -1)))
+    g = torch.Generator(device=device).manual_seed(seed)
+    i = 0
+    while True:
+        b, rgb, alpha = targets[i % n_frames]
+        sel = torch.randint(0, res * res, (n_rays,), device=device, generator=g)
+        batch = dict(b)
+        for k in ("rays_o", "rays_d", "near", "far"):
+            batch[k] = b[k][:, sel]
+        batch["rgb"], batch["alpha"] = rgb[:, sel], alpha[:, sel]
+        batch["bg_color"] = torch.ones_like(batch["rgb"])
+        yield batch
+        i += 1
+
+
+def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout):
+    """`steps` iterations of training_step; returns the last losses (device tensors)."""
+    optimizer = optimizer or configure_optimizer(model)
+    loss_fn = loss_fn or NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+    model.train()
+    t0 = time.perf_counter()
+    losses = None
+    for it, batch in zip(range(steps), batches):
+        losses = training_step(model, batch, optimizer, loss_fn)
+        if log_every and (it + 1) % log_every == 0:
+            torch.cuda.synchronize()
+            print("step %d  loss %.5f  mse %.5f  %.0f it/s" % (model.global_step, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
+                                                               (it + 1) / (time.perf_counter() - t0)), file=out)
+    return losses, optimizer
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--synthetic", action="store_true", required=True,
+                    help="synthetic SMPL-like body and targets (the only data source shipped with this package)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--ckpt", default="checkpoints/last.ckpt")
+    ap.add_argument("--resume", action="store_true")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("train: needs a GPU (the product path has no CPU fallback)")
+    device = torch.device("cuda", 0)
+    teacher, _, _ = build_synthetic_model(device)
+    model, _, _ = build_synthetic_model(device)
+    model.net_coarse.reset_parameters()
+    if args.resume and os.path.exists(args.ckpt):
+        ckpt_io.load_checkpoint(model, args.ckpt, map_location=device)
+        print("resumed from %s at step %d" % (args.ckpt, model.global_step))
+    losses, opt = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps)
+    os.makedirs(os.path.dirname(os.path.abspath(args.ckpt)), exist_ok=True)
+    ckpt_io.save_checkpoint(model, args.ckpt, optimizer=opt)
+    print("saved %s (step %d, mse %.5f)" % (args.ckpt, model.global_step, float(losses["mse_loss"])))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
