@@ -211,7 +211,16 @@ def main():
     if not args.no_graph:
         try:
             from instantavatar_amd.pipeline import GraphedRenderer
-            graphed = GraphedRenderer(model, batches[0], (res, res))
+            # iteration count of the wave-front loop measured on 12 poses spread over this rank's frames
+            probes = []
+            for j in range(12):
+                f = my[(j * max(n_total // 12, 1)) % n_total] % len(poses)
+                pb = dict(batches[0])
+                d = float(np.sqrt((tr[f] ** 2).sum()))
+                pb["global_orient"], pb["body_pose"], pb["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
+                pb["near"], pb["far"] = torch.full_like(batches[0]["near"], d - 1), torch.full_like(batches[0]["far"], d + 1)
+                probes.append(pb)
+            graphed = GraphedRenderer(model, batches[0], (res, res), margin=2, probe_batches=probes)
 
             def frame(i):  # noqa: F811  (same work, replayed from the captured HIP graph)
                 f = my[i] % len(poses)

@@ -325,8 +325,9 @@ int ia_density_grid_init(const float *jitter, int iters, int G,
  * max(min(MAX_BATCH // n_alive, MAX_SAMPLES), 1), computed on device; alive
  * compaction by ballot/prefix sum; no host synchronisation: `n_iters` loop
  * iterations are enqueued and iterations with no alive ray exit immediately.
- * n_alive_out (DEVICE int32[1]) holds the alive count after the last enqueued
- * iteration (0 = frame complete; >0 = call again with resume = 1).
+ * n_alive_out (DEVICE int32[2]) holds [0] the alive count after the last enqueued
+ * iteration (0 = frame complete; >0 = call again with resume = 1) and [1] the number of
+ * iterations that had rays to process so far.
  * rays_o/rays_d: [R,3] (SMPL-root frame, after transform_rays_w2s), near/far
  * [R].  aabb: DEVICE [6] occupancy aabb.  bg: [R,3] or NULL (white).
  * Outputs: rgb [R,3], depth [R], alpha [R], counter [R].                     */

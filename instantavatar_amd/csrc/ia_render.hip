@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_render_finalize(int R, const float *__r
 __global__ void k_render_report(RenderState *st, int max_samples, int32_t *n_alive_out) {
   int na = st->n_alive_next;
   if (st->k >= max_samples) na = 0;
-  if (n_alive_out) *n_alive_out = na;
+  if (n_alive_out) { n_alive_out[0] = na; n_alive_out[1] = st->iters; }  // [1]: iterations that had rays to process
 }
 
 // ---------------------------------------------------------------------------

@@ -56,14 +56,20 @@ class GraphedRenderer:
     (`incomplete` counts frames whose loop would have continued; they must be re-rendered
     through `model.render_image_fast`).  `sync_check=True` checks before returning."""
 
-    def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False):
+    def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False, probe_batches=()):
+        """probe_batches: further batches (other poses of the sequence) rendered once eagerly to measure
+        how many wave-front iterations the sequence needs; with a representative sample a small
+        `margin` is enough (every idle iteration costs six empty launches per frame)."""
         self.model, self.img_size, self.sync_check = model, img_size, sync_check
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         r = model.renderer
         need = 0
+        for b in probe_batches:
+            model.render_image_fast(b, img_size)
+            need = max(need, r.iters_executed())
         for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration count
             model.render_image_fast(self.static, img_size)
-            need = max(need, r.last_iters)
+            need = max(need, r.iters_executed())
         r._iters_hint = need + margin + ((need + margin) & 1)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -95,7 +101,7 @@ class GraphedRenderer:
         for k in ("global_orient", "body_pose", "transl", "near", "far"):
             self.static[k].copy_(batch[k], non_blocking=True)
         self.graph.replay()
-        self._host.copy_(self.model.renderer._n_alive_dev, non_blocking=True)
+        self._host.copy_(self.model.renderer._n_alive_dev[:1], non_blocking=True)
         self._ev = torch.cuda.Event()
         self._ev.record()
         if self.sync_check:

@@ -170,7 +170,7 @@ class Raymarcher(torch.nn.Module):
         need = L.ia_render_workspace_bytes(R, self.MAX_BATCH_SIZE, k)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
-            self._n_alive_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._n_alive_dev = torch.zeros(2, dtype=torch.int32, device=dev)  # [alive after the last iteration, iterations executed]
         rgb = torch.empty((R, 3), device=dev)
         depth, alpha, counter = torch.empty(R, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
         bg = bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None
@@ -192,7 +192,7 @@ class Raymarcher(torch.nn.Module):
         launch(total, 0)
         if sync and not getattr(self, "_graph_capture", False):
             # one device->host read per frame (4 bytes) to validate the hint
-            while int(self._n_alive_dev.item()) > 0 and total < 2 * self.MAX_SAMPLES:
+            while int(self._n_alive_dev[0].item()) > 0 and total < 2 * self.MAX_SAMPLES:
                 launch(4, 1)
                 total += 4
                 self._iters_hint = total
@@ -327,6 +327,10 @@ class Raymarcher(torch.nn.Module):
         if self.last_train_counts[1] > self._tc_cap:
             self.train_overflow += 1
             self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_train_counts[1])
+
+    def iters_executed(self):
+        """Wave-front iterations of the last fused test render that had rays to process (host read)."""
+        return int(self._n_alive_dev[1].item())
 
     def _occ_desc_cached(self, grid):
         key = id(grid.aabb)
