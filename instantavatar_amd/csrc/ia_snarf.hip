@@ -4,7 +4,7 @@
 //   k_precompute    a3     blended 3x4 transforms per skinning voxel, written
 //                          channel-LAST so a trilinear corner is 48 contiguous B
 //   k_search        a4+a5  Broyden root finding with lane refill (a workgroup owns
-//                          128 points x n_init solves as an LDS queue), duplicate
+//                          64 points x n_init solves as an LDS queue), duplicate
 //                          filter and ballot/prefix-sum compaction of the roots
 //
 // Reference semantics: fast_snarf/cuda/precompute/precompute.cu:24-71,
