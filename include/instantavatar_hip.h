@@ -180,6 +180,19 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
                             int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand,
                             int zero_counter, void *stream);
 
+/* ---- a7: implicit differentiation of the roots ----------------------------------------
+ * Backward of ForwardDeformer.forward's training branch (deformer_torch.py:50-67 with
+ * forward_skinning :118-128 and query_weights :190-202): x_c <- x_c* - J_inv (d(x_c*) - sg[d(x_c*)])
+ * has the value x_c* and the gradient dL/dtfs[n][c][k] = w_n(x_c*) v_c h_k, v = -J_inv^T dL/dx_c,
+ * h = (x_c*, 1), w = trilinear sample (align_corners, border padding) of the skinning-weight volume
+ * voxel_w [24,D,H,W].  xc, grad_xc: [n,3]; J_inv: [n,3,3]; valid: [n]; d_tfs [24,4,4] is ACCUMULATED
+ * (rows 0..2).  Per-workgroup partial sums in ws, added in a fixed order.                       */
+size_t ia_snarf_implicit_bwd_workspace_bytes(long n);
+int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *valid,
+                          const float *grad_xc, long n, const float *voxel_w,
+                          const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes,
+                          void *stream);
+
 /* ---- a9 + a10 + a11: canonical field ---------------------------------------
  * Replaces NeRFNGPNet.forward (ngp.py:73-83) = tcnn NetworkWithInputEncoding
  * (HashGrid -> FullyFusedMLP 32-64-16) + tcnn Network (16-64-64-16, sigmoid).

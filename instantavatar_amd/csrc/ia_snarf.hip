@@ -608,3 +608,122 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
   IA_LAUNCH_CHECK("k_search<1>");
   return IA_OK;
 }
+
+// ---------------------------------------------------------------------------
+// a7: implicit differentiation of the roots w.r.t. the bone transforms
+// (deformer_torch.py:50-67, forward_skinning :118-128, query_weights :190-202).
+//   x_c <- x_c* - J_inv (d(x_c*) - sg[d(x_c*)]),   d(x) = sum_n w_n(x) (R_n x + t_n)
+// has the value x_c* and the gradient  dL/dT_n[c][k] = w_n(x_c*) v_c h_k  with
+// v = -J_inv^T dL/dx_c and h = (x_c*, 1).  The reference builds it from a 24-channel grid_sample
+// (align_corners, border padding), an einsum, two batched mat-vecs and their autograd; here one
+// kernel gathers the 8 x 24 skinning weights of every valid candidate, forms the 24 x 12 outer
+// products in LDS and reduces them per workgroup (per-workgroup partials, added in a fixed order).
+// ---------------------------------------------------------------------------
+#define IA_ID_THREADS 256
+
+__device__ __forceinline__ float id_border_index(float g, int size) {
+  float c = ((g + 1.f) / 2) * (size - 1);          // align_corners = true
+  c = fminf(fmaxf(c, 0.f), (float)(size - 1));      // padding_mode = "border"
+  return c;
+}
+
+__global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
+    const float *__restrict__ xc, const float *__restrict__ J_inv, const uint8_t *__restrict__ valid,
+    const float *__restrict__ grad, long n, const float *__restrict__ voxel_w, SnarfGridDev g,
+    float *__restrict__ partial) {
+  __shared__ float s_w[IA_ID_THREADS][25];   // +1: the 24-float rows start in different banks
+  __shared__ float s_vh[IA_ID_THREADS][13];
+  const int tid = threadIdx.x;
+  const long vol = (long)g.D * g.H * g.W;
+  float acc0 = 0.f, acc1 = 0.f;              // outputs tid and tid + 256 of the 288 (bone, row, col) sums
+  for (long base = (long)blockIdx.x * IA_ID_THREADS; base < n; base += (long)gridDim.x * IA_ID_THREADS) {
+    const long i = base + tid;
+    const bool ok = i < n && valid[i];
+    float w[24], vh[12];
+#pragma unroll
+    for (int k = 0; k < 24; k++) w[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; k++) vh[k] = 0.f;
+    if (ok) {
+      const float x0 = xc[i * 3], x1 = xc[i * 3 + 1], x2 = xc[i * 3 + 2];
+      const float g0 = grad[i * 3], g1 = grad[i * 3 + 1], g2 = grad[i * 3 + 2];
+      const float *Ji = J_inv + i * 9;
+      const float v[3] = {-(Ji[0] * g0 + Ji[3] * g1 + Ji[6] * g2), -(Ji[1] * g0 + Ji[4] * g1 + Ji[7] * g2),
+                          -(Ji[2] * g0 + Ji[5] * g1 + Ji[8] * g2)};
+      const float h[4] = {x0, x1, x2, 1.f};
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) vh[c * 4 + k] = v[c] * h[k];
+      const float ix = id_border_index(g.scl[0] * (x0 + g.off[0]), g.W);
+      const float iy = id_border_index(g.scl[1] * (x1 + g.off[1]), g.H);
+      const float iz = id_border_index(g.scl[2] * (x2 + g.off[2]), g.D);
+      const int xa = (int)floorf(ix), ya = (int)floorf(iy), za = (int)floorf(iz);
+      const float fx = ix - xa, fy = iy - ya, fz = iz - za;
+#pragma unroll
+      for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+        for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+          for (int cx = 0; cx < 2; cx++) {
+            const int xx = xa + cx, yy = ya + cy, zz = za + cz;
+            if (xx >= g.W || yy >= g.H || zz >= g.D) continue;  // only at the clamped border, weight 0
+            const float wt = (cx ? fx : 1.f - fx) * (cy ? fy : 1.f - fy) * (cz ? fz : 1.f - fz);
+            const float *p = voxel_w + ((long)zz * g.H + yy) * g.W + xx;
+#pragma unroll
+            for (int k = 0; k < 24; k++) w[k] = __builtin_fmaf(wt, p[(long)k * vol], w[k]);
+          }
+    }
+    __syncthreads();  // previous tile consumed
+#pragma unroll
+    for (int k = 0; k < 24; k++) s_w[tid][k] = w[k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s_vh[tid][k] = vh[k];
+    __syncthreads();
+    {
+      const int o0 = tid, o1 = tid + IA_ID_THREADS;  // output o = bone * 12 + (row * 4 + col)
+      const int n0 = o0 / 12, q0 = o0 - n0 * 12, n1 = o1 / 12, q1 = o1 - n1 * 12;
+      float a0 = 0.f, a1 = 0.f;
+      for (int c = 0; c < IA_ID_THREADS; c++) {
+        a0 = __builtin_fmaf(s_w[c][n0], s_vh[c][q0], a0);
+        if (o1 < 288) a1 = __builtin_fmaf(s_w[c][n1], s_vh[c][q1], a1);
+      }
+      acc0 += a0; acc1 += a1;
+    }
+  }
+  partial[(size_t)blockIdx.x * 288 + tid] = acc0;
+  if (tid + IA_ID_THREADS < 288) partial[(size_t)blockIdx.x * 288 + tid + IA_ID_THREADS] = acc1;
+}
+
+__global__ __launch_bounds__(288) void k_implicit_bwd_reduce(const float *__restrict__ partial, int n_blocks,
+                                                             float *__restrict__ d_tfs) {
+  const int o = threadIdx.x;  // bone * 12 + row * 4 + col
+  float acc = 0.f;
+  for (int b = 0; b < n_blocks; b++) acc += partial[(size_t)b * 288 + o];
+  const int bone = o / 12, q = o - bone * 12;
+  d_tfs[bone * 16 + q] += acc;  // rows 0..2 of the 4x4; row 3 has no gradient
+}
+
+static int ia_implicit_blocks(long n) {
+  long b = (n + IA_ID_THREADS - 1) / IA_ID_THREADS;
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" size_t ia_snarf_implicit_bwd_workspace_bytes(long n) { return (size_t)ia_implicit_blocks(n) * 288 * sizeof(float); }
+
+extern "C" int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *valid, const float *grad_xc,
+                                     long n, const float *voxel_w, const ia_snarf_grid *grid, float *d_tfs, void *ws,
+                                     size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(n >= 0, "ia_snarf_implicit_bwd: n < 0");
+  if (n == 0) return IA_OK;
+  IA_CHECK_ARG(xc && J_inv && valid && grad_xc && voxel_w && grid && d_tfs && ws, "ia_snarf_implicit_bwd: null pointer");
+  if (ws_bytes < ia_snarf_implicit_bwd_workspace_bytes(n)) return ia_set_error(IA_ERR_WORKSPACE, "ia_snarf_implicit_bwd: workspace too small");
+  const int blocks = ia_implicit_blocks(n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_implicit_bwd, dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, voxel_w,
+                     ia_make_grid_dev(grid), static_cast<float *>(ws));
+  hipLaunchKernelGGL(k_implicit_bwd_reduce, dim3(1), dim3(288), 0, s, static_cast<const float *>(ws), blocks, d_tfs);
+  IA_LAUNCH_CHECK("k_implicit_bwd");
+  return IA_OK;
+}

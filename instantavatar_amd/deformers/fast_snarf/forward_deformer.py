@@ -138,10 +138,13 @@ class ForwardDeformer(torch.nn.Module):
         xc = xc.detach()  # invalid slots are already zero (ia_snarf_search writes them)
         if need_grad:
             # xc + 0 with d(xc) = -J_inv . d(skin(xc)): value unchanged, gradient to tfs
-            skinned = self.forward_skinning(xc, cond, tfs, mask=mask)
-            delta = skinned - skinned.detach()
-            xc = xc.clone()
-            xc[mask] = xc[mask] + bmv(-others["J_inv"][mask], delta.unsqueeze(-1)).squeeze(-1)
+            if FUSED_IMPLICIT_DIFF and xc.is_cuda and tfs.shape[0] == 1:
+                xc = _ImplicitDiffFn.apply(tfs, xc, others["J_inv"], mask, self)
+            else:
+                skinned = self.forward_skinning(xc, cond, tfs, mask=mask)
+                delta = skinned - skinned.detach()
+                xc = xc.clone()
+                xc[mask] = xc[mask] + bmv(-others["J_inv"][mask], delta.unsqueeze(-1)).squeeze(-1)
         return xc, others
 
     def forward_skinning(self, xc, cond, tfs, mask=None):
@@ -153,6 +156,39 @@ class ForwardDeformer(torch.nn.Module):
         g = self.normalize(xc.reshape(1, -1, 3))[:, :, None, None]
         w = F.grid_sample(self.lbs_voxel_final, g, align_corners=True, mode=mode, padding_mode="border")
         return w[0, :, :, 0, 0].T.reshape(*lead, -1)
+
+
+#: a7 through the HIP kernel `ia_snarf_implicit_bwd`; False = the reference's torch-op formulation
+#: (grid_sample + einsum + batched mat-vec under autograd), kept as the checker of the kernel
+FUSED_IMPLICIT_DIFF = True
+
+
+class _ImplicitDiffFn(torch.autograd.Function):
+    """x_c* with the gradient of  x_c* - J_inv (d(x_c*) - sg[d(x_c*)])  w.r.t. the bone transforms."""
+
+    @staticmethod
+    def forward(ctx, tfs, xc, J_inv, mask, deformer):
+        ctx.deformer = deformer
+        ctx.save_for_backward(xc, J_inv, mask)
+        ctx.tfs_shape = tfs.shape
+        return xc.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, J_inv, mask = ctx.saved_tensors
+        d = ctx.deformer
+        L = _lib.lib()
+        n = mask.numel()
+        x = xc.reshape(-1, 3).float().contiguous()
+        J = J_inv.reshape(-1, 9).float().contiguous()
+        m = mask.reshape(-1).to(torch.uint8).contiguous()
+        gg = g.reshape(-1, 3).float().contiguous()
+        d_tfs = torch.zeros(ctx.tfs_shape, device=x.device)
+        ws = torch.empty(int(L.ia_snarf_implicit_bwd_workspace_bytes(n)), dtype=torch.uint8, device=x.device)
+        _lib.check(L.ia_snarf_implicit_bwd(_lib.ptr(x), _lib.ptr(J), _lib.ptr(m), _lib.ptr(gg), n,
+                                           _lib.ptr(d.lbs_voxel_final), C.byref(d.grid_desc()), _lib.ptr(d_tfs),
+                                           _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_implicit_bwd")
+        return d_tfs, None, None, None, None
 
 
 def skinning_mask(x, w, tfs, inverse=False):

@@ -309,3 +309,36 @@ def test_implicit_differentiation_of_roots_wrt_pose(gw):
     an = grad.reshape(-1)[idx].cpu()
     cos = float((fd * an).sum() / (fd.norm() * an.norm()))
     assert cos > 0.98, (cos, fd, an)
+
+
+def test_implicit_diff_kernel_equals_torch_formulation(gw):
+    """ia_snarf_implicit_bwd against the reference's formulation of a7 (grid_sample with border
+    padding + einsum + batched mat-vec under autograd): same gradient w.r.t. the bone transforms."""
+    from instantavatar_amd.deformers.fast_snarf import forward_deformer as fd
+    model = gw[0]
+    dfm = model.deformer
+    poses, tr = W.poses()
+    base = make_batch(DEV, 16, poses[2], tr[2])
+    dfm.prepare_deformer(base)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    vd = dfm.deformer.voxel_d[0].reshape(3, -1)
+    sel = torch.randint(0, vd.shape[1], (5000,), device=DEV, generator=g)
+    pts = (vd[:, sel].T + 0.01 * torch.randn((5000, 3), device=DEV, generator=g)).contiguous()
+    pts[:50] += 5.0   # far outside: no roots, and border-clamped weight samples must not matter
+    r = torch.randn((5000, 13, 3), device=DEV, generator=g)
+    grads = []
+    for fused in (True, False):
+        fd.FUSED_IMPLICIT_DIFF = fused
+        try:
+            tfs = dfm.tfs.detach().clone().requires_grad_(True)
+            xc, others = dfm.deformer.forward(pts[None], None, tfs, eval_mode=False)
+            valid = others["valid_ids"]
+            assert valid.float().mean() > 0.05
+            ((xc * r[None])[valid]).sum().backward()
+            grads.append(tfs.grad.clone())
+        finally:
+            fd.FUSED_IMPLICIT_DIFF = True
+    a, b = grads
+    assert torch.isfinite(a).all() and b.abs().max() > 0
+    assert (a[..., 3, :] == 0).all()
+    assert (a - b).norm() / b.norm() < 1e-4, float((a - b).norm() / b.norm())
