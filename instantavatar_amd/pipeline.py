@@ -52,9 +52,10 @@ class GraphedRenderer:
     far are copied into static buffers and the graph is replayed.  The wave-front loop's
     length is data dependent; the graph holds `margin` more iterations than the warm-up
     frames needed (idle iterations are a few empty launches) and the device-side alive
-    counter of every frame is copied to pinned host memory and checked one call later
-    (`incomplete` counts frames whose loop would have continued; they must be re-rendered
-    through `model.render_image_fast`).  `sync_check=True` checks before returning."""
+    counter of every frame is copied to pinned host memory and inspected a few calls later without
+    blocking (`incomplete` counts frames whose loop would have continued, `incomplete_calls` lists
+    them; they must be re-rendered through `model.render_image_fast`).  `sync_check=True` checks
+    before returning."""
 
     def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False, probe_batches=()):
         """probe_batches: further batches (other poses of the sequence) rendered once eagerly to measure
@@ -81,35 +82,45 @@ class GraphedRenderer:
                 self.out = model.render_image_fast(self.static, img_size)
         finally:
             r._graph_capture = False
-        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._ev = None
+        # deferred alive check: a ring of pinned slots, polled without blocking -- the host may run up
+        # to DEPTH frames ahead of the GPU (blocking on the previous frame before launching the next
+        # one would leave the GPU idle for the host's wake-up + enqueue time every frame)
+        self.DEPTH = 4
+        self._host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
+        self._pending = []           # [(event, slot, call index)], oldest first
         self.incomplete = 0
         self.calls = 0
         self.incomplete_calls = []   # indices (0-based call numbers) of the frames that must be re-rendered
 
-    def _check_previous(self):
-        if self._ev is not None:
-            self._ev.synchronize()
-            if int(self._host[0]) > 0:
+    def _poll(self, block_all=False):
+        while self._pending:
+            ev, slot, call = self._pending[0]
+            if not ev.query():
+                if not block_all and len(self._pending) < self.DEPTH:
+                    return
+                ev.synchronize()
+            if int(self._host[slot]) > 0:
                 self.incomplete += 1
-                self.incomplete_calls.append(self.calls - 1)
-            self._ev = None
+                self.incomplete_calls.append(call)
+            self._pending.pop(0)
 
     def __call__(self, batch):
-        self._check_previous()
-        self.calls += 1
+        self._poll()
+        slot = self.calls % self.DEPTH
         for k in ("global_orient", "body_pose", "transl", "near", "far"):
             self.static[k].copy_(batch[k], non_blocking=True)
         self.graph.replay()
-        self._host.copy_(self.model.renderer._n_alive_dev[:1], non_blocking=True)
-        self._ev = torch.cuda.Event()
-        self._ev.record()
+        self._host[slot:slot + 1].copy_(self.model.renderer._n_alive_dev[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((ev, slot, self.calls))
+        self.calls += 1
         if self.sync_check:
-            self._check_previous()
+            self._poll(block_all=True)
         return self.out
 
     def finish(self):
-        self._check_previous()
+        self._poll(block_all=True)
         return self.incomplete
 
 
