@@ -401,3 +401,39 @@ def smpl_deform_query(pts, prep, field, eval_mode=True, threshold=0.05):
             rgb[bad] = 0
             sigma[bad] = -1e5
     return rgb, sigma
+
+
+# ---- a7: implicit differentiation of the roots (deformer_torch.py:50-67,118-128,190-202) ----------
+def query_weights(init, xc):
+    """ForwardDeformer.query_weights: trilinear sample of lbs_voxel_final [24,D,H,W] at xc [n,3] with
+    grid_sample(align_corners=True, padding_mode="border") semantics -> [n,24]."""
+    vol = init["lbs_voxel"]
+    _, D, H, W = vol.shape
+    g = (_f32(xc) + init["offset_kernel"]) * init["scale_kernel"]          # normalised coordinates
+    out = np.zeros((len(g), 24), np.float32)
+    idx = [np.clip((g[:, a] + 1) / 2 * (n - 1), 0, n - 1) for a, n in ((0, W), (1, H), (2, D))]
+    base = [np.floor(i).astype(np.int64) for i in idx]
+    frac = [(i - b).astype(np.float32) for i, b in zip(idx, base)]
+    for cz in (0, 1):
+        for cy in (0, 1):
+            for cx in (0, 1):
+                xx, yy, zz = base[0] + cx, base[1] + cy, base[2] + cz
+                ok = (xx < W) & (yy < H) & (zz < D)
+                wt = ((frac[0] if cx else 1 - frac[0]) * (frac[1] if cy else 1 - frac[1]) * (frac[2] if cz else 1 - frac[2]))
+                xx, yy, zz = np.minimum(xx, W - 1), np.minimum(yy, H - 1), np.minimum(zz, D - 1)
+                out += (wt * ok)[:, None] * vol[:, zz, yy, xx].T
+    return out
+
+
+def implicit_diff_grad(init, xc, J_inv, valid, grad_xc):
+    """dL/dtfs [24,4,4] of  x_c* - J_inv (d(x_c*) - sg[d(x_c*)]),  d(x) = sum_n w_n(x) (R_n x + t_n):
+    dL/dT_n[c][k] = sum_valid w_n v_c h_k,  v = -J_inv^T dL/dx_c,  h = (x_c*, 1)."""
+    xc, g = _f32(xc).reshape(-1, 3), _f32(grad_xc).reshape(-1, 3)
+    J = _f32(J_inv).reshape(-1, 3, 3)
+    m = np.asarray(valid).reshape(-1).astype(bool)
+    w = query_weights(init, xc[m]).astype(np.float64)
+    v = -np.einsum("prc,pr->pc", J[m].astype(np.float64), g[m].astype(np.float64))
+    h = np.concatenate([xc[m], np.ones((m.sum(), 1), np.float32)], 1).astype(np.float64)
+    out = np.zeros((24, 4, 4), np.float64)
+    out[:, :3, :] = np.einsum("pn,pc,pk->nck", w, v, h)
+    return out.astype(np.float32)

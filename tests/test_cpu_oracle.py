@@ -256,3 +256,37 @@ def test_driver_config_and_checkpoint_io(tmp_path):
     torch.save(sd, path)
     with pytest.raises(ValueError):
         ck.load_checkpoint(model2, path)
+
+
+def test_implicit_differentiation_formula_vs_finite_differences(oracle, small_world):
+    """Row a7 on the CPU: the closed-form gradient of the implicitly differentiated roots w.r.t. the
+    bone transforms (oracle.implicit_diff_grad) against central finite differences of the Broyden
+    roots themselves under a perturbation of tfs (the voxel transforms are rebuilt for every probe)."""
+    body, init, fp, world = small_world
+    tfs, vJ, vd = world["tfs"], world["voxel_J"], world["voxel_d"]
+    rng = np.random.RandomState(3)
+    v = vd.reshape(3, -1)
+    sel = rng.randint(0, v.shape[1], 1500)
+    xd = (v[:, sel].T + 0.005 * rng.randn(1500, 3)).astype(np.float32)
+    x, Jinv, valid = oracle.broyden(xd, vJ, tfs, init, syn.INIT_BONES)
+    valid = valid.astype(bool)
+    r = rng.randn(*x.shape).astype(np.float32)
+    grad = oracle.implicit_diff_grad(init, x, Jinv, valid, r)
+    assert valid.mean() > 0.05 and np.isfinite(grad).all()
+    # finite differences on the entries with the largest analytic gradient
+    flat = np.abs(grad[:, :3, :]).reshape(-1)
+    fd, an = [], []
+    for o in np.argsort(-flat)[:5]:
+        n, c, k = o // 12, (o % 12) // 4, o % 4
+        vals = []
+        for sgn in (+1, -1):
+            t2 = tfs.copy()
+            t2[n, c, k] += sgn * 2e-3
+            vJ2, _ = oracle.precompute(init, t2)
+            x2, _, v2 = oracle.broyden(xd, vJ2, t2, init, syn.INIT_BONES)
+            vals.append((x2, v2.astype(bool)))
+        both = valid & vals[0][1] & vals[1][1]
+        fd.append((((vals[0][0] - vals[1][0]) * r)[both].sum() / 4e-3))
+        an.append(oracle.implicit_diff_grad(init, x, Jinv, both, r)[n, c, k])
+    fd, an = np.array(fd), np.array(an)
+    assert float((fd * an).sum() / (np.linalg.norm(fd) * np.linalg.norm(an))) > 0.98, (fd, an)

@@ -342,3 +342,36 @@ def test_implicit_diff_kernel_equals_torch_formulation(gw):
     assert torch.isfinite(a).all() and b.abs().max() > 0
     assert (a[..., 3, :] == 0).all()
     assert (a - b).norm() / b.norm() < 1e-4, float((a - b).norm() / b.norm())
+
+
+def test_implicit_diff_kernel_matches_oracle(oracle, gw):
+    """ia_snarf_implicit_bwd against the CPU restatement of a7 (oracle.implicit_diff_grad) on the
+    same roots, Broyden J_inv, validity mask and incoming gradient."""
+    import ctypes as C
+    from instantavatar_amd import _lib
+    model = gw[0]
+    dfm = model.deformer
+    poses, tr = W.poses()
+    dfm.prepare_deformer(make_batch(DEV, 16, poses[1], tr[1]))
+    fd = dfm.deformer
+    g = torch.Generator(device=DEV).manual_seed(8)
+    vd = fd.voxel_d[0].reshape(3, -1)
+    sel = torch.randint(0, vd.shape[1], (4000,), device=DEV, generator=g)
+    pts = (vd[:, sel].T + 0.01 * torch.randn((4000, 3), device=DEV, generator=g)).contiguous()
+    xc, others = fd.search(pts[None], None, dfm.tfs, eval_mode=True, want_J_inv=True)
+    valid, J_inv = others["valid_ids"], others["J_inv"]
+    r = torch.randn(xc.shape, device=DEV, generator=g)
+    L = _lib.lib()
+    n = valid.numel()
+    d_tfs = torch.zeros((24, 4, 4), device=DEV)
+    ws = torch.empty(int(L.ia_snarf_implicit_bwd_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    x_, J_, m_, r_ = xc.reshape(-1, 3).contiguous(), J_inv.reshape(-1, 9).contiguous(), valid.reshape(-1).to(torch.uint8), r.reshape(-1, 3).contiguous()
+    _lib.check(L.ia_snarf_implicit_bwd(_lib.ptr(x_), _lib.ptr(J_), _lib.ptr(m_), _lib.ptr(r_), n, _lib.ptr(fd.lbs_voxel_final),
+                                       C.byref(fd.grid_desc()), _lib.ptr(d_tfs), _lib.ptr(ws), ws.numel(), _lib.stream()),
+               "ia_snarf_implicit_bwd")
+    init = dict(lbs_voxel=fd.lbs_voxel_final[0].cpu().numpy(), offset_kernel=fd.offset_kernel.reshape(3).cpu().numpy(),
+                scale_kernel=fd.scale_kernel.reshape(3).cpu().numpy())
+    ref = oracle.implicit_diff_grad(init, x_.cpu().numpy(), J_.cpu().numpy(), m_.cpu().numpy(), r_.cpu().numpy())
+    got = d_tfs.cpu().numpy()
+    assert valid.float().mean() > 0.05 and np.abs(ref).max() > 1
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-4
