@@ -5,7 +5,8 @@ body.  Run in the build container only (needs /root/reference):
     python tests/golden/make_lbs_golden.py
 
 The fixture pins oracle.smpl_forward / batch_rodrigues / batch_rigid_transform
-("LBS: call lbs.py directly").
+("LBS: call lbs.py directly"), including the per-vertex transforms T and the
+shape / pose offsets the SMPLDeformer plugin consumes (smpl_deformer.py:36-45,66-75).
 """
 import importlib.util
 import sys as _sys
@@ -56,6 +57,8 @@ def main():
         verts, joints, A, T, so, po = lbs_mod.lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, w)
         # SMPL.forward folds transl (body_models.py:353-360)
         A2 = A.clone(); A2[..., :3, 3] += transl.unsqueeze(1)
+        T2 = T.clone(); T2[..., :3, 3] += transl.unsqueeze(1)
+        cases.update({"T%d" % i: T2.numpy(), "shape_offsets%d" % i: so.numpy(), "pose_offsets%d" % i: po.numpy()})
         cases.update({"betas%d" % i: betas.numpy(), "pose%d" % i: pose.numpy(), "transl%d" % i: transl.numpy(),
                       "verts%d" % i: (verts + transl.unsqueeze(1)).numpy(), "joints%d" % i: (joints + transl.unsqueeze(1)).numpy(),
                       "A%d" % i: A2.numpy(), "rot%d" % i: lbs_mod.batch_rodrigues(pose.view(-1, 3)).numpy()})

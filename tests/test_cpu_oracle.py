@@ -92,6 +92,9 @@ def test_lbs_oracle_matches_reference_golden(oracle):
         assert np.abs(out["vertices"] - g["verts%d" % i][0]).max() < 2e-5
         assert np.abs(out["joints"] - g["joints%d" % i][0]).max() < 2e-5
         assert np.abs(oracle.batch_rodrigues(pose.reshape(-1, 3)) - g["rot%d" % i]).max() < 1e-6
+        assert np.abs(out["T"] - g["T%d" % i][0]).max() < 2e-5                      # consumed by SMPLDeformer
+        assert np.abs(out["shape_offsets"] - g["shape_offsets%d" % i][0]).max() < 1e-6
+        assert np.abs(out["pose_offsets"] - g["pose_offsets%d" % i][0]).max() < 1e-6
 
 
 def test_lbs_product_torch_matches_reference_golden():
@@ -104,6 +107,9 @@ def test_lbs_product_torch_matches_reference_golden():
         out = smpl(torch.as_tensor(g["betas%d" % i]), pose[:, 3:], pose[:, :3], torch.as_tensor(g["transl%d" % i]))
         assert (out.A - torch.as_tensor(g["A%d" % i])).abs().max() < 2e-5
         assert (out.vertices - torch.as_tensor(g["verts%d" % i])).abs().max() < 2e-5
+        assert (out.T - torch.as_tensor(g["T%d" % i])).abs().max() < 2e-5
+        assert (out.shape_offsets - torch.as_tensor(g["shape_offsets%d" % i])).abs().max() < 1e-6
+        assert (out.pose_offsets - torch.as_tensor(g["pose_offsets%d" % i])).abs().max() < 1e-6
 
 
 # ---------------------------------------------------------------- oracle self-consistency
