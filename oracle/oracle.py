@@ -437,3 +437,38 @@ def implicit_diff_grad(init, xc, J_inv, valid, grad_xc):
     out = np.zeros((24, 4, 4), np.float64)
     out[:, :3, :] = np.einsum("pn,pc,pk->nck", w, v, h)
     return out.astype(np.float32)
+
+
+# ---- a15: Raymarcher.render_train (raymarcher_acc.py:140-186) + composite (:25-36) -----------------
+def render_train(o, d, near, far, occ, aabb, model, jitter, MAX_SAMPLES=256, bg=None, noise=None):
+    """One training render: fixed MAX_SAMPLES slots per ray (raymarch_train), z += jitter * step
+    (jitter [N,S] replaces torch.rand_like, :156), masked field evaluation (empty slots sigma = -1e3),
+    optional sigma noise [N,S], relu / cumprod compositing.  model(pts) -> (rgb, sigma) in training
+    mode.  Returns rgb [N,3], depth [N], alpha [N] (= sum of weights), weights [N,S]."""
+    L = lib()
+    o = _f32(o).reshape(-1, 3); d = _f32(d).reshape(-1, 3)
+    near = _f32(near).reshape(-1); far = _f32(far).reshape(-1)
+    N, S = len(o), MAX_SAMPLES
+    step = ((far - near) / np.float32(S)).astype(np.float32)
+    offset = _f32(aabb[0]); scale = _f32(aabb[1] - aabb[0])
+    G = occ.shape[0]
+    occ8 = np.ascontiguousarray(occ, np.uint8)
+    z = np.zeros((N, S), np.float32)
+    L.orc_raymarch_train(_p(o), _p(d), _p(near), _p(far), C.c_long(N), _p(occ8), G, _p(scale), _p(offset), _p(step), S, _p(z))
+    mask = z > 0
+    z = (z + _f32(jitter).reshape(N, S) * step[:, None]).astype(np.float32)
+    pts = (z[..., None] * d[:, None] + o[:, None]).astype(np.float32)
+    rgb = np.zeros((N, S, 3), np.float32)
+    sig = np.full((N, S), -1e3, np.float32)
+    if mask.any():
+        r, s_ = model(pts[mask])
+        rgb[mask], sig[mask] = r, s_
+    if noise is not None:
+        sig = sig + _f32(noise).reshape(N, S)
+    tau = np.maximum(sig, 0) * step[:, None]
+    alpha = (1.0 - np.exp(-tau)).astype(np.float32)
+    trans = np.cumprod(np.concatenate([np.ones((N, 1), np.float32), (1 - alpha + np.float32(1e-10))], 1), 1).astype(np.float32)
+    w = alpha * trans[:, :-1]
+    bgc = 1.0 if bg is None else _f32(bg).reshape(-1, 3)
+    color = (w[..., None] * rgb).sum(1) + trans[:, -1:] * bgc
+    return dict(rgb=color.astype(np.float32), depth=(w * z).sum(1), alpha=w.sum(1), weights=w, n_field=int(mask.sum()))

@@ -296,3 +296,23 @@ def test_implicit_differentiation_formula_vs_finite_differences(oracle, small_wo
         an.append(oracle.implicit_diff_grad(init, x, Jinv, both, r)[n, c, k])
     fd, an = np.array(fd), np.array(an)
     assert float((fd * an).sum() / (np.linalg.norm(fd) * np.linalg.norm(an))) > 0.98, (fd, an)
+
+
+def test_render_train_oracle_is_consistent(oracle, small_world):
+    """oracle.render_train (a15): weights of a ray sum to 1 - T_end, empty slots carry no weight, the
+    background term is linear, and a frame rendered with jitter 0.5 resembles the test-time render."""
+    body, init, fp, world = small_world
+    res = 24
+    ro, rd = syn.make_camera_rays(res)
+    jit = np.random.RandomState(7).rand(2, 64 ** 3, 3).astype(np.float32)
+    aabb, density, occ = oracle.density_grid_initialize(world, jit)
+    o, d, near, far = oracle.transform_rays_w2s(ro, rd, world["w2s"])
+    query = lambda p: oracle.deform_query(p, world, eval_mode=False)
+    half = np.full((len(o), 256), 0.5, np.float32)
+    a = oracle.render_train(o, d, near, far, occ, aabb, query, half)
+    b = oracle.render_train(o, d, near, far, occ, aabb, query, half, bg=np.zeros((len(o), 3), np.float32))
+    assert a["n_field"] > 200 and (a["alpha"] > 0.5).mean() > 0.02
+    assert np.abs(a["weights"].sum(1) - a["alpha"]).max() < 1e-6
+    assert np.abs((a["rgb"] - b["rgb"]) - (1 - a["alpha"])[:, None]).max() < 2e-5      # rgb = sum w c + T_end * bg
+    t = oracle.render_test(o, d, near, far, occ, aabb, lambda p: oracle.deform_query(p, world, True))
+    assert np.abs(a["alpha"] - t["alpha"]).mean() < 0.02

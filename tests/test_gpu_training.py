@@ -375,3 +375,44 @@ def test_implicit_diff_kernel_matches_oracle(oracle, gw):
     got = d_tfs.cpu().numpy()
     assert valid.float().mean() > 0.05 and np.abs(ref).max() > 1
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-4
+
+
+def test_train_render_matches_oracle(oracle, gw):
+    """Row a15 end to end: render_train over compact samples (march + jitter, candidate search, field,
+    wave-per-ray compositing) against oracle.render_train on the same rays, occupancy, jitter and
+    background: rgb / alpha within 1e-3, weights within 1e-3."""
+    from instantavatar_amd.models.structures.utils import Rays
+    model, body, fp, init = gw
+    poses, tr = W.poses()
+    res, i, n = 64, 2, 1024
+    batch = make_batch(DEV, res, poses[i], tr[i])
+    model.deformer.prepare_deformer(batch)
+    grid = model.renderer.density_grid_train
+    model.renderer.density_grid_test.initialize(model.deformer, model.net_coarse, iters=2)
+    G = 64
+    coords = (grid.coords + 0.5 / G) * (grid.aabb[1] - grid.aabb[0]) + grid.aabb[0]
+    with torch.no_grad():
+        _, dens = model.deformer(coords.reshape(-1, 3), model.net_coarse, True)
+    grid._postprocess(dens.reshape(G, G, G))
+    sel = torch.randperm(res * res, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))[:n]
+    rays = Rays(o=batch["rays_o"][:, sel].clone(), d=batch["rays_d"][:, sel].clone(), near=batch["near"][:, sel].clone(),
+                far=batch["far"][:, sel].clone())
+    model.deformer.transform_rays_w2s(rays)
+    bg = torch.rand((1, n, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    torch.manual_seed(11)
+    jitter = torch.rand((n, 256), device=DEV)          # the first (and, without noise, only) draw of the render
+    torch.manual_seed(11)
+    out = model.renderer.render_train_fused(rays, model.deformer, model.net_coarse, 0, bg)
+    ow = W.oracle_world(oracle, body, fp, init, poses[i], tr[i])
+    c = lambda t: t.detach().reshape(-1, t.shape[-1]).cpu().numpy() if t.dim() > 2 else t.detach().reshape(-1).cpu().numpy()
+    ref = oracle.render_train(c(rays.o), c(rays.d), c(rays.near), c(rays.far), grid.density_field.cpu().numpy(),
+                              grid.aabb.cpu().numpy(), lambda p: oracle.deform_query(p, ow, eval_mode=False),
+                              jitter.cpu().numpy(), bg=c(bg))
+    rgb = out["rgb_coarse"].detach().reshape(-1, 3).cpu().numpy()
+    alpha = out["alpha_coarse"].detach().reshape(-1).cpu().numpy()
+    w = out["weight_coarse"].detach().reshape(n, 256).cpu().numpy()
+    assert (ref["alpha"] > 0.5).mean() > 0.02 and ref["n_field"] > 1000
+    err_rgb, err_a, err_w = np.abs(rgb - ref["rgb"]).max(1), np.abs(alpha - ref["alpha"]), np.abs(w - ref["weights"]).max(1)
+    assert (err_rgb > 1e-3).mean() < 5e-3 and (err_a > 1e-3).mean() < 5e-3 and (err_w > 1e-3).mean() < 5e-3, \
+        ((err_rgb > 1e-3).mean(), (err_a > 1e-3).mean(), (err_w > 1e-3).mean(), err_rgb.max())
+    assert np.median(err_rgb) < 1e-4
