@@ -236,6 +236,12 @@ int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb,
  * (tcnn kernel_grid_backward_input), needed when SMPL poses are optimised.   */
 int ia_hashgrid_bwd(const float *x, int V, const int32_t *n_dev, const ia_field *field,
                     const float *dfeat, float *dtable, float *dx, void *stream);
+/* The same scatter for levels [l_begin, l_end) only (no dx): a finished slice of the table
+ * gradient can go to the data-parallel all-reduce while the other levels are still being
+ * scattered (no counterpart in the single-GPU reference).                        */
+int ia_hashgrid_bwd_levels(const float *x, int V, const int32_t *n_dev, const ia_field *field,
+                           const float *dfeat, float *dtable, int l_begin, int l_end,
+                           void *stream);
 size_t ia_field_frags_bytes(void);
 int ia_field_prepare(const ia_field *field, uint16_t *frags_out, void *stream);
 /* Encoding only (the roofline kernel in isolation): feat fp16 [V,32].        */
@@ -339,8 +345,9 @@ int ia_density_grid_init(const float *jitter, int iters, int G,
  * compaction by ballot/prefix sum; no host synchronisation: `n_iters` loop
  * iterations are enqueued and iterations with no alive ray exit immediately.
  * n_alive_out (DEVICE int32[2]) holds [0] the alive count after the last enqueued
- * iteration (0 = frame complete; >0 = call again with resume = 1) and [1] the number of
- * iterations that had rays to process so far.
+ * iteration (0 = frame complete; >0 = call again with resume = the number of iterations
+ * enqueued so far for this frame, same workspace) and [1] the number of iterations that had
+ * rays to process so far.  resume = 0 starts a new frame.  At most 1023 iterations per frame.
  * rays_o/rays_d: [R,3] (SMPL-root frame, after transform_rays_w2s), near/far
  * [R].  aabb: DEVICE [6] occupancy aabb.  bg: [R,3] or NULL (white).
  * Outputs: rgb [R,3], depth [R], alpha [R], counter [R].                     */
@@ -401,6 +408,14 @@ int ia_composite_train_bwd(const float *d_color, const float *d_depth, const flo
  * cand_cap = length of cand_sigma (candidates past it were dropped).          */
 int ia_candidate_argmax(const float *cand_sigma, int cand_cap, const int32_t *pt_off,
                         const uint8_t *pt_cnt, int P, int n_init, int32_t *arg, void *stream);
+/* The gather that follows it (snarf_deformer.py:150-158, torch.gather on the arg-max) and
+ * its backward: rgb/sigma [P] <- candidate arg[p] (arg < 0: rgb 0, sigma = fill); the
+ * backward is a UNIQUE scatter (a candidate belongs to one point): plain stores into the
+ * caller-zeroed d_cand_* arrays.  d_rgb / d_sigma may be NULL.                             */
+int ia_candidate_gather_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *arg,
+                            int P, float fill, float *rgb, float *sigma, void *stream);
+int ia_candidate_gather_bwd(const float *d_rgb, const float *d_sigma, const int32_t *arg, int P,
+                            float *d_cand_rgb, float *d_cand_sigma, void *stream);
 
 /* ---- measurement hooks (bench.py only) --------------------------------------
  * When enabled, every launch of the Broyden-search kernel (id 0) and of the

@@ -56,6 +56,9 @@ _SIGS = {
     "ia_field_act_stride": (C.c_int, [C.c_int]),
     "ia_field_fwd_train": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
     "ia_hashgrid_bwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
+    "ia_hashgrid_bwd_levels": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, C.c_int, C.c_int, _VP]),
+    "ia_candidate_gather_fwd": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP]),
+    "ia_candidate_gather_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),
     "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
     "ia_smpl_nn_deform": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP]),

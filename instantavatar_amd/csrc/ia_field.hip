@@ -1070,14 +1070,15 @@ template <int L>
 __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ x, int V,
                                                       const int32_t *__restrict__ n_dev, FieldDev F,
                                                       const float *__restrict__ dfeat,
-                                                      float *__restrict__ dtable, float *__restrict__ dx) {
+                                                      float *__restrict__ dtable, float *__restrict__ dx,
+                                                      int l_begin, int l_end) {
   if (n_dev) V = min(V, *n_dev);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     float xn[3];
     normalise(F, x, (size_t)i, xn);
     float gx[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int l = 0; l < L; l++) {
+    for (int l = l_begin; l < l_end; l++) {
       const float scale = F.lv.scale[l];
       const uint32_t res = F.lv.res[l], size = F.lv.size[l];
       const bool hashed = F.lv.hashed[l] != 0;
@@ -1130,22 +1131,36 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
   }
 }
 
-extern "C" int ia_hashgrid_bwd(const float *x, int V, const int32_t *n_dev, const ia_field *field, const float *dfeat,
-                               float *dtable, float *dx, void *stream) {
-  IA_CHECK_ARG(V >= 0, "ia_hashgrid_bwd: V < 0");
+static int hashgrid_bwd_impl(const float *x, int V, const int32_t *n_dev, const ia_field *field, const float *dfeat,
+                             float *dtable, float *dx, int l_begin, int l_end, void *stream, const char *who) {
+  IA_CHECK_ARG(V >= 0, "%s: V < 0", who);
   if (V == 0) return IA_OK;
-  IA_CHECK_ARG(x && dfeat && dtable, "ia_hashgrid_bwd: null pointer");
+  IA_CHECK_ARG(x && dfeat && dtable, "%s: null pointer", who);
   FieldDev F;
   int rc = ia_make_field_dev(field, &F);
-  IA_CHECK_ARG(rc == 0, "ia_hashgrid_bwd: bad field descriptor (%d)", rc);
+  IA_CHECK_ARG(rc == 0, "%s: bad field descriptor (%d)", who, rc);
+  IA_CHECK_ARG(0 <= l_begin && l_begin < l_end && l_end <= F.lv.n_levels, "%s: bad level range [%d, %d)", who, l_begin, l_end);
+  IA_CHECK_ARG(!dx || (l_begin == 0 && l_end == F.lv.n_levels), "%s: dx needs the full level range", who);
   int blocks = (V + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (F.lv.n_levels == 16)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx, l_begin, l_end);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hashgrid_bwd<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, V, n_dev, F, dfeat, dtable, dx, l_begin, l_end);
   IA_LAUNCH_CHECK("k_hashgrid_bwd");
   return IA_OK;
+}
+
+extern "C" int ia_hashgrid_bwd(const float *x, int V, const int32_t *n_dev, const ia_field *field, const float *dfeat,
+                               float *dtable, float *dx, void *stream) {
+  return hashgrid_bwd_impl(x, V, n_dev, field, dfeat, dtable, dx, 0, field ? field->hash.n_levels : 0, stream, "ia_hashgrid_bwd");
+}
+
+// The same scatter restricted to levels [l_begin, l_end): lets the caller hand a finished slice of the table
+// gradient to the gradient all-reduce while the remaining levels are still being scattered.
+extern "C" int ia_hashgrid_bwd_levels(const float *x, int V, const int32_t *n_dev, const ia_field *field, const float *dfeat,
+                                      float *dtable, int l_begin, int l_end, void *stream) {
+  return hashgrid_bwd_impl(x, V, n_dev, field, dfeat, dtable, nullptr, l_begin, l_end, stream, "ia_hashgrid_bwd_levels");
 }
 
 extern "C" int ia_hashgrid_fwd(const float *x, int V, const ia_field *field, uint16_t *feat, void *stream) {

@@ -195,21 +195,21 @@ __global__ __launch_bounds__(256) void k_candidate_max(const float *__restrict__
 struct OccWs {
   double sum;               // sum of the max-pooled field
   unsigned long long best;  // (count << 32) | (~label)
+  float thr;                // clamp(mean, max = 0.01)
+  float pad;
 };
 
-__global__ void k_occ_reset(OccWs *w) { w->sum = 0.0; w->best = 0ull; }
-
-// f = 1 - exp(0.01 * -density)  (density_grid.py:104)
-__global__ __launch_bounds__(256) void k_occ_f(const float *__restrict__ density, int n, float *__restrict__ f) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) f[i] = 1.f - expf(0.01f * -density[i]);
-}
-
-// g = maxpool3(f); accumulate sum(g)
+// Launch 1 of 5: f = 1 - exp(0.01 * -density) (density_grid.py:104) evaluated on the fly for the
+// 27 neighbours, g = maxpool3(f), per-workgroup partial sums of g (fixed-order tree: the mean is
+// deterministic); also resets what the later launches accumulate into (component counts,
+// union-find parents, best-component word, border flag).
 __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ density, int G,
-                                                  float *__restrict__ pooled, double *__restrict__ partial) {
+                                                  float *__restrict__ pooled, double *__restrict__ partial,
+                                                  int32_t *__restrict__ parent, int32_t *__restrict__ count,
+                                                  OccWs *__restrict__ ws, uint32_t *__restrict__ bits) {
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { ws->sum = 0.0; ws->best = 0ull; bits[n >> 5] = 1u; }  // border flag: 1 = no border cell occupied
   float m = 0.f;
   if (i < n) {
     const int x = i / (G * G), y = i / G % G, z = i % G;
@@ -219,10 +219,12 @@ __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ dens
         for (int c = -1; c <= 1; c++) {
           const int xx = x + a, yy = y + b, zz = z + c;
           if (xx < 0 || yy < 0 || zz < 0 || xx >= G || yy >= G || zz >= G) continue;
-          const float f = density[(xx * G + yy) * G + zz];  // f precomputed by k_occ_f
+          const float f = 1.f - expf(0.01f * -density[(xx * G + yy) * G + zz]);
           m = (f > m || isnan(f)) ? f : m;
         }
     pooled[i] = m;
+    parent[i] = i;   // every cell starts as its own root; unoccupied cells are never linked nor queried
+    count[i] = 0;
   }
   // deterministic mean: fixed-order tree inside the workgroup, one partial per workgroup
   __shared__ double s_part[4];
@@ -234,9 +236,9 @@ __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ dens
   if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
-// fixed-order reduction of the workgroup partials (one workgroup)
-__global__ __launch_bounds__(256) void k_occ_mean(const double *__restrict__ partial, int n_part, OccWs *ws) {
-  __shared__ double s[256];
+// fixed-order reduction of the workgroup partials, evaluated identically by every workgroup that needs
+// the threshold (256 threads): thr = clamp(mean, max = 0.01)  (density_grid.py:106)
+__device__ __forceinline__ float occ_threshold(const double *__restrict__ partial, int n_part, int n, double *s /*[256]*/) {
   double v = 0.0;
   for (int k = threadIdx.x; k < n_part; k += 256) v += partial[k];
   s[threadIdx.x] = v;
@@ -245,19 +247,8 @@ __global__ __launch_bounds__(256) void k_occ_mean(const double *__restrict__ par
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) ws->sum = s[0];
-}
-
-// grid = g > clamp(mean, max=0.01); union-find parent init
-__global__ __launch_bounds__(256) void k_occ_threshold(const float *__restrict__ pooled, int G,
-                                                       const OccWs *__restrict__ ws,
-                                                       int32_t *__restrict__ parent) {
-  const int n = G * G * G;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float mean = (float)(ws->sum / (double)n);
-  const float thr = mean > 0.01f ? 0.01f : mean;  // density_grid.py:106
-  parent[i] = pooled[i] > thr ? i : -1;
+  const float mean = (float)(s[0] / (double)n);
+  return mean > 0.01f ? 0.01f : mean;
 }
 
 __device__ __forceinline__ int uf_find(int32_t *parent, int i) {
@@ -270,13 +261,18 @@ __device__ __forceinline__ int uf_find(int32_t *parent, int i) {
   return i;
 }
 
-// 26-connected union (max_pool3d 3x3x3 label propagation, density_grid.py:118-125):
-// the surviving label of a component is its LARGEST linear index (+1), so roots
-// are the maximum index (parent[i] >= i).
-__global__ __launch_bounds__(256) void k_occ_union(int G, int32_t *parent) {
+// Launch 2 of 5: grid = g > thr, 26-connected union (max_pool3d 3x3x3 label propagation,
+// density_grid.py:118-125): the surviving label of a component is its LARGEST linear index (+1), so
+// roots are the maximum index (parent[i] >= i).
+__global__ __launch_bounds__(256) void k_occ_union(int G, const float *__restrict__ pooled,
+                                                   const double *__restrict__ partial, int n_part, OccWs *ws,
+                                                   int32_t *parent) {
+  __shared__ double s_red[256];
   const int n = G * G * G;
+  const float thr = occ_threshold(partial, n_part, n, s_red);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || parent[i] < 0) return;
+  if (i == 0) { ws->thr = thr; ws->sum = s_red[0]; }
+  if (i >= n || !(pooled[i] > thr)) return;
   const int x = i / (G * G), y = i / G % G, z = i % G;
   // the 13 neighbours with a larger linear index
   for (int a = 0; a <= 1; a++)
@@ -286,7 +282,7 @@ __global__ __launch_bounds__(256) void k_occ_union(int G, int32_t *parent) {
         const int xx = x + a, yy = y + b, zz = z + c;
         if (xx >= G || yy < 0 || yy >= G || zz < 0 || zz >= G) continue;
         const int j = (xx * G + yy) * G + zz;
-        if (__hip_atomic_load(&parent[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) continue;
+        if (!(pooled[j] > thr)) continue;
         int ra = i, rb = j;
         while (true) {
           ra = uf_find(parent, ra); rb = uf_find(parent, rb);
@@ -298,13 +294,14 @@ __global__ __launch_bounds__(256) void k_occ_union(int G, int32_t *parent) {
       }
 }
 
-__global__ __launch_bounds__(256) void k_occ_count(int G, int32_t *parent, int32_t *__restrict__ label,
-                                                   int32_t *count) {
+// Launch 3 of 5: labels + component sizes
+__global__ __launch_bounds__(256) void k_occ_count(int G, const float *__restrict__ pooled, const OccWs *__restrict__ ws,
+                                                   int32_t *parent, int32_t *__restrict__ label, int32_t *count) {
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int l = -1;
-  if (parent[i] >= 0) l = uf_find(parent, i);
+  if (pooled[i] > ws->thr) l = uf_find(parent, i);
   label[i] = l;
   // most lanes of a wave belong to the same (largest) component: one atomic per wave then
   const unsigned long long m = __ballot(l >= 0);
@@ -417,22 +414,34 @@ __global__ __launch_bounds__(256) void k_transform_rays(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// fused render_test loop state (device resident)
+// fused render_test loop state (device resident).  ONE record per wave-front iteration: the
+// kernels of iteration `it` work on st[it]; the alive compaction of iteration it - 1 counts into
+// st[it].n_alive.  Every kernel derives the loop condition and the N_step schedule
+// (raymarcher_acc.py:107-112) itself from (n_alive, k_before) -- a pure function -- so no
+// single-thread "begin iteration" launch sits between two iterations; the march kernel's first
+// thread records the derived values for the kernels that follow it and for the next iteration.
 // ---------------------------------------------------------------------------
+#define IA_RENDER_MAX_ITERS 1024
 struct RenderState {
-  int32_t n_alive;       // rays alive at the start of the current iteration
-  int32_t n_alive_next;  // compaction counter for the next iteration
-  int32_t n_step;        // N_step of the current iteration
-  int32_t k;             // samples-per-ray budget consumed (raymarcher_acc.py:107,127)
-  int32_t n_samples;     // compact sample counter
-  int32_t n_cand;        // compact candidate counter
-  int32_t iters;         // iterations actually executed
+  int32_t n_alive;    // rays handed over by the previous iteration's compaction (R for iteration 0)
+  int32_t n_samples;  // compact sample counter of this iteration
+  int32_t n_cand;     // compact candidate counter of this iteration
+  int32_t k_before;   // samples-per-ray budget consumed before this iteration (raymarcher_acc.py:107,127)
+  int32_t iters;      // iterations before this one that had rays to process
+  int32_t n_step;     // N_step of this iteration   } written by the march kernel's first thread,
+  int32_t n_eff;      // rays actually processed     } read by the kernels behind it
   int32_t pad;
 };
 
-__global__ void k_render_init_state(RenderState *st, int R) {
-  st->n_alive = 0; st->n_alive_next = R; st->n_step = 0; st->k = 0;
-  st->n_samples = 0; st->n_cand = 0; st->iters = 0; st->pad = 0;
+__device__ __forceinline__ void render_schedule(const RenderState *st, int max_samples, int max_batch, int &na, int &ns) {
+  na = st->n_alive;
+  if (st->k_before >= max_samples) na = 0;  // while k < MAX_SAMPLES
+  ns = 0;
+  if (na > 0) {
+    ns = max_batch / na;
+    ns = ns < max_samples ? ns : max_samples;
+    ns = ns > 1 ? ns : 1;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_render_init_rays(int R, const float *__restrict__ near,
@@ -440,34 +449,18 @@ __global__ __launch_bounds__(256) void k_render_init_rays(int R, const float *__
                                                           float *__restrict__ near_w, float *__restrict__ step,
                                                           float *__restrict__ color, float *__restrict__ depth,
                                                           float *__restrict__ nohit, float *__restrict__ counter,
-                                                          int32_t *__restrict__ alive, int max_samples) {
+                                                          int32_t *__restrict__ alive, int max_samples,
+                                                          RenderState *st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // all iteration records zeroed, st[0].n_alive = R (first word)
+  for (int w = i; w < IA_RENDER_MAX_ITERS * (int)(sizeof(RenderState) / 4); w += gridDim.x * blockDim.x)
+    reinterpret_cast<int32_t *>(st)[w] = (w == 0) ? R : 0;
   if (i >= R) return;
   near_w[i] = near[i];
   step[i] = (far[i] - near[i]) / max_samples;  // raymarcher_acc.py:101
   color[(size_t)i * 3] = 0.f; color[(size_t)i * 3 + 1] = 0.f; color[(size_t)i * 3 + 2] = 0.f;
   depth[i] = 0.f; nohit[i] = 1.f; counter[i] = 0.f;
   alive[i] = i;
-}
-
-// raymarcher_acc.py:107-112: loop condition and N_step schedule, on device.
-__global__ void k_iter_begin(RenderState *st, int max_samples, int max_batch) {
-  int na = st->n_alive_next;
-  if (st->k >= max_samples) na = 0;  // while k < MAX_SAMPLES
-  st->n_alive = na;
-  st->n_alive_next = 0;
-  st->n_samples = 0;
-  st->n_cand = 0;
-  if (na > 0) {
-    int ns = max_batch / na;
-    ns = ns < max_samples ? ns : max_samples;
-    ns = ns > 1 ? ns : 1;
-    st->n_step = ns;
-    st->k += ns;
-    st->iters += 1;
-  } else {
-    st->n_step = 0;
-  }
 }
 
 // march + sample compaction: every alive ray counts its samples (pass 1), the
@@ -478,11 +471,16 @@ __global__ __launch_bounds__(256) void k_march_compact(
     const float *__restrict__ fars, const float *__restrict__ step, const int32_t *__restrict__ alive,
     RenderState *st, const uint32_t *__restrict__ bits, int G, const float *__restrict__ aabb,
     float *__restrict__ s_pts, float *__restrict__ s_t, int32_t *__restrict__ ray_off,
-    int32_t *__restrict__ ray_cnt, float *__restrict__ counter, int sample_cap) {
-  const int n_alive = st->n_alive;
+    int32_t *__restrict__ ray_cnt, float *__restrict__ counter, int sample_cap, int max_samples, int max_batch) {
+  int n_alive, N_steps;
+  render_schedule(st, max_samples, max_batch, n_alive, N_steps);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {  // the derived schedule, for the kernels behind this one and for the next iteration
+    st->n_eff = n_alive; st->n_step = N_steps;
+    st[1].k_before = st->k_before + N_steps;
+    st[1].iters = st->iters + (n_alive > 0 ? 1 : 0);
+  }
   if ((i - ia_lane()) >= n_alive) return;  // whole wave idle
-  const int N_steps = st->n_step;
   const bool live = i < n_alive;
   int cnt = 0;
   size_t n = 0;
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(256) void k_composite_compact(
     const uint8_t *__restrict__ pt_cnt, const float *__restrict__ cand_rgb,
     const float *__restrict__ cand_sigma, int n_init, float *color, float *depth, float *nohit,
     float thresh) {
-  const int n_alive = st->n_alive;
+  const int n_alive = st->n_eff;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if ((i - ia_lane()) >= n_alive) return;
   const int N_steps = st->n_step;
@@ -564,7 +562,7 @@ __global__ __launch_bounds__(256) void k_composite_compact(
   const unsigned long long m = __ballot(keep);
   const int total = __popcll(m);
   int base = 0;
-  if (ia_lane() == 0 && total > 0) base = atomicAdd(&st->n_alive_next, total);
+  if (ia_lane() == 0 && total > 0) base = atomicAdd(&st[1].n_alive, total);  // hand-over to the next iteration
   base = __shfl(base, 0, 64);
   if (keep) alive_next[base + __popcll(m & ((1ull << ia_lane()) - 1ull))] = n;
 }
@@ -573,11 +571,18 @@ __global__ __launch_bounds__(256) void k_render_finalize(int R, const float *__r
                                                          const float *__restrict__ depth,
                                                          const float *__restrict__ nohit,
                                                          const float *__restrict__ counter,
-                                                         const float *__restrict__ bg, const RenderState *st,
+                                                         const float *__restrict__ bg, const RenderState *st_end,
+                                                         int max_samples, int32_t *__restrict__ n_alive_out,
                                                          float *__restrict__ rgb_out, float *__restrict__ depth_out,
                                                          float *__restrict__ alpha_out,
                                                          float *__restrict__ counter_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && n_alive_out) {
+    // st_end = record of the first iteration NOT enqueued: would the loop continue?
+    int na = st_end->n_alive;
+    if (st_end->k_before >= max_samples) na = 0;
+    n_alive_out[0] = na; n_alive_out[1] = st_end->iters;  // [1]: iterations that had rays to process
+  }
   if (i >= R) return;
   const float T = nohit[i];
 #pragma unroll
@@ -586,13 +591,6 @@ __global__ __launch_bounds__(256) void k_render_finalize(int R, const float *__r
   depth_out[i] = depth[i];
   alpha_out[i] = 1.f - T;
   counter_out[i] = counter[i];
-}
-
-// After the last enqueued iteration: report whether the loop would continue.
-__global__ void k_render_report(RenderState *st, int max_samples, int32_t *n_alive_out) {
-  int na = st->n_alive_next;
-  if (st->k >= max_samples) na = 0;
-  if (n_alive_out) { n_alive_out[0] = na; n_alive_out[1] = st->iters; }  // [1]: iterations that had rays to process
 }
 
 // ---------------------------------------------------------------------------
@@ -682,16 +680,13 @@ extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *
   float *fval = w.take<float>(n);
   double *partial = w.take<double>(ia_div_up(n, 256));
   const dim3 grid(ia_div_up(n, 256)), blk(256);
-  hipLaunchKernelGGL(k_occ_reset, dim3(1), dim3(1), 0, s, ow);
-  hipLaunchKernelGGL(k_fill_i32, grid, blk, 0, s, count, 0, n);
-  hipLaunchKernelGGL(k_occ_f, grid, blk, 0, s, density, n, fval);
-  hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, fval, G, pooled, partial);
-  hipLaunchKernelGGL(k_occ_mean, dim3(1), blk, 0, s, partial, ia_div_up(n, 256), ow);
-  hipLaunchKernelGGL(k_occ_threshold, grid, blk, 0, s, pooled, G, ow, parent);
-  hipLaunchKernelGGL(k_occ_union, grid, blk, 0, s, G, parent);
-  hipLaunchKernelGGL(k_occ_count, grid, blk, 0, s, G, parent, label, count);
+  // (fval is no longer needed: f is evaluated inside the pooling kernel)
+  (void)fval;
+  const int n_part = ia_div_up(n, 256);
+  hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, density, G, pooled, partial, parent, count, ow, occ_bits);
+  hipLaunchKernelGGL(k_occ_union, grid, blk, 0, s, G, pooled, partial, n_part, ow, parent);
+  hipLaunchKernelGGL(k_occ_count, grid, blk, 0, s, G, pooled, ow, parent, label, count);
   hipLaunchKernelGGL(k_occ_best, grid, blk, 0, s, G, count, ow);
-  hipLaunchKernelGGL(k_occ_set_flag, dim3(1), dim3(1), 0, s, occ_bits, n);
   hipLaunchKernelGGL(k_occ_final, grid, blk, 0, s, G, label, ow, occ_bits, occ_bool);
   IA_LAUNCH_CHECK("occupancy_from_density");
   return IA_OK;
@@ -845,7 +840,7 @@ struct RenderWs {
 };
 static size_t render_ws_bytes(int R, int max_batch, int n_init) {
   const size_t cap = (size_t)(R > max_batch ? R : max_batch);
-  return ia_align(sizeof(RenderState)) + 4 * ia_align((size_t)R * 4) + ia_align((size_t)R * 12) + ia_align((size_t)R * 4) +
+  return ia_align(sizeof(RenderState) * IA_RENDER_MAX_ITERS) + 4 * ia_align((size_t)R * 4) + ia_align((size_t)R * 12) + ia_align((size_t)R * 4) +
          4 * ia_align((size_t)R * 4) + ia_align(cap * 12) + ia_align(cap * 4) + query_ws_bytes((int)cap, n_init);
 }
 extern "C" size_t ia_render_workspace_bytes(int R, int max_batch, int n_init) {
@@ -869,40 +864,37 @@ extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const fl
   const int cap = R > max_batch ? R : max_batch;
   WsCarver w(ws, ws_bytes);
   RenderWs rw;
-  rw.st = w.take<RenderState>(1);
+  rw.st = w.take<RenderState>(IA_RENDER_MAX_ITERS);
   rw.near_w = w.take<float>(R); rw.step = w.take<float>(R); rw.depth = w.take<float>(R); rw.nohit = w.take<float>(R);
   rw.color = w.take<float>((size_t)R * 3); rw.counter = w.take<float>(R);
   rw.alive_a = w.take<int32_t>(R); rw.alive_b = w.take<int32_t>(R); rw.ray_off = w.take<int32_t>(R); rw.ray_cnt = w.take<int32_t>(R);
   rw.s_pts = w.take<float>((size_t)cap * 3); rw.s_t = w.take<float>(cap);
   rw.q = carve_query(w, cap, n_init);
-  rw.q.n_cand = &rw.st->n_cand;  // zeroed by k_iter_begin: no separate zero-fill launch per iteration
   rw.sample_cap = cap;
   const dim3 blk(256), gR(ia_div_up(R, 256));
-  if (!resume) {
-    hipLaunchKernelGGL(k_render_init_state, dim3(1), dim3(1), 0, s, rw.st, R);
+  // `resume` = number of iterations enqueued by earlier calls for this frame (0: new frame)
+  const int it0 = resume;
+  IA_CHECK_ARG(it0 >= 0 && it0 + n_iters < IA_RENDER_MAX_ITERS, "ia_render_test: more than %d wave-front iterations", IA_RENDER_MAX_ITERS - 1);
+  if (it0 == 0)
     hipLaunchKernelGGL(k_render_init_rays, gR, blk, 0, s, R, near, far, rw.near_w, rw.step, rw.color, rw.depth,
-                       rw.nohit, rw.counter, rw.alive_a, max_samples);
-  }
-  // NOTE: alive lists ping-pong; with resume the parity of previously executed
-  // launches must be kept by the caller (n_iters even) -- enforced here.
-  IA_CHECK_ARG(n_iters % 2 == 0, "ia_render_test: n_iters must be even (alive list ping-pong)");
-  for (int it = 0; it < n_iters; it++) {
-    int32_t *cur = (it & 1) ? rw.alive_b : rw.alive_a;
+                       rw.nohit, rw.counter, rw.alive_a, max_samples, rw.st);
+  for (int it = it0; it < it0 + n_iters; it++) {
+    int32_t *cur = (it & 1) ? rw.alive_b : rw.alive_a;  // alive lists ping-pong on the absolute iteration index
     int32_t *nxt = (it & 1) ? rw.alive_a : rw.alive_b;
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, s, rw.st, max_samples, max_batch);
+    RenderState *st = rw.st + it;
     // upper bounds for the launches: iteration 0 may have R alive rays, later
     // ones never more than the first compaction leaves; keep R (idle waves exit).
-    hipLaunchKernelGGL(k_march_compact, gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, rw.st, occ_bits,
-                       G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap);
-    rc = query_impl(rw.s_pts, cap, &rw.st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s, 0);
+    hipLaunchKernelGGL(k_march_compact, gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, st, occ_bits,
+                       G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap, max_samples, max_batch);
+    rw.q.n_cand = &st->n_cand;  // zeroed with the record: no zero-fill launch per iteration
+    rc = query_impl(rw.s_pts, cap, &st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_composite_compact, gR, blk, 0, s, cur, nxt, rw.st, rw.ray_off, rw.ray_cnt, rw.s_t, rw.step,
+    hipLaunchKernelGGL(k_composite_compact, gR, blk, 0, s, cur, nxt, st, rw.ray_off, rw.ray_cnt, rw.s_t, rw.step,
                        rw.q.pt_off, rw.q.pt_cnt, rw.q.cand_rgb, rw.q.cand_sigma, n_init, rw.color, rw.depth, rw.nohit,
                        0.01f);
   }
-  hipLaunchKernelGGL(k_render_finalize, gR, blk, 0, s, R, rw.color, rw.depth, rw.nohit, rw.counter, bg, rw.st, rgb,
-                     depth, alpha, counter);
-  hipLaunchKernelGGL(k_render_report, dim3(1), dim3(1), 0, s, rw.st, max_samples, n_alive_out);
+  hipLaunchKernelGGL(k_render_finalize, gR, blk, 0, s, R, rw.color, rw.depth, rw.nohit, rw.counter, bg,
+                     rw.st + it0 + n_iters, max_samples, n_alive_out, rgb, depth, alpha, counter);
   IA_LAUNCH_CHECK("ia_render_test");
   return IA_OK;
 }
@@ -984,8 +976,9 @@ __global__ __launch_bounds__(64 * IA_MT_RAYS) void k_march_train_compact(
   }
   int tot_k;
   const int excl_k = ia_wave_excl_scan(kcnt, tot_k);
-  const int alloc = min(tot_c, max_samples);
-  if (lane == 0) s_tot[wave] = live ? alloc : 0;
+  // reserve exactly the kept samples: slots whose depth is <= 0 (camera within one unit of the root) are
+  // masked out by the reference (z_vals > 0) and never written here, so they must not be queued either
+  if (lane == 0) s_tot[wave] = live ? tot_k : 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     int tot = 0;
@@ -1238,5 +1231,61 @@ extern "C" int ia_candidate_argmax(const float *cand_sigma, int cand_cap, const 
   hipLaunchKernelGGL(k_candidate_argmax, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_sigma, cand_cap,
                      pt_off, pt_cnt, P, n_init, arg);
   IA_LAUNCH_CHECK("k_candidate_argmax");
+  return IA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// deform_train's arg-max gather (snarf_deformer.py:150-158) as a kernel pair: forward takes the
+// winning candidate's (rgb, sigma) per point (fill values where an invalid slot won), backward
+// scatters the point gradients back.  Every candidate belongs to exactly one point, so the scatter
+// is unique: plain stores, no atomics, no sort (torch's index backward sorts the indices first).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_candidate_gather_fwd(const float *__restrict__ cand_rgb,
+                                                              const float *__restrict__ cand_sigma,
+                                                              const int32_t *__restrict__ arg, int P, float fill,
+                                                              float *__restrict__ rgb, float *__restrict__ sigma) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int a = arg[p];
+  sigma[p] = a >= 0 ? cand_sigma[a] : fill;
+#pragma unroll
+  for (int c = 0; c < 3; c++) rgb[(size_t)p * 3 + c] = a >= 0 ? cand_rgb[(size_t)a * 3 + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_candidate_gather_bwd(const float *__restrict__ d_rgb,
+                                                              const float *__restrict__ d_sigma,
+                                                              const int32_t *__restrict__ arg, int P,
+                                                              float *__restrict__ d_cand_rgb,
+                                                              float *__restrict__ d_cand_sigma) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int a = arg[p];
+  if (a < 0) return;
+  if (d_sigma) d_cand_sigma[a] = d_sigma[p];
+  if (d_rgb) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) d_cand_rgb[(size_t)a * 3 + c] = d_rgb[(size_t)p * 3 + c];
+  }
+}
+
+extern "C" int ia_candidate_gather_fwd(const float *cand_rgb, const float *cand_sigma, const int32_t *arg, int P,
+                                       float fill, float *rgb, float *sigma, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_candidate_gather_fwd: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(cand_rgb && cand_sigma && arg && rgb && sigma, "ia_candidate_gather_fwd: null pointer");
+  hipLaunchKernelGGL(k_candidate_gather_fwd, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, cand_rgb,
+                     cand_sigma, arg, P, fill, rgb, sigma);
+  IA_LAUNCH_CHECK("k_candidate_gather_fwd");
+  return IA_OK;
+}
+
+extern "C" int ia_candidate_gather_bwd(const float *d_rgb, const float *d_sigma, const int32_t *arg, int P,
+                                       float *d_cand_rgb, float *d_cand_sigma, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_candidate_gather_bwd: P < 0");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(arg && d_cand_rgb && d_cand_sigma, "ia_candidate_gather_bwd: null pointer");
+  hipLaunchKernelGGL(k_candidate_gather_bwd, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, d_sigma,
+                     arg, P, d_cand_rgb, d_cand_sigma);
+  IA_LAUNCH_CHECK("k_candidate_gather_bwd");
   return IA_OK;
 }

@@ -201,34 +201,11 @@ def bmv(m, v):
     return m @ v
 
 
-def knn(query, verts, K, chunk=16384):
-    """Exact K nearest vertices per query point: (squared distances ascending, indices).
-    Stands in for pytorch3d's knn_points used at deformer_torch.py:227."""
-    out_d, out_i = [], []
-    v2 = (verts * verts).sum(-1)
-    for s in range(0, query.shape[0], chunk):
-        q = query[s:s + chunk]
-        approx = (q * q).sum(-1, keepdim=True) - 2.0 * (q @ verts.T) + v2
-        idx = approx.topk(K + 16, dim=1, largest=False).indices  # shortlist by the GEMM form ...
-        d2 = ((q[:, None] - verts[idx]) ** 2).sum(-1)            # ... exact distances decide the K
-        d2, order = d2.sort(dim=1)
-        out_d.append(d2[:, :K])
-        out_i.append(idx.gather(1, order)[:, :K])
-    return torch.cat(out_d), torch.cat(out_i)
-
-
-def _six_neighbour_mean(w):
-    c = w[:, 1:-1, 1:-1, 1:-1]
-    return (w[:, 2:, 1:-1, 1:-1] + w[:, :-2, 1:-1, 1:-1] + w[:, 1:-1, 2:, 1:-1] + w[:, 1:-1, :-2, 1:-1] +
-            w[:, 1:-1, 1:-1, 2:] + w[:, 1:-1, 1:-1, :-2]) / 6.0, c
-
-
 def voxelise_skinning_weights(points, verts, vert_weights, dims):
     """deformer_torch.py:225-244 on the GPU: `ia_voxelise_weights` (exact brute-force 30-NN with
-    the vertices staged in LDS + inverse-distance blend + 30 smoothing passes).  CPU tensors use
-    the torch restatement below (host-logic tests only; the per-frame path never runs on the CPU)."""
-    if not points.is_cuda:
-        return voxelise_skinning_weights_torch(points, verts, vert_weights, dims)
+    the vertices staged in LDS + inverse-distance blend + 30 smoothing passes).  There is no CPU route:
+    CPU tensors raise (the checkers of this kernel live in oracle/ and tests/)."""
+    _lib.require_cuda(points)
     d, h, w = dims
     L = _lib.lib()
     pts, vs, vw = points.float().contiguous(), verts.float().contiguous(), vert_weights.float().contiguous()
@@ -237,18 +214,3 @@ def voxelise_skinning_weights(points, verts, vert_weights, dims):
     _lib.check(L.ia_voxelise_weights(_lib.ptr(pts), _lib.ptr(vs), vs.shape[0], _lib.ptr(vw), d, h, w, SMOOTH_PASSES,
                                      _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_voxelise_weights")
     return out
-
-
-def voxelise_skinning_weights_torch(points, verts, vert_weights, dims):
-    """Plain PyTorch fp32 restatement of deformer_torch.py:225-244 (reference for the HIP kernel):
-    inverse-distance blend of the K=30 nearest SMPL vertices' weights, then 30 rounds of
-    6-neighbour smoothing + renormalisation.  points [N,3] in (d,h,w) raster order -> [24,d,h,w]."""
-    d2, idx = knn(points, verts, KNN_K)
-    inv = 1.0 / d2.sqrt().clamp(1e-4, 1.0)
-    inv = inv / inv.sum(-1, keepdim=True)
-    vox = (inv[..., None] * vert_weights[idx]).sum(-2).T.reshape(24, *dims).contiguous()
-    for _ in range(SMOOTH_PASSES):
-        mean, centre = _six_neighbour_mean(vox)
-        vox[:, 1:-1, 1:-1, 1:-1] = (centre - mean) * SMOOTH_BLEND + mean
-        vox = vox / vox.sum(0, keepdim=True)
-    return vox

@@ -89,10 +89,19 @@ class SMPLDeformer():
         P = x.shape[0]
         cano = torch.empty((P, 3), device=x.device)
         valid = torch.empty(P, dtype=torch.uint8, device=x.device)
+        need_grad = torch.is_grad_enabled() and (self.T_inv.requires_grad or pts.requires_grad)
+        idx = torch.empty(P, dtype=torch.int32, device=x.device) if need_grad else None
         if P:
-            _lib.check(_lib.lib().ia_smpl_nn_deform(_lib.ptr(x), P, None, _lib.ptr(self.vertices), _lib.ptr(self.T_inv),
+            _lib.check(_lib.lib().ia_smpl_nn_deform(_lib.ptr(x), P, None, _lib.ptr(self.vertices.detach()), _lib.ptr(self.T_inv.detach()),
                                                     self.vertices.shape[1], float(self.threshold), _lib.ptr(cano),
-                                                    _lib.ptr(valid), None, _lib.stream()), "ia_smpl_nn_deform")
+                                                    _lib.ptr(valid), _lib.ptr(idx), _lib.stream()), "ia_smpl_nn_deform")
+        if need_grad and P:
+            # SMPL refinement with this deformer (SNARF_NGP_refine + deformer=smpl): the reference's pts_cano
+            # (smpl_deformer.py:100-107) is differentiable w.r.t. the per-vertex transforms; the nearest-vertex
+            # index comes from the kernel, the affine map is re-applied in torch so that autograd reaches T_inv
+            T = self.T_inv[0][idx.long()]
+            xh = pts.reshape(-1, 3).float()
+            cano = (T[:, :3, :3] @ xh[:, :, None])[:, :, 0] + T[:, :3, 3]
         return cano, valid.bool()
 
     def _workspace(self, nbytes, device):

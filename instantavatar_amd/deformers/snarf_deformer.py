@@ -55,6 +55,34 @@ def _abs_path(p):
         return os.path.abspath(p) if isinstance(p, str) else p
 
 
+class _CandidateGatherFn(torch.autograd.Function):
+    """rgb / sigma of the winning candidate per point (torch.max + torch.gather of snarf_deformer.py:150-158)."""
+
+    @staticmethod
+    def forward(ctx, cand_rgb, cand_sigma, arg, fill):
+        cand_rgb, cand_sigma = cand_rgb.contiguous(), cand_sigma.contiguous()
+        P = arg.shape[0]
+        rgb = torch.empty((P, 3), device=arg.device)
+        sigma = torch.empty(P, device=arg.device)
+        _lib.check(_lib.lib().ia_candidate_gather_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), _lib.ptr(arg), P, float(fill),
+                                                      _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream()), "ia_candidate_gather_fwd")
+        ctx.save_for_backward(arg)
+        ctx.n_cand = cand_sigma.shape[0]
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        (arg,) = ctx.saved_tensors
+        c = lambda t: None if t is None else t.float().contiguous()
+        d_rgb, d_sigma = c(d_rgb), c(d_sigma)
+        d_cand_rgb = torch.zeros((ctx.n_cand, 3), device=arg.device)
+        d_cand_sigma = torch.zeros(ctx.n_cand, device=arg.device)
+        _lib.check(_lib.lib().ia_candidate_gather_bwd(_lib.ptr(d_rgb), _lib.ptr(d_sigma), _lib.ptr(arg), arg.shape[0],
+                                                      _lib.ptr(d_cand_rgb), _lib.ptr(d_cand_sigma), _lib.stream()),
+                   "ia_candidate_gather_bwd")
+        return d_cand_rgb, d_cand_sigma, None, None
+
+
 class SNARFDeformer():
     #: capacity (candidates) of one training-mode field call (`query_train_fused`)
     train_cand_capacity = 1 << 20
@@ -235,27 +263,52 @@ class SNARFDeformer():
                                                       _lib.ptr(out["n_cand"]), 0, _lib.stream()), "ia_snarf_search_compact")
         return out
 
+    #: number of `query_train_fused` calls whose candidates exceeded the capacity (they were dropped); the
+    #: capacity doubles after every such call (deferred check, see `_cand_count_check`)
+    train_overflow = 0
+
+    def _cand_count_post(self, n_cand, cap):
+        """copy the device-side candidate count to pinned memory without blocking; looked at by the next call"""
+        if not hasattr(self, "_cc_host"):
+            self._cc_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._cc_host.copy_(n_cand, non_blocking=True)
+        self._cc_event = torch.cuda.Event()
+        self._cc_event.record()
+        self._cc_cap = cap
+
+    def _cand_count_check(self):
+        """Deferred overflow check of the previous `query_train_fused` call (that call has long finished: no
+        stall).  An overflowing call dropped candidates in compaction order -- its densities had holes; it is
+        counted in `train_overflow` and the capacity grows so that it cannot happen twice at that size."""
+        ev = getattr(self, "_cc_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._cc_event = None
+        self.last_cand_count = int(self._cc_host[0])
+        if self.last_cand_count > self._cc_cap:
+            self.train_overflow += 1
+            self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_cand_count)
+
     def query_train_fused(self, pts, net):
         """deform_train (snarf_deformer.py:143-159) without the dense [P,13,*] temporaries:
-        compacted candidates -> field under autograd -> arg-max gather.  No host synchronisation."""
+        compacted candidates -> field under autograd -> arg-max gather (`ia_candidate_gather_*`, whose
+        backward is a unique scatter: no index sort).  No host synchronisation: the field runs on a
+        capacity-sized candidate buffer with the device-side count; the count is inspected one call later
+        (`train_overflow`, growing `train_cand_capacity`)."""
         P = pts.shape[0]
         k = len(self.deformer.init_bones)
+        self._cand_count_check()
         sc = self.search_compact(pts)
-        dev = pts.device
-        # no host read: the field runs on a capacity-sized candidate buffer with the device-side count
-        # (candidates past the capacity are dropped by the compaction; cf. Raymarcher.render_train_fused)
         cap = min(P * k, self.train_cand_capacity)
         from ..training import field_autograd
         rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cap], n_dev=sc["n_cand"])
-        arg = torch.empty(P, dtype=torch.int32, device=dev)
+        self._cand_count_post(sc["n_cand"], cap)
+        arg = torch.empty(P, dtype=torch.int32, device=pts.device)
         sig_d = sig_c.detach().float().contiguous()
         _lib.check(_lib.lib().ia_candidate_argmax(_lib.ptr(sig_d), cap, _lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), P, k,
                                                   _lib.ptr(arg), _lib.stream()), "ia_candidate_argmax")
-        has = arg >= 0
-        idx = arg.clamp(min=0).long()
-        sigma = torch.where(has, sig_c.float()[idx], torch.full_like(sig_c[:1], -1e5).expand(P))
-        rgb = torch.where(has[:, None], rgb_c.float()[idx], torch.zeros((), device=dev))
-        return rgb, sigma
+        return _CandidateGatherFn.apply(rgb_c.float(), sig_c.float(), arg, -1e5)
 
     def deform_train(self, pts, model):
         """snarf_deformer.py:143-159."""

@@ -82,7 +82,12 @@ def build_model(args, device):
     if not getattr(deformer, "initialized", False):
         deformer.initialize(torch.as_tensor(betas, device=device).reshape(1, 10), device)
         deformer.initialized = True
-    net.initialize(deformer.bbox)   # DNeRF.py:134
+    # The reference's animate.py never calls net.initialize: `center` / `scale` come from the checkpoint
+    # (buffers written by training, DNeRF.py:134).  Only a checkpoint without them falls back to the bbox.
+    if "net_coarse.center" in missing or "net_coarse.scale" in missing:
+        net.initialize(deformer.bbox)
+    else:
+        net.bbox = deformer.bbox    # attribute only (NeRFNGPNet.initialize is a no-op once `bbox` exists)
     return model, betas
 
 

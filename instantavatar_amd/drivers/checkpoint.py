@@ -6,17 +6,20 @@ reported and ignored on load."""
 import torch
 
 
-def save_checkpoint(model, path, optimizer=None, epoch=0):
+def save_checkpoint(model, path, optimizer=None, epoch=0, scheduler=None):
     ckpt = {"state_dict": model.state_dict(), "global_step": int(getattr(model, "global_step", 0)), "epoch": int(epoch)}
     if optimizer is not None:
         ckpt["optimizer_states"] = [optimizer.state_dict()]
+    if scheduler is not None:
+        ckpt["lr_schedulers"] = [scheduler.state_dict()]
     torch.save(ckpt, path)
     return path
 
 
-def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True):
+def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, optimizer=None, scheduler=None):
     """Returns (missing, unexpected).  The tcnn parameter vectors must have the tcnn-v1.6 layout this
-    package restates ([MLP weights..., grid]); a size mismatch raises."""
+    package restates ([MLP weights..., grid]); a size mismatch raises.  `optimizer` / `scheduler`: restored
+    from Lightning's `optimizer_states[0]` / `lr_schedulers[0]` when the checkpoint holds them (resume)."""
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     own = model.state_dict()
@@ -43,4 +46,8 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True):
         if grid is not None and hasattr(grid, "pack_bits") and grid.density_field.is_cuda:
             grid.pack_bits()  # the kernels read the bit-packed mirror of density_field
     model.global_step = int(ckpt.get("global_step", 0)) if isinstance(ckpt, dict) else 0
+    if optimizer is not None and isinstance(ckpt, dict) and ckpt.get("optimizer_states"):
+        optimizer.load_state_dict(ckpt["optimizer_states"][0])
+    if scheduler is not None and isinstance(ckpt, dict) and ckpt.get("lr_schedulers"):
+        scheduler.load_state_dict(ckpt["lr_schedulers"][0])
     return missing, unexpected

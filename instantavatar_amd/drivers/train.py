@@ -16,7 +16,7 @@ import torch
 
 from .. import synthetic
 from ..pipeline import build_synthetic_model, make_batch
-from ..training import NeRFLoss, configure_optimizer, training_step
+from ..training import NeRFLoss, configure_optimizer, configure_scheduler, training_step
 from . import checkpoint as ckpt_io
 
 
@@ -43,20 +43,28 @@ def synthetic_batches(device, teacher, res=256, n_frames=8, n_rays=4096, seed=12
         i += 1
 
 
-def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout):
-    """`steps` iterations of training_step; returns the last losses (device tensors)."""
+def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout, scheduler=None,
+        steps_per_epoch=None, max_epochs=None, world_size=1):
+    """`steps` iterations of training_step; returns (last losses (device tensors), optimizer, scheduler).
+    The reference steps its LambdaLR `(1 - epoch / max_epochs) ** 1.5` once per epoch (DNeRF.py:52-55, Lightning's
+    default interval): pass `steps_per_epoch` (= frames of the sequence) and `max_epochs` to get the same decay."""
     optimizer = optimizer or configure_optimizer(model)
+    if scheduler is None and steps_per_epoch and max_epochs:
+        scheduler = configure_scheduler(optimizer, max_epochs)
     loss_fn = loss_fn or NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
     model.train()
     t0 = time.perf_counter()
     losses = None
     for it, batch in zip(range(steps), batches):
-        losses = training_step(model, batch, optimizer, loss_fn)
+        losses = training_step(model, batch, optimizer, loss_fn, world_size=world_size)
+        if scheduler is not None and steps_per_epoch and model.global_step % steps_per_epoch == 0:
+            scheduler.step()
         if log_every and (it + 1) % log_every == 0:
             torch.cuda.synchronize()
-            print("step %d  loss %.5f  mse %.5f  %.0f it/s" % (model.global_step, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
-                                                               (it + 1) / (time.perf_counter() - t0)), file=out)
-    return losses, optimizer
+            print("step %d  loss %.5f  mse %.5f  lr %.2e  %.0f it/s" % (
+                model.global_step, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
+                optimizer.param_groups[0]["lr"], (it + 1) / (time.perf_counter() - t0)), file=out)
+    return losses, optimizer, scheduler
 
 
 def main(argv=None):
@@ -67,6 +75,8 @@ def main(argv=None):
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--ckpt", default="checkpoints/last.ckpt")
     ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--steps-per-epoch", type=int, default=8, help="frames per epoch (LR decays once per epoch)")
+    ap.add_argument("--max-epochs", type=int, default=200, help="confs/SNARF_NGP.yaml scheduler.max_epochs")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("train: needs a GPU (the product path has no CPU fallback)")
@@ -74,12 +84,17 @@ def main(argv=None):
     teacher, _, _ = build_synthetic_model(device)
     model, _, _ = build_synthetic_model(device)
     model.net_coarse.reset_parameters()
+    opt = configure_optimizer(model)
+    sched = configure_scheduler(opt, args.max_epochs)
     if args.resume and os.path.exists(args.ckpt):
-        ckpt_io.load_checkpoint(model, args.ckpt, map_location=device)
-        print("resumed from %s at step %d" % (args.ckpt, model.global_step))
-    losses, opt = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps)
+        # parameters, buffers, global_step AND the optimiser moments / LR-scheduler epoch: a resumed run
+        # continues the interrupted one instead of restarting Adam from zero moments
+        ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, optimizer=opt, scheduler=sched)
+        print("resumed from %s at step %d (lr %.2e)" % (args.ckpt, model.global_step, opt.param_groups[0]["lr"]))
+    losses, opt, sched = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps, optimizer=opt, scheduler=sched,
+                             steps_per_epoch=args.steps_per_epoch, max_epochs=args.max_epochs)
     os.makedirs(os.path.dirname(os.path.abspath(args.ckpt)), exist_ok=True)
-    ckpt_io.save_checkpoint(model, args.ckpt, optimizer=opt)
+    ckpt_io.save_checkpoint(model, args.ckpt, optimizer=opt, scheduler=sched, epoch=sched.last_epoch)
     print("saved %s (step %d, mse %.5f)" % (args.ckpt, model.global_step, float(losses["mse_loss"])))
     return 0
 

@@ -136,10 +136,15 @@ class DensityGrid(torch.nn.Module):
         self._postprocess(density)
 
     # -- training-time grid ---------------------------------------------------------
-    def update(self, deformer, net, step):
-        """density_grid.py:46-92 (smpl_init bootstrap, which needs kaolin, is out of scope)."""
+    def update(self, deformer, net, step, reduce_hook=None, jitter=None):
+        """density_grid.py:46-92.  `reduce_hook(density_cached)` (optional) runs between the EMA update
+        and the thresholding: data-parallel training MAX-reduces the cache there, so `density_field`,
+        the returned `valid` mask and the occupancy bits all come from the reduced cache, once.
+        `jitter` ([G,G,G,3] in [0,1)) may be injected for reproducible tests (reference: torch.rand_like)."""
         G = self.grid_size
-        coords = denormalize(self.coords + torch.rand_like(self.coords) / G, self.aabb)
+        if jitter is None:
+            jitter = torch.rand_like(self.coords)
+        coords = denormalize(self.coords + jitter.reshape(self.coords.shape).to(self.coords) / G, self.aabb)
         with torch.enable_grad():
             _, density = deformer(coords.reshape(-1, 3), net, eval_mode=False)
         density = density.clip(min=0).reshape(coords.shape[:-1])
@@ -147,6 +152,8 @@ class DensityGrid(torch.nn.Module):
         if step < 500 and self.smpl_init:
             raise NotImplementedError("smpl_init occupancy bootstrap (kaolin mesh distances) is out of scope")
         self.density_cached = torch.maximum(self.density_cached * 0.8, density.detach())
+        if reduce_hook is not None:
+            reduce_hook(self.density_cached)
         self._postprocess(self.density_cached)
         density = 1 - torch.exp(0.01 * -F.relu(density))
         valid = self.density_field if step < 500 else old

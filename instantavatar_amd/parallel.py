@@ -2,9 +2,18 @@
 RCCL over xGMI on the MI355X node, "gloo" in the CPU tests).
 
 The hot path shards over independent units -- frames at inference (no data-path
-collective), frames + ray batches at training (one gradient all-reduce per step,
-instantavatar_amd.training.all_reduce_grads, plus a MAX reduction of the cached
-occupancy densities every 20 steps so all ranks threshold the same field)."""
+collective), frames + ray batches at training:
+
+* start / resume: `broadcast_module_state` makes every replica bit-identical to rank 0
+  (parameters AND buffers: the cached occupancy densities are state too);
+* every step: ONE gradient average.  The 52 MB hash-table gradient is produced last in the
+  backward pass, level group by level group (`ia_hashgrid_bwd_levels`); `GradReducer` starts the
+  all-reduce of a finished group on RCCL's stream while the next group is still being scattered,
+  so only the last bucket's transfer is exposed.  xGMI is point-to-point (7 links per GPU), so a
+  few multi-megabyte buckets beat many small ones: 4 buckets of ~6-16 MB;
+* every 20 steps: MAX reduction of the cached occupancy densities (1 MB) between the EMA update
+  and the thresholding, so that all ranks march the same grid.
+"""
 import torch
 
 
@@ -13,10 +22,131 @@ def shard_frames(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
 def reduce_density_cache(density_cached, world_size):
     """In-place MAX all-reduce of DensityGrid.density_cached (1 MB)."""
     if world_size <= 1:
         return density_cached
-    import torch.distributed as dist
+    dist = _dist()
     dist.all_reduce(density_cached, op=dist.ReduceOp.MAX)
     return density_cached
+
+
+def broadcast_module_state(module, world_size, src=0):
+    """Start-up / resume broadcast: parameters and buffers of `module` from rank `src`.
+    Replicas must not rely on equal seeds: a resumed checkpoint, a different library version or a
+    rank-dependent RNG draw would silently fork them."""
+    if world_size <= 1:
+        return
+    dist = _dist()
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.dtype == torch.bool:  # NCCL has no bool: go through uint8
+                u = t.to(torch.uint8)
+                dist.broadcast(u, src=src)
+                t.copy_(u.bool())
+            else:
+                dist.broadcast(t.data, src=src)
+    if hasattr(module, "modules"):
+        for m in module.modules():
+            if hasattr(m, "mark_updated"):
+                m.mark_updated()       # fp16 shadows / MFMA fragments follow the new master weights
+            if hasattr(m, "pack_bits") and getattr(m, "density_field", None) is not None and m.density_field.is_cuda:
+                m.pack_bits()          # bit-packed occupancy follows density_field
+
+
+class GradReducer:
+    """Gradient averaging with the transfers started from inside the backward pass.
+
+    `reduce_async(t)` is called by the producer of a gradient bucket right after the kernel that
+    finishes it has been enqueued: torch's process group makes the collective wait (event) for the
+    work enqueued so far on the current stream and runs it on the communication stream, so later
+    backward kernels overlap with the transfer.  `finish(params)` reduces whatever was not handed
+    in, waits for everything and turns sums into means."""
+
+    def __init__(self, world_size):
+        self.world_size = world_size
+        self._works = []
+        self._ranges = []   # (first byte, last byte) already handed in
+        self._fields = 0    # field calls recorded in this step's autograd graph, not yet back-propagated
+
+    @property
+    def active(self):
+        return self.world_size > 1
+
+    def field_forward(self):
+        self._fields += 1
+
+    def field_backward_done(self):
+        """called once per field backward; True for the LAST one of the step: from then on the table gradient
+        receives no further contribution and finished slices may be sent"""
+        self._fields -= 1
+        return self._fields == 0
+
+    def _op(self):
+        dist = _dist()
+        # RCCL averages in the collective; gloo (CPU tests) has no AVG: sum now, scale in finish()
+        if dist.get_backend() == "nccl":
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, True
+
+    def reduce_async(self, t):
+        if not self.active:
+            return
+        assert t.is_contiguous()
+        op, scale = self._op()
+        w = _dist().all_reduce(t, op=op, async_op=True)
+        self._works.append((w, t, scale))
+        b0 = t.data_ptr()
+        self._ranges.append((b0, b0 + t.numel() * t.element_size()))
+
+    def _covered(self, t):
+        """bytes of `t` already handed in, as a list of (start, end) element ranges still missing"""
+        b0, b1, es = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t.element_size()
+        segs = sorted((max(a, b0), min(b, b1)) for a, b in self._ranges if a < b1 and b > b0)
+        missing, cur = [], b0
+        for a, b in segs:
+            if a > cur:
+                missing.append(((cur - b0) // es, (a - b0) // es))
+            cur = max(cur, b)
+        if cur < b1:
+            missing.append(((cur - b0) // es, (b1 - b0) // es))
+        return missing
+
+    def finish(self, params):
+        if not self.active:
+            return
+        for p in params:
+            if p.grad is None and p.requires_grad:
+                p.grad = torch.zeros_like(p)   # every rank must issue the same collectives
+            g = p.grad
+            if g is None:
+                continue
+            flat = g.view(-1) if g.is_contiguous() else None
+            if flat is None:
+                g = p.grad = g.contiguous()
+                flat = g.view(-1)
+            for a, b in self._covered(flat):
+                self.reduce_async(flat[a:b])
+        for w, t, scale in self._works:
+            w.wait()
+            if scale:
+                t.div_(self.world_size)
+        self._works, self._ranges, self._fields = [], [], 0
+
+
+#: the reducer of the training step in flight (set by training.training_step, read by the autograd
+#: functions that produce gradient buckets)
+_current = [None]
+
+
+def current_reducer():
+    return _current[0]
+
+
+def set_current_reducer(r):
+    _current[0] = r

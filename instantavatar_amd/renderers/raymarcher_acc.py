@@ -193,7 +193,7 @@ class Raymarcher(torch.nn.Module):
         if sync and not getattr(self, "_graph_capture", False):
             # one device->host read per frame (4 bytes) to validate the hint
             while int(self._n_alive_dev[0].item()) > 0 and total < 2 * self.MAX_SAMPLES:
-                launch(4, 1)
+                launch(4, total)   # resume = iterations already enqueued for this frame
                 total += 4
                 self._iters_hint = total
         self.last_iters = total

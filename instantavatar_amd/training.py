@@ -57,10 +57,21 @@ class _FieldFn(torch.autograd.Function):
         ctx.need_dx = x.requires_grad
         ctx.n_dev = n_dev
         ctx.save_for_backward(xc, acts, rgb)
+        from . import parallel
+        red = parallel.current_reducer()
+        if red is not None:
+            red.field_forward()   # the last backward of the step starts the bucketed all-reduce
         return rgb, sigma
 
     @staticmethod
     def backward(ctx, d_rgb, d_sigma):
+        """Gradients of the two parameter vectors are ACCUMULATED IN PLACE into `param.grad` (created
+        zero-filled on the first contribution after `zero_grad(set_to_none=True)`) and `None` is returned
+        for them: the 52 MB table gradient is written once, by the scatter kernel, into the buffer the
+        optimiser reads -- no autograd copy -- and, with several ranks, finished level groups are handed
+        to the all-reduce while the remaining groups are still being scattered (parallel.GradReducer).
+        Consequence: `torch.autograd.grad(..., params)` is not supported for these two tensors; use
+        `.backward()` and read `.grad` (as Lightning's training loop does)."""
         net = ctx.net
         xc, acts, rgb = ctx.saved_tensors
         V = xc.shape[0]
@@ -71,13 +82,13 @@ class _FieldFn(torch.autograd.Function):
         # cast to half (tcnn relies on a fixed 1024x loss scale, DNeRF.py:58); device scalar, no sync
         amax = torch.maximum((d_rgb * rgb * (1 - rgb)).abs().max(), d_sigma.abs().max()).clamp(min=1e-30)
         S = (1024.0 / amax).reshape(1)
-        g_enc = torch.zeros_like(net.encoder.params)
-        g_col = torch.zeros_like(net.color_net.params)
+        g_enc = _grad_buffer(net.encoder.params)
+        g_col = _grad_buffer(net.color_net.params)
         n1 = net.sig_w1_size
+        L = _lib.lib()
         if FUSED_MLP_BACKWARD:
             dfeat = torch.empty((V, nf), device=xc.device)
             base_e, base_c = g_enc.data_ptr(), g_col.data_ptr()
-            L = _lib.lib()
             ws = torch.empty(int(L.ia_field_bwd_workspace_bytes(V, net.n_levels)), dtype=torch.uint8, device=xc.device)
             _lib.check(L.ia_field_bwd(_lib.ptr(acts), _lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V,
                                       _lib.ptr(ctx.n_dev), _lib.ptr(S), C.byref(net.field_desc()), _lib.ptr(dfeat), base_e,
@@ -85,12 +96,42 @@ class _FieldFn(torch.autograd.Function):
                                       _lib.stream()), "ia_field_bwd")
         else:
             dfeat = _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col)
-        dtable = g_enc[n1 + 1024:]
+        w_end = n1 + 1024
+        dtable = g_enc[w_end:]
         dx = (torch.zeros if ctx.n_dev is not None else torch.empty)((V, 3), device=xc.device) if ctx.need_dx else None
-        _lib.check(_lib.lib().ia_hashgrid_bwd(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
-                                              _lib.ptr(dfeat), dtable.data_ptr(), _lib.ptr(dx), _lib.stream()),
-                   "ia_hashgrid_bwd")
-        return dx, g_enc, g_col, None, None
+        from . import parallel
+        red = parallel.current_reducer()
+        last = red is not None and red.active and red.field_backward_done()  # last field call of this step's graph?
+        if last and dx is None:
+            # level groups, finest first; each finished slice of the table gradient goes to RCCL while the next
+            # group is scattered.  The MLP weight gradients travel with the last (small, dense-level) bucket.
+            off = [int(o) for o in net.hash_desc.offset[:net.n_levels + 1]]
+            red.reduce_async(g_col)
+            for l0, l1 in _level_groups(net.n_levels):
+                _lib.check(L.ia_hashgrid_bwd_levels(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
+                                                    _lib.ptr(dfeat), dtable.data_ptr(), l0, l1, _lib.stream()),
+                           "ia_hashgrid_bwd_levels")
+                lo = w_end + 2 * off[l0] if l0 > 0 else 0   # the bucket of the coarsest group starts at the MLP weights
+                red.reduce_async(g_enc[lo:w_end + 2 * off[l1]])
+        else:
+            _lib.check(L.ia_hashgrid_bwd(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
+                                         _lib.ptr(dfeat), dtable.data_ptr(), _lib.ptr(dx), _lib.stream()),
+                       "ia_hashgrid_bwd")
+        return dx, None, None, None, None
+
+
+def _grad_buffer(p):
+    """`p.grad`, created zero-filled on the first contribution of a step."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _level_groups(n_levels, n_groups=4):
+    """[(l0, l1)] finest first: 16 levels -> (12,16) (8,12) (4,8) (0,4): three 16.8 MB buckets + the dense levels"""
+    per = max(n_levels // n_groups, 1)
+    cuts = list(range(0, n_levels, per))
+    return [(c, min(c + per, n_levels)) for c in reversed(cuts)]
 
 
 #: MLP backward through the fused MFMA kernel (`ia_field_bwd`).  False = the GEMM formulation
@@ -127,9 +168,9 @@ def _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col):
     inv = 1.0 / S
     dfeat = (_mm_f32(dH1, W1h) * inv).contiguous()
     n1 = net.sig_w1_size
-    g_enc[:n1] = (dW1 * inv).reshape(-1)
-    g_enc[n1:n1 + 1024] = (dW2 * inv).reshape(-1)
-    g_col.copy_(torch.cat([(dWc1 * inv).reshape(-1), (dWc2 * inv).reshape(-1), (dWc3 * inv).reshape(-1)]))
+    g_enc[:n1] += (dW1 * inv).reshape(-1)
+    g_enc[n1:n1 + 1024] += (dW2 * inv).reshape(-1)
+    g_col += torch.cat([(dWc1 * inv).reshape(-1), (dWc2 * inv).reshape(-1), (dWc3 * inv).reshape(-1)])
     return dfeat
 
 
@@ -193,7 +234,7 @@ class NeRFLoss(torch.nn.Module):
 
 def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
     """DNeRFModel.configure_optimizers (DNeRF.py:32-59): one Adam, hash encoding and
-    the rest in separate groups, GradScaler(1024) kept for interface parity."""
+    the rest in separate groups."""
     enc, rest = [], []
     for name, p in model.named_parameters():
         (enc if "encoder" in name else rest).append(p)
@@ -202,31 +243,72 @@ def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
     return opt
 
 
-def all_reduce_grads(model, world_size):
-    """Data-parallel gradient averaging: one RCCL all-reduce per parameter tensor
-    (the 52 MB hash-table gradient is ONE flat bucket; xGMI is point-to-point, so
-    few large collectives beat many small ones)."""
+def configure_scheduler(optimizer, max_epochs):
+    """DNeRF.py:52-55: LambdaLR(lambda epoch: (1 - epoch / max_epochs) ** 1.5), stepped once per EPOCH
+    (Lightning's default interval); `fit` in drivers/train.py calls `.step()` every `steps_per_epoch`."""
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda epoch: (1 - min(epoch, max_epochs) / max_epochs) ** 1.5)
+
+
+def _non_finite_flag(params):
+    """float32 device scalar: 1.0 when any gradient holds an inf / NaN (no host synchronisation).
+    sum() propagates both; 52 MB are read once (~10 us)."""
+    tot = None
+    for p in params:
+        if p.grad is not None:
+            t = p.grad.sum()
+            tot = t if tot is None else tot + t
+    if tot is None:
+        return None
+    return (~torch.isfinite(tot)).float()
+
+
+def optimizer_step_skip_non_finite(optimizer, params):
+    """GradScaler.step's inf/NaN skip (DNeRF.py:151-154: `self.scaler.step(optimizer)`) without its host
+    synchronisation: torch's fused Adam takes a device-side `found_inf` flag and leaves parameters, moments
+    and step counters untouched when it is set.  One non-finite gradient would otherwise poison the whole
+    52 MB table (the per-call gradient scale S = 1024 / amax turns a single NaN into NaN everywhere).
+    Non-fused optimisers (CPU tests) fall back to a host check.  Returns the flag (device scalar)."""
+    flag = _non_finite_flag(params)
+    fused = all(g.get("fused") for g in optimizer.param_groups)
+    if flag is None:
+        optimizer.step()
+        return flag
+    if fused and flag.is_cuda:
+        optimizer.grad_scale, optimizer.found_inf = None, flag
+        try:
+            optimizer.step()
+        finally:
+            optimizer.grad_scale, optimizer.found_inf = None, None
+    elif not bool(flag):
+        optimizer.step()
+    return flag
+
+
+def all_reduce_grads(model, world_size, reducer=None):
+    """Data-parallel gradient averaging.  With a `parallel.GradReducer` that was active during backward the
+    big buckets are already in flight (started from inside the hash-grid backward); this reduces what is
+    left, waits, and turns sums into means.  Without one: a fresh reducer, i.e. one all-reduce per
+    parameter tensor (the 52 MB hash-table gradient as ONE flat bucket; xGMI is point-to-point, so few
+    large collectives beat many small ones)."""
     if world_size <= 1:
         return
-    import torch.distributed as dist
-    for p in model.parameters():
-        if p.grad is not None:
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-            p.grad.div_(world_size)
+    from .parallel import GradReducer
+    (reducer or GradReducer(world_size)).finish([p for p in model.parameters()])
 
 
 def update_density_grid(model, world_size=1):
-    """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the
-    cached densities are MAX-reduced so that every rank thresholds the same field."""
+    """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the cached densities are
+    MAX-reduced between the EMA update and the thresholding (DensityGrid.update's reduce hook), so every
+    rank thresholds -- and regularises with -- the same field, once."""
     N = 20
     if model.global_step % N != 0:
         return None
     grid = model.renderer.density_grid_train
-    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step)
+    hook = None
     if world_size > 1:
         from .parallel import reduce_density_cache
-        reduce_density_cache(grid.density_cached, world_size)
-        grid._postprocess(grid.density_cached)
+        hook = lambda cached: reduce_density_cache(cached, world_size)
+    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook)
     inv = (~valid).to(density.dtype)   # mean over the cells outside the grid, without a boolean-mask gather (host sync)
     reg = N * (density * inv).sum() / inv.sum().clamp(min=1.0)
     if model.global_step < 500:
@@ -236,20 +318,27 @@ def update_density_grid(model, world_size=1):
 
 def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False):
     """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs."""
+    from . import parallel
     model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
     model.deformer.prepare_deformer(batch)
-    reg = update_density_grid(model, world_size)
-    model.net_coarse.initialize(model.deformer.bbox)
-    use_noise = model.global_step < 1000 and not is_refine
-    predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
-    losses = loss_fn(predicts, batch)
-    if reg is not None and not is_refine:
-        losses["reg"] = reg
-        losses["loss"] = losses["loss"] + reg
-    optimizer.zero_grad(set_to_none=True)
-    losses["loss"].backward()
-    all_reduce_grads(model, world_size)
-    optimizer.step()
+    reducer = parallel.GradReducer(world_size)
+    parallel.set_current_reducer(reducer if world_size > 1 else None)
+    try:
+        reg = update_density_grid(model, world_size)
+        model.net_coarse.initialize(model.deformer.bbox)
+        use_noise = model.global_step < 1000 and not is_refine
+        predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
+        losses = loss_fn(predicts, batch)
+        if reg is not None and not is_refine:
+            losses["reg"] = reg
+            losses["loss"] = losses["loss"] + reg
+        optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        all_reduce_grads(model, world_size, reducer)
+    finally:
+        parallel.set_current_reducer(None)
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params)
     if hasattr(model.net_coarse, "mark_updated"):
         model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
     model.global_step += 1

@@ -31,6 +31,8 @@ EXTS = {
     "ref_precompute": ["deformers/fast_snarf/cuda/precompute/precompute.cpp",
                        "deformers/fast_snarf/cuda/precompute/precompute.cu"],
     "ref_raymarch": ["renderers/cuda/raymarcher.cpp", "renderers/cuda/raymarcher.cu"],
+    # pytorch3d's CPU KNN (plain C++, no hipify): the reference source + our binding stub oracle/ref_knn_bind.cpp
+    "ref_knn": ["../third_parties/pytorch3d/cuda/knn_cpu.cpp", "@oracle/ref_knn_bind.cpp"],
 }
 
 
@@ -51,7 +53,7 @@ def build(force=False):
         staged = []
         for s in srcs:
             t = os.path.join(stage, os.path.basename(s))
-            shutil.copy(os.path.join(REF, s), t)
+            shutil.copy(os.path.join(HERE, os.path.basename(s)) if s.startswith("@oracle/") else os.path.join(REF, s), t)
             if t.endswith("raymarcher.cu"):
                 txt = open(t).read()
                 for v in ("rays_o", "sigma_vals"):

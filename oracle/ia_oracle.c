@@ -684,6 +684,29 @@ void orc_occupancy_from_density(const float *density, int G, uint8_t *occ,
 /* distance blend + 30 Laplacian smoothing passes.  pts [N,3] (N = d*h*w in   */
 /* (d,h,w) order), verts [Vn,3], vw [Vn,24] -> weights [24,d,h,w].            */
 /* ------------------------------------------------------------------------ */
+/* K nearest vertices of every point: squared distances ascending + indices
+ * (pytorch3d knn_points as called at deformer_torch.py:227; same distance expression
+ * dx*dx + dy*dy + dz*dz summed in x,y,z order as third_parties/pytorch3d/cuda/knn_cpu.cpp:40-49,
+ * strict `<` so that the earlier index wins a tie, as its priority queue does).            */
+void orc_knn(const float *pts, long N, const float *verts, int Vn, int K, float *dist_out,
+             long long *idx_out) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (long i = 0; i < N; i++) {
+    float bd[64]; int bi[64]; int nb = 0;
+    float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    for (int v = 0; v < Vn; v++) {
+      float dx = px - verts[v * 3], dy = py - verts[v * 3 + 1], dz = pz - verts[v * 3 + 2];
+      float dist = dx * dx + dy * dy + dz * dz;
+      if (nb < K || dist < bd[nb - 1]) {
+        int j = nb < K ? nb++ : K - 1;
+        while (j > 0 && bd[j - 1] > dist) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; j--; }
+        bd[j] = dist; bi[j] = v;
+      }
+    }
+    for (int k = 0; k < K; k++) { dist_out[i * K + k] = bd[k]; idx_out[i * K + k] = bi[k]; }
+  }
+}
+
 void orc_query_weights_smpl(const float *pts, long N, const float *verts,
                             int Vn, const float *vw, int d, int h, int w,
                             int n_smooth, float *weights) {

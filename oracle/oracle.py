@@ -186,6 +186,16 @@ def deformer_initialize(body, betas, cano_pose, resolution=128, n_smooth=30, glo
                 grid_denorm=gd)
 
 
+def knn(pts, verts, K=30):
+    """pytorch3d knn_points (deformer_torch.py:227): (squared distances ascending [N,K], indices [N,K])."""
+    pts, verts = _f32(pts).reshape(-1, 3), _f32(verts).reshape(-1, 3)
+    assert K <= 64
+    d = np.empty((len(pts), K), np.float32)
+    i = np.empty((len(pts), K), np.int64)
+    lib().orc_knn(_p(pts), C.c_long(len(pts)), _p(verts), C.c_int(len(verts)), C.c_int(K), _p(d), _p(i))
+    return d, i
+
+
 def prepare_deformer(body, init, betas, body_pose, global_orient, transl):
     """snarf_deformer.py:71-93 -> tfs [24,4,4], w2s [4,4] and precompute."""
     so = smpl_forward(body, betas, body_pose, global_orient, transl, want_verts=False)
@@ -293,6 +303,39 @@ def density_grid_initialize(world, jitter, G=64):
         _, d = deform_query(coords.astype(np.float32), world, eval_mode=True)
         density = np.maximum(density, d)
     return aabb, density, occupancy_from_density(density, G)
+
+
+#: aabb of the training occupancy grid (Raymarcher.__init__, raymarcher_acc.py:56)
+TRAIN_AABB = np.array([[-1.25, -1.55, -1.25], [1.25, 0.95, 1.25]], np.float32)
+
+
+def density_grid_update(world, density_cached, density_field_old, jitter, step, G=64, aabb=TRAIN_AABB):
+    """DensityGrid.update, the branch every non-`smpl_init` configuration takes (density_grid.py:46-51,77-92).
+    jitter [G^3,3] replaces torch.rand_like (:47).  Returns dict(density_cached, density_field, density, valid):
+    the new state plus the two values handed to DNeRFModel.update_density_grid."""
+    idx = np.arange(G, dtype=np.float32)
+    cx, cy, cz = np.meshgrid(idx, idx, idx, indexing="ij")
+    coords0 = (np.stack([cx, cy, cz], -1).reshape(-1, 3) / np.float32(G)).astype(np.float32)
+    coords = ((coords0 + _f32(jitter).reshape(-1, 3) / np.float32(G)) * (aabb[1] - aabb[0]) + aabb[0]).astype(np.float32)
+    _, density = deform_query(coords, world, eval_mode=False)           # :48-49 (invalid candidates: -1e5)
+    density = np.maximum(density, np.float32(0)).astype(np.float32)     # :50 clip(min=0)
+    cached = np.maximum(_f32(density_cached).reshape(-1) * np.float32(0.8), density).astype(np.float32)  # :77
+    field = occupancy_from_density(cached, G)                           # :78-85
+    dens_out = (np.float32(1) - np.exp(np.float32(0.01) * -np.maximum(density, np.float32(0)))).astype(np.float32)  # :87
+    valid = field.astype(bool) if step < 500 else np.asarray(density_field_old).astype(bool)             # :88-91
+    return dict(density_cached=cached.reshape(G, G, G), density_field=field.reshape(G, G, G).astype(bool),
+                density=dens_out.reshape(G, G, G), valid=valid.reshape(G, G, G))
+
+
+def update_density_grid_reg(density, valid, step, N=20):
+    """DNeRFModel.update_density_grid (DNeRF.py:99-110): reg = N * mean(density outside the grid)
+    (+ 0.5 * mean(density) for the first 500 steps)."""
+    d = _f32(density).reshape(-1).astype(np.float64)
+    out = d[~np.asarray(valid).reshape(-1)]
+    reg = N * (out.mean() if len(out) else float("nan"))
+    if step < 500:
+        reg += 0.5 * d.mean()
+    return float(reg)
 
 
 def render_test(o, d, near, far, occ, aabb, model, MAX_SAMPLES=256, MAX_BATCH_SIZE=291600, bg=None):

@@ -316,3 +316,69 @@ def test_render_train_oracle_is_consistent(oracle, small_world):
     assert np.abs((a["rgb"] - b["rgb"]) - (1 - a["alpha"])[:, None]).max() < 2e-5      # rgb = sum w c + T_end * bg
     t = oracle.render_test(o, d, near, far, occ, aabb, lambda p: oracle.deform_query(p, world, True))
     assert np.abs(a["alpha"] - t["alpha"]).mean() < 0.02
+
+
+# ---------------------------------------------------------------- a20: K-nearest-neighbour pin
+def _knn_inputs():
+    body = syn.make_body()
+    verts = np.ascontiguousarray(body["v_template"], np.float32)
+    rng = np.random.RandomState(3)
+    lo, hi = verts.min(0) - 0.2, verts.max(0) + 0.2
+    pts = (rng.rand(1500, 3) * (hi - lo) + lo).astype(np.float32)
+    pts[:200] = verts[rng.randint(0, len(verts), 200)] + rng.randn(200, 3).astype(np.float32) * 1e-3  # near-surface queries
+    return pts, verts
+
+
+def test_knn_oracle_matches_pytorch3d_reference(oracle):
+    """oracle.knn (the K = 30 neighbour search inside oracle.deformer_initialize / orc_query_weights_smpl) against the
+    reference's own pytorch3d KNearestNeighborIdxCpu (third_parties/pytorch3d/cuda/knn_cpu.cpp:13-69), compiled
+    unmodified into oracle/_ref/ref_knn.so by oracle/build_ref.py -- and against the frozen golden of the same run."""
+    pts, verts = _knn_inputs()
+    d, i = oracle.knn(pts, verts, 30)
+    gpath = os.path.join(os.path.dirname(__file__), "golden", "knn_golden.npz")
+    g = np.load(gpath)
+    assert np.array_equal(i[:256], g["idx"]) and np.array_equal(d[:256], g["dist"])   # frozen reference outputs
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_knn.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/ref_knn.so not built (needs /root/reference); golden vectors were checked")
+    from oracle import build_ref
+    ref = build_ref.load_ext("ref_knn")
+    n1, n2 = torch.tensor([len(pts)]), torch.tensor([len(verts)])
+    ri, rd = ref.knn_points_idx_cpu(torch.from_numpy(pts)[None], torch.from_numpy(verts)[None], n1, n2, 2, 30)
+    assert np.array_equal(ri[0].numpy(), i), "neighbour sets / order differ from pytorch3d"
+    assert np.array_equal(rd[0].numpy(), d), "squared distances differ from pytorch3d"
+
+
+# ---------------------------------------------------------------- a17: training-time occupancy update
+def test_density_grid_update_oracle_semantics(oracle, small_world):
+    """oracle.density_grid_update restates density_grid.py:46-92: EMA 0.8 with torch.maximum, thresholding on the
+    CACHE (not on the fresh densities), `valid` = new field before step 500 and the previous field afterwards,
+    and DNeRF.py:99-110's regulariser."""
+    body, init, fp, world = small_world
+    G = 16
+    rng = np.random.RandomState(0)
+    cached = np.zeros((G, G, G), np.float32)
+    field = np.zeros((G, G, G), bool)
+    aabb = np.stack([world["voxel_d"].reshape(3, -1).min(1), world["voxel_d"].reshape(3, -1).max(1)]).astype(np.float32)
+    outs = []
+    for step in (0, 20, 520):
+        jit = rng.rand(G ** 3, 3).astype(np.float32)
+        out = oracle.density_grid_update(world, cached, field, jit, step, G=G, aabb=aabb)
+        fresh = -100.0 * np.log1p(-out["density"].astype(np.float64))   # invert 1 - exp(-0.01 d)
+        assert np.allclose(out["density_cached"], np.maximum(cached * np.float32(0.8), fresh), rtol=2e-3, atol=1e-3)
+        assert (out["density_cached"] >= cached * np.float32(0.8) - 1e-6).all()
+        assert np.array_equal(out["density_field"], oracle.occupancy_from_density(out["density_cached"].reshape(-1), G).reshape(G, G, G).astype(bool))
+        assert np.array_equal(out["valid"], out["density_field"] if step < 500 else field)
+        reg = oracle.update_density_grid_reg(out["density"], out["valid"], step)
+        expect = 20 * out["density"][~out["valid"]].astype(np.float64).mean() + (0.5 * out["density"].astype(np.float64).mean() if step < 500 else 0)
+        assert abs(reg - expect) < 1e-9
+        cached, field = out["density_cached"], out["density_field"]
+        outs.append(out)
+    assert outs[0]["density_field"].any() and (outs[0]["density"] >= 0).all() and (outs[0]["density"] < 1).all()
+
+
+def test_voxeliser_has_no_cpu_route():
+    from instantavatar_amd import _lib
+    from instantavatar_amd.deformers.fast_snarf.forward_deformer import voxelise_skinning_weights
+    with pytest.raises(_lib.IAError):
+        voxelise_skinning_weights(torch.zeros(8, 3), torch.zeros(10, 3), torch.zeros(10, 24), (2, 2, 2))
