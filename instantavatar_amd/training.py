@@ -296,7 +296,7 @@ def all_reduce_grads(model, world_size, reducer=None):
     (reducer or GradReducer(world_size)).finish([p for p in model.parameters()])
 
 
-def update_density_grid(model, world_size=1):
+def update_density_grid(model, world_size=1, jitter=None):
     """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the cached densities are
     MAX-reduced between the EMA update and the thresholding (DensityGrid.update's reduce hook), so every
     rank thresholds -- and regularises with -- the same field, once."""
@@ -308,7 +308,7 @@ def update_density_grid(model, world_size=1):
     if world_size > 1:
         from .parallel import reduce_density_cache
         hook = lambda cached: reduce_density_cache(cached, world_size)
-    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook)
+    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook, jitter=jitter)
     inv = (~valid).to(density.dtype)   # mean over the cells outside the grid, without a boolean-mask gather (host sync)
     reg = N * (density * inv).sum() / inv.sum().clamp(min=1.0)
     if model.global_step < 500:

@@ -1,0 +1,119 @@
+"""a17 and a20 on the GPU (-m gpu).
+
+a17  DensityGrid.update + DNeRFModel.update_density_grid (density_grid.py:46-92, DNeRF.py:99-110): the product's
+     training-time occupancy update (compact candidate search -> field in training mode -> arg-max gather ->
+     EMA -> occupancy post-process) against oracle.density_grid_update / oracle.update_density_grid_reg over
+     three consecutive updates that cross the `step < 500` switch, on injected jitter.
+a20  the skinning-weight voxelisation (`ia_voxelise_weights`: exact 30-NN inverse-distance blend + 30 smoothing
+     passes, deformer_torch.py:130-202,225-244) against oracle.deformer_initialize, whose neighbour search is
+     pinned against the reference's pytorch3d knn_cpu.cpp in tests/test_cpu_oracle.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from instantavatar_amd import synthetic as syn, training
+from instantavatar_amd.models.structures.density_grid import DensityGrid
+from instantavatar_amd.pipeline import build_synthetic_model, make_batch
+
+import world as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = 64
+
+
+def test_density_grid_update_matches_oracle(oracle):
+    model, body, fp, init = W.build(DEV, 64, 16)
+    poses, tr = W.poses()
+    model.deformer.prepare_deformer(make_batch(DEV, 64, poses[2], tr[2]))
+    world = W.oracle_world(oracle, body, fp, init, poses[2], tr[2])
+    grid = DensityGrid(G, aabb=model.renderer.aabb.clone()).to(DEV)
+    grid.aabb = model.renderer.aabb
+    saved = model.renderer.density_grid_train_all
+    model.renderer.density_grid_train_all = torch.nn.ModuleList([grid])
+    cached = np.zeros((G, G, G), np.float32)
+    field = np.zeros((G, G, G), bool)
+    rng = np.random.RandomState(17)
+    aabb = model.renderer.aabb.cpu().numpy()
+    assert np.array_equal(aabb, oracle.TRAIN_AABB)
+    try:
+        for step in (0, 20, 520):
+            jit = rng.rand(G ** 3, 3).astype(np.float32)
+            model.global_step = step
+            old_field = grid.density_field.clone()
+            reg = training.update_density_grid(model, jitter=torch.as_tensor(jit, device=DEV).reshape(G, G, G, 3))
+            ref = oracle.density_grid_update(world, cached, field, jit, step)
+            ref_reg = oracle.update_density_grid_reg(ref["density"], ref["valid"], step)
+            got_cached = grid.density_cached.detach().cpu().numpy()
+            got_field = grid.density_field.cpu().numpy()
+            # fp16 field outputs: equal up to Broyden validity flips at the thresholds (none expected: shared FMA convention)
+            diff = np.abs(got_cached - ref["density_cached"])
+            info = dict(step=step, cached_mismatch=float((diff > 1e-3 * np.maximum(1.0, np.abs(ref["density_cached"]))).mean()),
+                        field_flips=float((got_field != ref["density_field"]).mean()), occupied=float(ref["density_field"].mean()),
+                        reg=(float(reg), ref_reg))
+            print(info)
+            assert info["cached_mismatch"] < 2e-4, info
+            assert info["field_flips"] < 2e-4, info
+            assert info["occupied"] > 0.005, info
+            assert abs(float(reg) - ref_reg) < 2e-3 * max(1.0, abs(ref_reg)), info
+            # (`valid` -- the NEW field before step 500, the previous one afterwards, density_grid.py:88-91 -- enters `reg`)
+            assert step < 500 or old_field.any()
+            assert reg.requires_grad      # the regulariser back-propagates into the field (update() runs under enable_grad)
+            cached, field = ref["density_cached"], ref["density_field"]
+        # occupancy bits follow density_field
+        bits = grid.occ_bits[:G ** 3 // 32].cpu().numpy().view(np.uint32)
+        unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)[None]) & 1).astype(bool).reshape(G, G, G)
+        assert np.array_equal(unpacked, grid.density_field.cpu().numpy())
+    finally:
+        model.renderer.density_grid_train_all = saved
+        model.global_step = 0
+        for p in model.parameters():
+            p.grad = None
+
+
+def test_train_candidate_capacity_overflow_is_detected_and_grows(oracle):
+    """`query_train_fused` must not drop candidates silently: an undersized capacity is detected one
+    call later (deferred, no stall), counted, and the capacity grows."""
+    model, body, fp, init = W.build(DEV, 64, 16)
+    poses, tr = W.poses()
+    model.deformer.prepare_deformer(make_batch(DEV, 64, poses[2], tr[2]))
+    d = model.deformer
+    bb = d.bbox
+    pts = torch.rand((20000, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * (bb[1] - bb[0]) * 0.5 + (bb[0] + bb[1]) * 0.5 - (bb[1] - bb[0]) * 0.25
+    saved = (d.train_cand_capacity, d.train_overflow)
+    try:
+        d.train_cand_capacity, d.train_overflow = 1 << 20, 0
+        with torch.enable_grad():
+            _, s_full = d(pts, model.net_coarse, eval_mode=False)
+        d._cand_count_check()
+        n = d.last_cand_count
+        assert n > 2048 and d.train_overflow == 0
+        d.train_cand_capacity = 1024
+        with torch.enable_grad():
+            d(pts, model.net_coarse, eval_mode=False)
+            d(pts, model.net_coarse, eval_mode=False)     # the check of call 1 happens here
+        assert d.train_overflow == 1 and d.train_cand_capacity >= 2 * n
+        with torch.enable_grad():
+            _, s_again = d(pts, model.net_coarse, eval_mode=False)
+        assert torch.equal(s_full, s_again)
+    finally:
+        d.train_cand_capacity, d.train_overflow = saved
+
+
+def test_voxelise_kernel_matches_oracle_deformer_initialize(oracle):
+    """a20: SNARFDeformer.initialize -> switch_to_explicit -> query_weights_smpl on the GPU vs the oracle."""
+    res = 32
+    model, body, fp = build_synthetic_model(DEV, resolution=res)
+    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=res, n_smooth=30)
+    fd = model.deformer.deformer
+    got = fd.lbs_voxel_final[0].cpu().numpy()
+    assert got.shape == init["lbs_voxel"].shape == (24, res // 4, res, res)
+    err = np.abs(got - init["lbs_voxel"])
+    print("voxelised weights: max err %.2e, mean %.2e" % (err.max(), err.mean()))
+    assert err.max() < 5e-5
+    assert np.abs(got.sum(0) - 1).max() < 1e-5 and got.min() >= 0
+    assert np.abs(fd.offset_kernel.reshape(3).cpu().numpy() - init["offset_kernel"]).max() < 1e-6
+    assert np.abs(fd.scale_kernel.reshape(3).cpu().numpy() - init["scale_kernel"]).max() < 1e-5
+    assert np.abs(model.deformer.bbox.cpu().numpy() - init["bbox"]).max() < 1e-6
+    assert np.abs(model.deformer.tfs_inv_t[0].cpu().numpy() - init["tfs_inv_t"]).max() < 1e-5

@@ -121,26 +121,6 @@ def test_state_dict_surface_matches_reference_keys(gw):
     assert any("encoder" in n for n in names)  # optimiser grouping of DNeRF.py:42-45
 
 
-def test_voxelise_kernel_matches_torch_reference():
-    """a20: ia_voxelise_weights (K-NN blend + smoothing) against the PyTorch fp32 restatement."""
-    from instantavatar_amd.deformers.fast_snarf.forward_deformer import (voxelise_skinning_weights,
-                                                                         voxelise_skinning_weights_torch)
-    body = syn.make_body()
-    g = torch.Generator(device=DEV).manual_seed(0)
-    verts = torch.as_tensor(body["v_template"], device=DEV)
-    vw = torch.as_tensor(body["lbs_weights"], device=DEV)
-    d, h, w = 8, 32, 32
-    lo, hi = verts.min(0).values - 0.1, verts.max(0).values + 0.1
-    zz, yy, xx = torch.meshgrid(torch.linspace(0, 1, d, device=DEV), torch.linspace(0, 1, h, device=DEV),
-                                torch.linspace(0, 1, w, device=DEV), indexing="ij")
-    pts = (torch.stack([xx, yy, zz], -1).reshape(-1, 3) * (hi - lo) + lo).contiguous()
-    a = voxelise_skinning_weights(pts, verts, vw, (d, h, w))
-    b = voxelise_skinning_weights_torch(pts, verts, vw, (d, h, w))
-    assert a.shape == (24, d, h, w)
-    assert (a - b).abs().max() < 2e-5
-    assert (a.sum(0) - 1).abs().max() < 1e-5 and a.min() >= 0
-
-
 def test_animate_driver_writes_frames(tmp_path):
     """PL-free animate driver (animate.py equivalent): synthetic avatar, 3 frames at 135x135 -> RGBA PNGs
     + GIF; the frames must equal render_image_fast on the same batches."""
