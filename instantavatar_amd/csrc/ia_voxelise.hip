@@ -39,7 +39,13 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn_blend(const float *__restri
         if (d < worst) {  // replace the current worst, then find the new worst
           s_d[worst_k][t] = d; s_i[worst_k][t] = v0 + v;
           worst = -1.f;
-          for (int k = 0; k < KNN_K; k++) { const float dk = s_d[k][t]; if (dk > worst) { worst = dk; worst_k = k; } }
+          // the entry to evict next: largest distance, among equal distances the LARGEST vertex index (pytorch3d's
+          // priority queue of (distance, index) tuples pops exactly that one, knn_cpu.cpp:36-56)
+          int worst_i = -1;
+          for (int k = 0; k < KNN_K; k++) {
+            const float dk = s_d[k][t]; const int ik = s_i[k][t];
+            if (dk > worst || (dk == worst && ik > worst_i)) { worst = dk; worst_k = k; worst_i = ik; }
+          }
         }
       }
     }

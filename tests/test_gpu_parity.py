@@ -208,6 +208,54 @@ def test_occupancy_postprocess_bit_exact(oracle, gpu_world):
     assert grid.density_field.sum().item() == 0
 
 
+def test_occupancy_components_lds_path_and_fallback(oracle, gpu_world):
+    """The occupancy post-process has two routes with identical results: one workgroup in LDS (up to 16 384
+    occupied cells -- every posed body) and the global-memory union-find (anything larger, e.g. an untrained
+    field).  Cases: two components of EQUAL size (torch.mode keeps the smaller label), diagonal-only (26-)
+    connectivity, a component touching the border (border flag), sparse noise with hundreds of components,
+    and sizes on both sides of the LDS capacity.  density_grid.py:104-125."""
+    model = gpu_world[0]
+    G = 64
+    grid = model.renderer.density_grid_test
+    rng = np.random.RandomState(5)
+
+    def check(dens, what):
+        ref = oracle.occupancy_from_density(dens, G).astype(bool)
+        grid._postprocess(torch.as_tensor(dens, device=DEV))
+        got = grid.density_field.cpu().numpy()
+        assert np.array_equal(got, ref), (what, int(got.sum()), int(ref.sum()))
+        words = grid.occ_bits.cpu().numpy().view(np.uint32)
+        unpacked = ((words[:G ** 3 // 32, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(G, G, G).astype(bool)
+        assert np.array_equal(unpacked, got), what
+        border = got.copy(); border[1:-1, 1:-1, 1:-1] = False
+        assert int(words[G ** 3 // 32]) == (0 if border.any() else 1), what   # flag word: 1 = no border cell occupied
+        return int(got.sum())
+
+    d = np.zeros((G, G, G), np.float32)
+    d[10:14, 10:14, 10:14] = 100; d[40:44, 40:44, 40:44] = 100          # equal sizes: the component with the smaller label wins
+    n = check(d, "tie")
+    assert n == 6 ** 3
+    d = np.zeros((G, G, G), np.float32)
+    for k in range(20):
+        d[20 + k, 20 + k, 20 + k] = 50                                     # a diagonal chain (dilated by the max-pool)
+    d[5:8, 50:60, 30:33] = 80
+    check(d, "diagonal")
+    d = np.zeros((G, G, G), np.float32)
+    d[0:6, 30:36, 28:40] = 120                                            # touches x = 0
+    assert check(d, "border") > 0
+    d = (rng.rand(G, G, G) > 0.9995).astype(np.float32) * 70                # ~130 isolated seeds -> many 27-cell components
+    d[30:36, 30:36, 30:36] = 90
+    check(d, "noise")
+    for side, what in ((22, "below the LDS capacity"), (24, "above the LDS capacity")):   # (side + 2)^3 cells after dilation
+        d = np.zeros((G, G, G), np.float32)
+        d[8:8 + side, 8:8 + side, 8:8 + side] = rng.rand(side, side, side) * 200 + 50
+        d[50:53, 50:53, 50:53] = 60
+        n = check(d, what)
+        assert (n <= 16384) == (side == 22), (side, n)
+    d = rng.rand(G, G, G).astype(np.float32) * 100                          # untrained-field-like: most of the grid occupied
+    check(d, "dense")
+
+
 def test_raymarch_and_composite_kernels(oracle, gpu_world):
     model = gpu_world[0]
     G = 64
