@@ -196,7 +196,7 @@ struct OccWs {
   double sum;               // sum of the max-pooled field
   unsigned long long best;  // (count << 32) | (~label)
   float thr;                // clamp(mean, max = 0.01)
-  int32_t run_global;       // 1: the global-memory component kernels have to do the job (set by the LDS kernel)
+  float pad;
 };
 
 // Launch 1 of 5: f = 1 - exp(0.01 * -density) (density_grid.py:104) evaluated on the fly for the
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_occ_pool(const float *__restrict__ dens
                                                   OccWs *__restrict__ ws, uint32_t *__restrict__ bits) {
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { ws->sum = 0.0; ws->best = 0ull; ws->run_global = 1; bits[n >> 5] = 1u; }  // border flag: 1 = no border cell occupied
+  if (i == 0) { ws->sum = 0.0; ws->best = 0ull; bits[n >> 5] = 1u; }  // border flag: 1 = no border cell occupied
   float m = 0.f;
   if (i < n) {
     const int x = i / (G * G), y = i / G % G, z = i % G;
@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void k_occ_union(int G, const float *__restric
                                                    const double *__restrict__ partial, int n_part, OccWs *ws,
                                                    int32_t *parent) {
   __shared__ double s_red[256];
-  if (!ws->run_global) return;  // the LDS kernel did the job
   const int n = G * G * G;
   const float thr = occ_threshold(partial, n_part, n, s_red);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,7 +297,6 @@ __global__ __launch_bounds__(256) void k_occ_union(int G, const float *__restric
 // Launch 3 of 5: labels + component sizes
 __global__ __launch_bounds__(256) void k_occ_count(int G, const float *__restrict__ pooled, const OccWs *__restrict__ ws,
                                                    int32_t *parent, int32_t *__restrict__ label, int32_t *count) {
-  if (!ws->run_global) return;
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -316,7 +314,6 @@ __global__ __launch_bounds__(256) void k_occ_count(int G, const float *__restric
 
 // torch.mode(mcc[field]): most frequent label, smallest label on ties (:109)
 __global__ __launch_bounds__(256) void k_occ_best(int G, const int32_t *__restrict__ count, OccWs *ws) {
-  if (!ws->run_global) return;
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -327,7 +324,6 @@ __global__ __launch_bounds__(256) void k_occ_best(int G, const int32_t *__restri
 __global__ __launch_bounds__(256) void k_occ_final(int G, const int32_t *__restrict__ label,
                                                    const OccWs *__restrict__ ws, uint32_t *__restrict__ bits,
                                                    uint8_t *__restrict__ occ_bool) {
-  if (!ws->run_global) return;
   const int n = G * G * G;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long best = ws->best;
@@ -347,164 +343,6 @@ __global__ __launch_bounds__(256) void k_occ_final(int G, const int32_t *__restr
   }
 }
 
-// ---------------------------------------------------------------------------
-// Launches 2-5 as ONE workgroup working in LDS (G <= 64, at most IA_OCC_LDS_MAX occupied cells -- a posed
-// body fills ~1.5 % of its 64^3 grid; anything larger takes the global-memory kernels above).  The
-// union-find of the global version spends its time in chains of device-scope atomics (~100 us for ~4 000
-// cells); in LDS a find / link is a few hundred cycles and the whole post-process (threshold, 26-connected
-// components, mode, bit packing) is one launch.  Cells are addressed by their RANK among the occupied
-// cells (bit mask + per-word prefix popcounts): ranks grow with the linear index, so "root = maximum rank"
-// is the reference's "label = maximum linear index" (density_grid.py:118-125) and the smallest root rank
-// wins ties of torch.mode (:109).
-// ---------------------------------------------------------------------------
-#define IA_OCC_LDS_MAX 16384
-#define IA_OCC_LDS_THREADS 1024
-#define IA_OCC_LDS_WORDS 8192  // 64^3 / 32
-
-__device__ __forceinline__ int lds_find(volatile uint16_t *parent, int i) {
-  int p = parent[i];
-  while (p != i) { const int gp = parent[p]; if (gp != p) parent[i] = (uint16_t)gp; i = p; p = gp; }  // path halving: only ever raises a parent
-  return i;
-}
-
-__global__ __launch_bounds__(IA_OCC_LDS_THREADS) void k_occ_components_lds(
-    int G, const float *__restrict__ pooled, const double *__restrict__ partial, int n_part, OccWs *ws,
-    uint32_t *__restrict__ bits, uint8_t *__restrict__ occ_bool) {
-  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-  uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn);                       // 32 KB
-  uint16_t *s_prefix = reinterpret_cast<uint16_t *>(s_dyn + 32768);             // 16 KB: occupied cells before word w
-  uint16_t *s_parent = reinterpret_cast<uint16_t *>(s_dyn + 49152);             // 32 KB
-  uint32_t *s_count = reinterpret_cast<uint32_t *>(s_dyn + 81920);              // 32 KB: two 16-bit counters per word
-  __shared__ double s_red[256];
-  __shared__ int s_scan[IA_OCC_LDS_THREADS / 64];
-  __shared__ unsigned s_best, s_border;
-  __shared__ int s_total;
-  const int n = G * G * G, n_words = n >> 5;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- threshold (identical arithmetic to occ_threshold: threads 0..255 in the same order) ----
-  if (tid < 256) {
-    double v = 0.0;
-    for (int k = tid; k < n_part; k += 256) v += partial[k];
-    s_red[tid] = v;
-  }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) s_red[tid] += s_red[tid + o];
-    __syncthreads();
-  }
-  const float mean = (float)(s_red[0] / (double)n);
-  const float thr = mean > 0.01f ? 0.01f : mean;
-  if (tid == 0) { ws->thr = thr; ws->sum = s_red[0]; s_best = 0u; s_border = 0u; }
-  // ---- occupancy mask: one coalesced 256-byte load per wave step, ballot -> two words ----
-  for (int base = wave * 64; base < n; base += IA_OCC_LDS_THREADS) {
-    const unsigned long long m = __ballot(pooled[base + lane] > thr);
-    if (lane == 0) { s_bits[base >> 5] = (uint32_t)m; s_bits[(base >> 5) + 1] = (uint32_t)(m >> 32); }
-  }
-  __syncthreads();
-  // ---- ranks: exclusive prefix of the word popcounts (thread t owns words [8t, 8t+8)) ----
-  const int wpt = n_words / IA_OCC_LDS_THREADS;  // 8 for G = 64
-  int mine = 0;
-  for (int k = 0; k < wpt; k++) mine += __popc(s_bits[tid * wpt + k]);
-  int wtot;
-  int excl = ia_wave_excl_scan(mine, wtot);
-  if (lane == 0) s_scan[wave] = wtot;
-  __syncthreads();
-  if (tid == 0) {
-    int tot = 0;
-    for (int w = 0; w < IA_OCC_LDS_THREADS / 64; w++) { const int c = s_scan[w]; s_scan[w] = tot; tot += c; }
-    s_total = tot;
-  }
-  __syncthreads();
-  const int total = s_total;
-  if (total > IA_OCC_LDS_MAX) {  // uniform: leave the job to the global-memory kernels
-    if (tid == 0) ws->run_global = 1;
-    return;
-  }
-  if (tid == 0) ws->run_global = 0;
-  {
-    int run = s_scan[wave] + excl;
-    for (int k = 0; k < wpt; k++) { s_prefix[tid * wpt + k] = (uint16_t)run; run += __popc(s_bits[tid * wpt + k]); }
-  }
-  for (int e = tid; e < total; e += IA_OCC_LDS_THREADS) s_parent[e] = (uint16_t)e;
-  for (int e = tid; e < IA_OCC_LDS_MAX / 2; e += IA_OCC_LDS_THREADS) s_count[e] = 0u;
-  __syncthreads();
-  auto rank_of = [&](int cell) { const int w = cell >> 5; return (int)s_prefix[w] + __popc(s_bits[w] & ((1u << (cell & 31)) - 1u)); };
-  // ---- 26-connected union: words interleaved over the threads (a body spans consecutive words) ----
-  for (int w = tid; w < n_words; w += IA_OCC_LDS_THREADS) {
-    uint32_t m = s_bits[w];
-    while (m) {
-      const int b = __ffs(m) - 1;
-      m &= m - 1;
-      const int i = (w << 5) | b;
-      const int x = i / (G * G), y = i / G % G, z = i % G;
-      const int ri = (int)s_prefix[w] + __popc(s_bits[w] & ((1u << b) - 1u));
-      for (int a = 0; a <= 1; a++)
-        for (int bb = -1; bb <= 1; bb++)
-          for (int c = -1; c <= 1; c++) {
-            if (a == 0 && (bb < 0 || (bb == 0 && c <= 0))) continue;  // the 13 neighbours with a larger linear index
-            const int xx = x + a, yy = y + bb, zz = z + c;
-            if (xx >= G || yy < 0 || yy >= G || zz < 0 || zz >= G) continue;
-            const int j = (xx * G + yy) * G + zz;
-            if (!((s_bits[j >> 5] >> (j & 31)) & 1u)) continue;
-            int ra = ri, rb = rank_of(j);
-            while (true) {
-              ra = lds_find(s_parent, ra); rb = lds_find(s_parent, rb);
-              if (ra == rb) break;
-              if (ra > rb) { const int t = ra; ra = rb; rb = t; }
-              // link the smaller root under the larger: 16-bit compare-and-swap on the containing 32-bit word
-              uint32_t *wp = reinterpret_cast<uint32_t *>(s_parent) + (ra >> 1);
-              const int sh = (ra & 1) * 16;
-              const uint32_t old = *wp;
-              if (((old >> sh) & 0xffffu) != (uint32_t)ra) continue;  // no longer a root: find again
-              const uint32_t upd = (old & ~(0xffffu << sh)) | ((uint32_t)rb << sh);
-              if (atomicCAS(wp, old, upd) == old) break;                // (a concurrent change of the other half retries)
-            }
-          }
-    }
-  }
-  __syncthreads();
-  // ---- component sizes (two 16-bit counters per word: sizes <= 16384) and the mode ----
-  for (int e = tid; e < total; e += IA_OCC_LDS_THREADS) {
-    const int r = lds_find(s_parent, e);
-    atomicAdd(&s_count[r >> 1], 1u << ((r & 1) * 16));
-  }
-  __syncthreads();
-  for (int r = tid; r < total; r += IA_OCC_LDS_THREADS) {
-    const uint32_t c = (s_count[r >> 1] >> ((r & 1) * 16)) & 0xffffu;
-    if (c) atomicMax(&s_best, (c << 14) | (uint32_t)(IA_OCC_LDS_MAX - 1 - r));  // most cells; smallest root on ties
-  }
-  __syncthreads();
-  const int best_root = s_best ? (IA_OCC_LDS_MAX - 1 - (int)(s_best & (IA_OCC_LDS_MAX - 1))) : -1;
-  // ---- keep the winning component ----
-  for (int w = tid; w < n_words; w += IA_OCC_LDS_THREADS) {
-    uint32_t m = s_bits[w], out = 0u;
-    while (m) {
-      const int b = __ffs(m) - 1;
-      m &= m - 1;
-      const int r = (int)s_prefix[w] + __popc(s_bits[w] & ((1u << b) - 1u));
-      if (lds_find(s_parent, r) == best_root) {
-        out |= 1u << b;
-        const int i = (w << 5) | b;
-        const int x = i / (G * G), y = i / G % G, z = i % G;
-        if (x == 0 || y == 0 || z == 0 || x == G - 1 || y == G - 1 || z == G - 1) s_border = 1u;
-      }
-    }
-    bits[w] = out;
-    s_count[w] = out;  // (counts are consumed: reuse the 32 KB as the final mask for the bool mirror below)
-  }
-  __syncthreads();
-  if (tid == 0) bits[n_words] = s_border ? 0u : 1u;  // border flag: 1 = no border cell occupied
-  if (occ_bool) {  // bool mirror, four cells per 32-bit store, coalesced
-    uint32_t *ob = reinterpret_cast<uint32_t *>(occ_bool);
-    for (int k = tid; k < n / 4; k += IA_OCC_LDS_THREADS) {
-      const uint32_t nib = (s_count[(k * 4) >> 5] >> ((k * 4) & 31)) & 0xfu;
-      ob[k] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
-    }
-  }
-}
-
-// fallback dispatch of the global-memory kernels: every one of them first looks at the flag the LDS kernel
-// left (device side, no host read); when the LDS kernel did the job they exit immediately
 __global__ void k_occ_set_flag(uint32_t *bits, int n) { bits[n >> 5] = 1u; }
 
 __global__ __launch_bounds__(256) void k_occ_pack(const uint8_t *__restrict__ occ_bool, int n, int G,
@@ -874,17 +712,6 @@ extern "C" int ia_occupancy_from_density(const float *density, int G, uint32_t *
   (void)fval;
   const int n_part = ia_div_up(n, 256);
   hipLaunchKernelGGL(k_occ_pool, grid, blk, 0, s, density, G, pooled, partial, parent, count, ow, occ_bits);
-  if ((n >> 5) % IA_OCC_LDS_THREADS == 0 && (n >> 5) <= IA_OCC_LDS_WORDS) {
-    // one workgroup, everything in LDS; sets ow->run_global = 0 unless more than IA_OCC_LDS_MAX cells are occupied,
-    // in which case the four launches below (which otherwise exit at once) do the job
-    static bool attr_done = false;
-    const size_t shmem = 32768 + 16384 + 32768 + 32768;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_occ_components_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k_occ_components_lds, dim3(1), dim3(IA_OCC_LDS_THREADS), shmem, s, G, pooled, partial, n_part, ow, occ_bits, occ_bool);
-  }
   hipLaunchKernelGGL(k_occ_union, grid, blk, 0, s, G, pooled, partial, n_part, ow, parent);
   hipLaunchKernelGGL(k_occ_count, grid, blk, 0, s, G, pooled, ow, parent, label, count);
   hipLaunchKernelGGL(k_occ_best, grid, blk, 0, s, G, count, ow);

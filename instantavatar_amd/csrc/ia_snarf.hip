@@ -145,8 +145,13 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
 #pragma unroll
       for (int c = 0; c < 12; c++) J[v][c] = 0.f;
     // precompute.cu:51-59: J[c] accumulates over j in joint order
-    // (requesting all 24 planes before the first use was measured: 193 VGPRs, 98 -> 115 us)
-#pragma unroll 2
+    // (requesting all 24 planes before the first use was measured: 193 VGPRs, 98 -> 115 us; one voxel per thread with
+    // all 24 four-byte loads in flight and LDS-transposed, fully coalesced stores: 180 us -- 4-byte-per-lane plane
+    // loads stream at half the rate of 16-byte ones)
+#ifndef IA_PRE_UNROLL
+#define IA_PRE_UNROLL 4  // joint planes in flight per thread: 2 / 4 / 6 / 8 measured 98.7 / 92.8 / 96.6 / 105.1 us
+#endif
+#pragma unroll IA_PRE_UNROLL
     for (int j = 0; j < 24; j++) {
       union { vec_t v; float f[VPT]; } w;
       w.v = *reinterpret_cast<const vec_t *>(voxel_w + (size_t)j * n + index0);
@@ -187,62 +192,6 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
 #pragma unroll
         for (int v = 0; v < VPT; v++) voxel_d[(size_t)i0 * n + index0 + v] = xi[i0][v];
     }
-  }
-  if (bbox) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float a = ia_wave_min(mn[c]), b = ia_wave_max(mx[c]);
-      if (ia_lane() == 0) { ia_atomic_min_f(bbox + c, a); ia_atomic_max_f(bbox + 3 + c, b); }
-    }
-  }
-}
-
-// Second formulation of a3 (default): ONE voxel per thread, all 24 joint-plane loads of a thread in flight
-// at once (24 data VGPRs; with 8 waves per CU ~48 KB of reads outstanding per CU, what a streaming kernel
-// needs to reach the HBM rate), and the 48-byte records transposed through LDS so that every store
-// instruction writes 1 KB of contiguous memory per wave instead of 64 pieces of 16 B at stride 48 B.
-// Same accumulation order over the joints -> bit-identical voxel_J / voxel_d / bbox.
-__global__ __launch_bounds__(256) void k_precompute_lds(const float *__restrict__ voxel_w, const float *__restrict__ tfs,
-                                                        float *__restrict__ voxel_J, float *__restrict__ voxel_d,
-                                                        float *__restrict__ bbox, SnarfGridDev g) {
-  __shared__ __attribute__((aligned(16))) float s_J[256 * 12];
-  const int n = g.D * g.H * g.W;
-  const int tid = threadIdx.x;
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {  // n % 256 == 0 (checked by the host)
-    const int index = base + tid;
-    float wj[24];
-#pragma unroll
-    for (int j = 0; j < 24; j++) wj[j] = voxel_w[(size_t)j * n + index];
-    float J[12];
-#pragma unroll
-    for (int c = 0; c < 12; c++) J[c] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 24; j++)  // precompute.cu:51-59: J[c] accumulates over j in joint order
-#pragma unroll
-      for (int c = 0; c < 12; c++) J[c] = __builtin_fmaf(wj[j], tfs[j * 16 + c], J[c]);
-    const int hw = g.H * g.W;
-    const int idx_d = index / hw, idx_h = index % hw / g.W, idx_w = index % hw % g.W;
-    const float cx = (((float)idx_w) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];  // precompute.cu:42-47
-    const float cy = (((float)idx_h) / (g.H - 1) * 2 - 1) / g.scl[1] - g.off[1];
-    const float cz = (((float)idx_d) / (g.D - 1) * 2 - 1) / g.scl[2] - g.off[2];
-#pragma unroll
-    for (int i0 = 0; i0 < 3; i0++) {  // precompute.cu:66-70
-      const float xi = IA_DOT3(J[i0 * 4 + 0], cx, J[i0 * 4 + 1], cy, J[i0 * 4 + 2], cz) + J[i0 * 4 + 3];
-      mn[i0] = fminf(mn[i0], xi);
-      mx[i0] = fmaxf(mx[i0], xi);
-      if (voxel_d) voxel_d[(size_t)i0 * n + index] = xi;
-    }
-    __syncthreads();  // previous tile read out
-    float4 *sj = reinterpret_cast<float4 *>(s_J + tid * 12);
-    sj[0] = make_float4(J[0], J[1], J[2], J[3]);
-    sj[1] = make_float4(J[4], J[5], J[6], J[7]);
-    sj[2] = make_float4(J[8], J[9], J[10], J[11]);
-    __syncthreads();
-    const float4 *src = reinterpret_cast<const float4 *>(s_J);
-    float4 *dst = reinterpret_cast<float4 *>(voxel_J + (size_t)base * 12);
-#pragma unroll
-    for (int q = 0; q < 3; q++) dst[q * 256 + tid] = src[q * 256 + tid];
   }
   if (bbox) {
 #pragma unroll
@@ -615,15 +564,6 @@ extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxe
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)grid->D * grid->H * grid->W;
   if (bbox) { hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox); IA_LAUNCH_CHECK("k_bbox_init"); }
-#ifndef IA_PRE_LDS
-#define IA_PRE_LDS 1
-#endif
-  if (IA_PRE_LDS && n % 256 == 0) {
-    const int blocks = (int)(n / 256 < 2048 ? n / 256 : 2048);  // 8 workgroups per CU
-    hipLaunchKernelGGL(k_precompute_lds, dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox, ia_make_grid_dev(grid));
-    IA_LAUNCH_CHECK("k_precompute_lds");
-    return IA_OK;
-  }
   const long nt = n / IA_PRE_VPT;
   const int blocks = (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
