@@ -523,7 +523,12 @@ def main():
                               "units": v["units"]} for n, v in kernels.items()}}
         cj, csrc = _profile_json("r02_pmc_search.json")
         if cj is not None:
-            roof["counters"] = dict(cj, source=csrc)
+            # committed PMC passes of this kernel (tools/pmc_r2.sh): what actually bounds k_search is the rate at which a
+            # CU's vector L1 (TCP) looks up cache lines for divergent 16-byte gathers -- ~1 access per clock and CU
+            keep = ("l1_hit_rate", "l2_hit_rate", "tcp_accesses_per_clk_per_cu_at_2.4GHz", "wave_cycle_split", "avg_launch_us_in_pass", "launches")
+            roof["counters"] = {v: {k: cj[v][k] for k in keep if k in cj[v]} for v in ("k_search/probe", "k_search/render") if v in cj}
+            roof["counters"]["source"] = csrc
+            roof["counters"]["vgprs"], roof["counters"]["waves_per_simd"] = 116, 4
 
     frames = args.steps * world_size
     fps = frames / dt

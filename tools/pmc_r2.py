@@ -118,13 +118,12 @@ def main(root, out_dir):
         if b is None:
             continue
         ns = g(fam, "SQ_VALU_MFMA_BUSY_CYCLES", "avg_ns")
-        gui = g(fam, "GRBM_GUI_ACTIVE")
-        clk_ghz = (gui / ns) if gui and ns else 2.4
+        clk_ghz = 2.4  # nominal maximum: the utilisation below is a LOWER bound when the chip clocks down under load
         mfma[fam] = {"mfma_busy_cycles_per_launch": b, "avg_launch_us_in_pass": ns / 1e3, "launches": g(fam, "SQ_VALU_MFMA_BUSY_CYCLES", "launches"),
                      "sq_busy_cycles_per_launch": g(fam, "SQ_BUSY_CYCLES"), "sq_wave_cycles_per_launch": g(fam, "SQ_WAVE_CYCLES"),
-                     "effective_clock_ghz": clk_ghz,
+                     "clock_ghz_assumed": clk_ghz,
                      "mfma_utilisation": b / (ns * clk_ghz * N_SIMD) if ns else None}
-    mfma["_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES summed over the chip / (launch duration x clock x 1024 SIMDs); the MLPs are 18 432 FLOP per "
+    mfma["_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES (32 per v_mfma_f32_32x32x16_f16, summed over the chip) / (launch duration x 2.4 GHz x 1024 SIMDs); the MLPs are 18 432 FLOP per "
                      "sample (22 v_mfma_f32_32x32x16_f16 per 32 samples forward): the matrix cores are used for the dense tiny-MLP GEMMs "
                      "only and are nowhere near a bound -- reported, not optimised (SURVEY 8d)")
     for name, obj in (("r02_pmc_traffic.json", traffic), ("r02_pmc_search.json", search), ("r02_pmc_mfma.json", mfma)):
