@@ -28,7 +28,15 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
     for k, v in sd.items():
         if k in own:
             if tuple(own[k].shape) != tuple(v.shape):
-                raise ValueError("checkpoint tensor %s has shape %s, expected %s" % (k, tuple(v.shape), tuple(own[k].shape)))
+                hint = ""
+                net = getattr(model, "net_coarse", None)
+                if k.endswith("encoder.params") and hasattr(net, "tcnn_encoder_sizes"):
+                    sizes = net.tcnn_encoder_sizes(net.n_levels, net.log2_T)
+                    other = [r for r, n in sizes.items() if n == v.numel()]
+                    if other:
+                        hint = (" -- the checkpoint uses the tcnn layout with level-3 resolution %d; build the network with "
+                                "level3_res=%d (or IA_TCNN_LEVEL3_RES=%d)" % (other[0], other[0], other[0]))
+                raise ValueError("checkpoint tensor %s has shape %s, expected %s%s" % (k, tuple(v.shape), tuple(own[k].shape), hint))
             take[k] = v
         else:
             unexpected.append(k)

@@ -39,11 +39,12 @@ class _TcnnParams(nn.Module):
 
 
 class NeRFNGPNet(nn.Module):
-    def __init__(self, opt, n_levels=N_LEVELS, log2_hashmap_size=LOG2_HASHMAP):
+    def __init__(self, opt, n_levels=N_LEVELS, log2_hashmap_size=LOG2_HASHMAP, level3_res=None):
         super().__init__()
         self.n_levels = n_levels
         self.log2_T = log2_hashmap_size
-        self.hash_desc = _lib.make_hash_desc(n_levels, log2_hashmap_size, BASE_RES, PER_LEVEL_SCALE)
+        # level3_res (54 | 55 | None = host libm / IA_TCNN_LEVEL3_RES): see _lib.apply_level3_override
+        self.hash_desc = _lib.make_hash_desc(n_levels, log2_hashmap_size, BASE_RES, PER_LEVEL_SCALE, level3_res=level3_res)
         self.n_entries = int(self.hash_desc.offset[n_levels])
         self.sig_w1_size = 64 * 2 * n_levels
         self.encoder = _TcnnParams(self.sig_w1_size + SIG_W2 + 2 * self.n_entries)
@@ -84,6 +85,38 @@ class NeRFNGPNet(nn.Module):
             self.center = torch.as_tensor(fp["center"], dtype=torch.float32, device=dev)
             self.scale = torch.as_tensor(fp["scale"], dtype=torch.float32, device=dev)
         self._desc = None
+
+    @staticmethod
+    def tcnn_encoder_sizes(n_levels=N_LEVELS, log2_hashmap_size=LOG2_HASHMAP):
+        """{level-3 resolution: numel of `encoder.params`} for the two layouts tcnn v1.6 can produce (see
+        _lib.apply_level3_override): [W1 64x2L | W2 16x64 | grid]."""
+        out = {}
+        for r3 in (54, 55):
+            hd = _lib.make_hash_desc(n_levels, log2_hashmap_size, BASE_RES, PER_LEVEL_SCALE, level3_res=r3)
+            out[r3] = 64 * 2 * n_levels + SIG_W2 + 2 * int(hd.offset[n_levels])
+        return out
+
+    def load_tcnn_params(self, encoder_params, color_params):
+        """Load the reference's two flat tcnn parameter vectors (state-dict entries `net_coarse.encoder.params`,
+        `net_coarse.color_net.params`, ngp.py:27-58).  Sizes are checked against this module's level table; a
+        vector with the OTHER level-3 layout is rejected with the size it has, the size expected and the switch to
+        flip -- never loaded shifted."""
+        enc, col = torch.as_tensor(encoder_params).reshape(-1), torch.as_tensor(color_params).reshape(-1)
+        sizes = self.tcnn_encoder_sizes(self.n_levels, self.log2_T)
+        own = self.encoder.params.numel()
+        if enc.numel() != own:
+            other = [r for r, n in sizes.items() if n == enc.numel()]
+            hint = (" -- that is the layout with a level-3 resolution of %d (this module was built for %d): construct "
+                    "NeRFNGPNet(..., level3_res=%d) or set IA_TCNN_LEVEL3_RES=%d" % (other[0], int(self.hash_desc.res[3]), other[0], other[0])
+                    ) if other and self.n_levels > 3 else ""
+            raise ValueError("encoder.params has %d elements, expected %d (= 64x%d + 16x64 + 2 x %d grid entries)%s"
+                             % (enc.numel(), own, 2 * self.n_levels, self.n_entries, hint))
+        if col.numel() != self.color_net.params.numel():
+            raise ValueError("color_net.params has %d elements, expected %d (64x16 + 64x64 + 16x64)" % (col.numel(), self.color_net.params.numel()))
+        with torch.no_grad():
+            self.encoder.params.copy_(enc.to(self.encoder.params))
+            self.color_net.params.copy_(col.to(self.color_net.params))
+        self.mark_updated()
 
     def initialize(self, bbox):
         """ngp.py:64-71"""

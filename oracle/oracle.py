@@ -61,9 +61,21 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def hash_desc(n_levels=16, log2_T=19, base=16, pls=1.5):
+def hash_desc(n_levels=16, log2_T=19, base=16, pls=1.5, level3_res=None):
+    """tcnn v1.6 level table.  level3_res / IA_TCNN_LEVEL3_RES in {54, 55}: the one resolution that depends on the last
+    bit of exp2f (see instantavatar_amd/_lib.py: apply_level3_override); default = this host's libm (glibc: 54)."""
     hd = HashDesc()
     lib().orc_hash_desc_init(C.byref(hd), n_levels, log2_T, base, C.c_float(pls))
+    if level3_res is None:
+        level3_res = os.environ.get("IA_TCNN_LEVEL3_RES")
+    if level3_res is not None and n_levels > 3:
+        hd.res[3] = int(level3_res)
+        off = 0
+        for l in range(n_levels):
+            r = int(hd.res[l])
+            hd.offset[l] = off
+            off += min((r * r * r + 7) // 8 * 8, 1 << log2_T)
+        hd.offset[n_levels] = off
     return hd
 
 

@@ -72,12 +72,13 @@ def test_hash_level_table_pinned(oracle):
     hd_o = oracle.hash_desc()
     hd_p = _lib.make_hash_desc()
     sc, res, off = syn.hash_level_table()
-    expect_res = [16, 24, 36, 54, 81, 122, 183, 274, 411, 616, 923, 1384, 2076, 3114, 4671, 7007]
+    r3 = int(os.environ.get("IA_TCNN_LEVEL3_RES", 54))   # the suite can be run under either level-3 layout
+    expect_res = [16, 24, 36, r3, 81, 122, 183, 274, 411, 616, 923, 1384, 2076, 3114, 4671, 7007]
     assert list(hd_o.res) == expect_res == list(hd_p.res) == list(res)
     assert list(hd_o.offset) == list(hd_p.offset) == list(off)
-    assert hd_o.offset[16] == 6513496  # => encoder.params = 3072 + 13026992
+    assert hd_o.offset[16] == (6513496 if r3 == 54 else 6522408)  # => encoder.params = 3072 + 13026992 (54) / 13044816 (55)
     assert np.allclose(np.array(hd_o.scale[:]), sc, rtol=0, atol=0)
-    assert list(hd_o.offset[:5]) == [0, 4096, 17920, 64576, 222040]
+    assert list(hd_o.offset[:5]) == [0, 4096, 17920, 64576, 222040 if r3 == 54 else 230952]
 
 
 # ---------------------------------------------------------------- LBS golden (reference lbs.py)
@@ -382,3 +383,38 @@ def test_voxeliser_has_no_cpu_route():
     from instantavatar_amd.deformers.fast_snarf.forward_deformer import voxelise_skinning_weights
     with pytest.raises(_lib.IAError):
         voxelise_skinning_weights(torch.zeros(8, 3), torch.zeros(10, 3), torch.zeros(10, 24), (2, 2, 2))
+
+
+# ---------------------------------------------------------------- tcnn level-3 resolution (54 vs 55)
+def test_tcnn_param_vector_sizes_and_loader_messages(oracle, monkeypatch):
+    """The one quantity of the tcnn restatement that cannot be settled offline: level 3 of the hash grid has an exact
+    scale of 53.0, so its resolution is 54 or 55 depending on the last bit of exp2f.  Both layouts are supported
+    explicitly; a parameter vector of the other layout is rejected with a precise message, never loaded shifted."""
+    from instantavatar_amd import _lib
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    monkeypatch.delenv("IA_TCNN_LEVEL3_RES", raising=False)
+    sizes = NeRFNGPNet.tcnn_encoder_sizes()
+    assert sizes[55] - sizes[54] == 2 * 8912                     # 55^3 = 166 375 -> 166 376 vs 54^3 = 157 464 entries
+    assert sizes[55] == 3072 + 2 * 6522408                        # SURVEY.md 8a: 13 044 816 grid parameters
+    for r3 in (54, 55):
+        hd = _lib.make_hash_desc(16, 19, 16, 1.5, level3_res=r3)
+        oh = oracle.hash_desc(16, 19, level3_res=r3)
+        assert list(hd.res[:16]) == list(oh.res[:16]) and list(hd.offset[:17]) == list(oh.offset[:17])
+        assert hd.res[3] == r3 and all(int(hd.offset[l + 1]) - int(hd.offset[l]) == 524288 for l in range(4, 16))
+    net = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), level3_res=54)
+    enc55 = torch.zeros(sizes[55])
+    with pytest.raises(ValueError) as e:
+        net.load_tcnn_params(enc55, torch.zeros(6144))
+    msg = str(e.value)
+    assert str(sizes[55]) in msg and str(sizes[54]) in msg and "level3_res=55" in msg
+    with pytest.raises(ValueError):
+        net.load_tcnn_params(torch.zeros(sizes[54] - 1), torch.zeros(6144))
+    with pytest.raises(ValueError):
+        net.load_tcnn_params(torch.zeros(sizes[54]), torch.zeros(6143))
+    net.load_tcnn_params(torch.full((sizes[54],), 0.25), torch.full((6144,), -0.5))
+    assert float(net.encoder.params.min()) == 0.25 and float(net.color_net.params.max()) == -0.5
+    net55 = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), level3_res=55)
+    net55.load_tcnn_params(enc55, torch.zeros(6144))
+    monkeypatch.setenv("IA_TCNN_LEVEL3_RES", "55")             # the suite-wide switch
+    assert NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])).encoder.params.numel() == sizes[55]
+    assert int(oracle.hash_desc().res[3]) == 55
