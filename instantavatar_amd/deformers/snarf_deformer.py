@@ -133,8 +133,10 @@ class SNARFDeformer():
             self.initialized = True
         go, bp, tr = smpl_params["global_orient"], smpl_params["body_pose"], smpl_params["transl"]
         needs_grad = any(t.requires_grad for t in (go, bp, tr))
-        if needs_grad or not go.is_cuda:
-            # differentiable / CPU route (SMPL-parameter refinement, config 4): torch ops
+        _lib.require_cuda(go)  # no CPU route: the per-frame path is HIP kernels
+        if needs_grad:
+            # differentiable route (SMPL-parameter refinement, config 4): torch ops under autograd; the voxel
+            # precompute / search below still run as kernels, the gradient reaches tfs by implicit differentiation
             out = self.body_model(betas=smpl_params["betas"], body_pose=bp, global_orient=go, transl=tr,
                                   return_verts=False)
             s2w = out.A[:, 0].float()
