@@ -417,6 +417,37 @@ int ia_candidate_gather_fwd(const float *cand_rgb, const float *cand_sigma, cons
 int ia_candidate_gather_bwd(const float *d_rgb, const float *d_sigma, const int32_t *arg, int P,
                             float *d_cand_rgb, float *d_cand_sigma, void *stream);
 
+/* ---- f4: the data side of a training step, on the device ----------------------
+ * make_rays (instant_avatar/datasets/peoplesnapshot.py:12-25): rays_o / rays_d [H*W,3] fp32 of a pinhole
+ * camera, evaluated in fp64 like the reference's numpy code.  K_inv [9], c2w_R [9] (row-major), c2w_t [3]:
+ * HOST arrays (three tiny matrices; inv(K) is the caller's np.linalg.inv as in the reference).          */
+int ia_make_rays(const double *K_inv, const double *c2w_R, const double *c2w_t, int H, int W,
+                 float *rays_o, float *rays_d, void *stream);
+/* EdgeSampler's band (instant_avatar/utils/sampler.py:25-28): edge = cv2.dilate(mask, ones(k,k)) -
+ * cv2.erode(mask, ones(k,k)), anchor (k/2, k/2), pixels outside the image ignored.  mask, edge: [H,W].    */
+size_t ia_mask_edge_workspace_bytes(int H, int W);
+int ia_mask_edge(const float *mask, int H, int W, int kernel_size, float *edge, void *ws,
+                 size_t ws_bytes, void *stream);
+/* np.where(mask[y0:y1, x0:x1])[rank] for n ranks derived from uniform draws u [n] in [0,1) on the device:
+ * with replacement rank = floor(u * count) (np.random.randint, sampler.py:33-35); without replacement the
+ * floor(u_i * (count - i))-th element not chosen before (np.random.choice(replace=False), sampler.py:69).
+ * out_row / out_col [n]: coordinates RELATIVE to the window, row-major order of np.where; -1 when the window
+ * holds no nonzero element.  count_out (optional, DEVICE int32): number of nonzeros.  No host sync.        */
+size_t ia_nonzero_select_workspace_bytes(int rows, int n);
+int ia_nonzero_select(const float *mask, int H, int W, int y0, int y1, int x0, int x1, const float *u,
+                      int n, int without_replacement, int32_t *out_row, int32_t *out_col,
+                      int32_t *count_out, void *ws, size_t ws_bytes, void *stream);
+/* The batch of one training step (peoplesnapshot.py:99-151) for n sampled pixels, given either as flat pixel
+ * indices (EdgeSampler) or as n_patch patch corners (PatchSampler; n = n_patch * patch^2, sample (p,i,j) =
+ * corner_p + (i,j)): alpha = mask, rgb = img * mask + (1 - mask) * bg, rays gathered.  img: uint8 [H*W,3]
+ * (divided by 255 as at :107) or float [H*W,3] (give one, the other NULL).  bg [n,3]: uniform draws
+ * (training, :111) or NULL = white (:114).  bg_out / idx_out optional.                                     */
+int ia_sample_batch(const uint8_t *img_u8, const float *img_f, const float *mask, const float *rays_o,
+                    const float *rays_d, int H, int W, const int32_t *flat_idx,
+                    const int32_t *corner_row, const int32_t *corner_col, int n_patch, int patch, int n,
+                    const float *bg, float *rgb, float *alpha, float *o_out, float *d_out,
+                    float *bg_out, int32_t *idx_out, void *stream);
+
 /* ---- measurement hooks (bench.py only) --------------------------------------
  * When enabled, every launch of the Broyden-search kernel (id 0) and of the
  * field kernel (id 1) is bracketed by HIP events on the caller's stream and the

@@ -59,6 +59,14 @@ _SIGS = {
     "ia_hashgrid_bwd_levels": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, C.c_int, C.c_int, _VP]),
     "ia_candidate_gather_fwd": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP]),
     "ia_candidate_gather_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    "ia_make_rays": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, _VP, _VP, _VP]),
+    "ia_mask_edge_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ia_mask_edge": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
+    "ia_nonzero_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ia_nonzero_select": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, _VP,
+                                    _VP, C.c_size_t, _VP]),
+    "ia_sample_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP,
+                                  _VP, _VP, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),
     "ia_field_prepare": (C.c_int, [C.POINTER(Field), _VP, _VP]),
     "ia_smpl_nn_deform": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP]),

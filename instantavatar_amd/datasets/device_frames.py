@@ -1,0 +1,102 @@
+"""The data side of a training step on the device: what
+instant_avatar/datasets/peoplesnapshot.py does per item on the host with numpy / cv2 in 8 DataLoader workers --
+camera rays (:12-25), masked compositing with a random background (:107-115), the sampler call (:117-119), near / far
+(:141-150) -- with the frames resident in HBM and every step a handful of kernels.  At ~1.2 ms per training step the
+host loader would be the bottleneck.
+
+Image decoding and resizing (cv2.imread / cv2.resize, :100-105) stay on the host: they happen once, when the frames
+are uploaded by `DeviceFrames.from_arrays`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils.sampler import EdgeSampler, PatchSampler
+
+
+def make_rays(K, c2w, H, W, device):
+    """peoplesnapshot.py:17-25 on the device: (rays_o, rays_d) float32 [H, W, 3].  K [3,3], c2w [4,4] (or [3,4]): host arrays."""
+    K = np.asarray(K, np.float64)
+    c2w = np.asarray(c2w, np.float64)
+    Kinv = np.ascontiguousarray(np.linalg.inv(K))
+    R = np.ascontiguousarray(c2w[:3, :3])
+    t = np.ascontiguousarray(c2w[:3, 3])
+    o = torch.empty((H, W, 3), device=device)
+    d = torch.empty((H, W, 3), device=device)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _lib.require_cuda(o)
+    _lib.check(_lib.lib().ia_make_rays(dp(Kinv), dp(R), dp(t), H, W, _lib.ptr(o), _lib.ptr(d), _lib.stream()), "ia_make_rays")
+    return o, d
+
+
+class DeviceFrames:
+    """A sequence's frames, masks, camera rays and SMPL parameters resident on the GPU; `batch(idx)` is
+    PeopleSnapshotDataset.__getitem__ for split == "train" (peoplesnapshot.py:99-151) followed by the DataLoader's
+    batch dimension of 1."""
+
+    def __init__(self, images_u8, masks, K, c2w, smpl_params, sampler, near=None, far=None):
+        """images_u8: uint8 [N,H,W,3] (as cv2.imread returns them, already at the training resolution);
+        masks: float [N,H,W]; smpl_params: dict of arrays (betas [1,10], body_pose [N,69], global_orient [N,3], transl [N,3])."""
+        self.images = images_u8
+        self.masks = masks
+        _lib.require_cuda(images_u8, masks)
+        N, H, W, _ = images_u8.shape
+        self.N, self.H, self.W = N, H, W
+        self.rays_o, self.rays_d = make_rays(K, c2w, H, W, images_u8.device)
+        dev = images_u8.device
+        self.smpl_params = {k: torch.as_tensor(np.asarray(v, np.float32), device=dev) for k, v in smpl_params.items()}
+        self.sampler = sampler
+        self.near, self.far = near, far
+
+    @classmethod
+    def from_arrays(cls, images_u8, masks, K, c2w, smpl_params, sampler, device, **kw):
+        return cls(torch.as_tensor(np.ascontiguousarray(images_u8), device=device), torch.as_tensor(np.ascontiguousarray(masks, np.float32), device=device),
+                   K, c2w, smpl_params, sampler, **kw)
+
+    def __len__(self):
+        return self.N
+
+    def batch(self, idx, draws=None, bg_draws=None, generator=None):
+        """One training batch (leading batch dimension 1, as the reference's DataLoader with batch_size=1 yields)."""
+        dev = self.images.device
+        L = _lib.lib()
+        H, W = self.H, self.W
+        mask2d = self.masks[idx]
+        s = self.sampler
+        flat_idx = rows = cols = None
+        if isinstance(s, EdgeSampler):
+            flat_idx = s.sample_indices(mask2d, draws=draws, generator=generator)
+            n, shape, P, n_patch = flat_idx.numel(), (flat_idx.numel(),), 0, 0
+        elif isinstance(s, PatchSampler):
+            rows, cols = s.sample_corners(mask2d, draws=draws, generator=generator)
+            P, n_patch = s.patch_size, s.n
+            n, shape = n_patch * P * P, (n_patch, P, P)
+        else:
+            raise TypeError("DeviceFrames needs an instantavatar_amd.utils.sampler.EdgeSampler / PatchSampler")
+        if bg_draws is None:
+            bg_draws = torch.rand((n, 3), device=dev, generator=generator)    # np.random.rand(*img.shape) at :111, for the sampled pixels
+        bg = bg_draws.reshape(n, 3).float().contiguous()
+        rgb, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev)
+        ro, rd = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
+        img = self.images[idx]
+        img_u8 = img if img.dtype == torch.uint8 else None
+        img_f = None if img_u8 is not None else img.float().contiguous()
+        m = mask2d.float().contiguous()
+        _lib.check(L.ia_sample_batch(_lib.ptr(img_u8), _lib.ptr(img_f), _lib.ptr(m), _lib.ptr(self.rays_o), _lib.ptr(self.rays_d), H, W,
+                                     _lib.ptr(flat_idx), _lib.ptr(rows), _lib.ptr(cols), n_patch, P, n, _lib.ptr(bg), _lib.ptr(rgb),
+                                     _lib.ptr(alpha), _lib.ptr(ro), _lib.ptr(rd), None, None, _lib.stream()), "ia_sample_batch")
+        p = self.smpl_params
+        transl = p["transl"][idx]
+        if self.near is not None and self.far is not None:
+            near, far = torch.full(shape, float(self.near), device=dev), torch.full(shape, float(self.far), device=dev)
+        else:  # distance from the camera to the mid-hip (:146-150)
+            dist = torch.sqrt(torch.square(transl).sum(-1))
+            near, far = (dist - 1).expand(shape).contiguous(), (dist + 1).expand(shape).contiguous()
+        return {
+            "rgb": rgb.reshape(1, *shape, 3), "rays_o": ro.reshape(1, *shape, 3), "rays_d": rd.reshape(1, *shape, 3),
+            "betas": p["betas"][0][None], "global_orient": p["global_orient"][idx][None], "body_pose": p["body_pose"][idx][None],
+            "transl": transl[None], "alpha": alpha.reshape(1, *shape), "bg_color": bg.reshape(1, *shape, 3),
+            "idx": torch.tensor([idx], device=dev), "near": near[None], "far": far[None],
+        }

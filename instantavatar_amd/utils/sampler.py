@@ -1,0 +1,130 @@
+"""Ray samplers on the device (drop-in names for instant_avatar/utils/sampler.py: `EdgeSampler`, `PatchSampler`;
+`confs/sampler/{edge,patch}.yaml` re-point their `_target_` here).
+
+    sampler.sample(mask, *args)  ->  [mask_s, *args_s]
+
+as in the reference, but every tensor lives on the GPU and the pipeline np.where -> random choice -> gather runs as
+HIP kernels without a host round trip (`ia_mask_edge`, `ia_nonzero_select`, gathers by index).  Random numbers are
+uniform draws in [0,1) taken from torch's device generator, or injected (`draws=`) so that tests can feed the CPU
+checker the same numbers.  The mapping from a uniform draw to an index is `floor(u * count)` -- the same
+distribution as np.random.randint / np.random.choice, not the same stream.
+"""
+import torch
+
+from .. import _lib
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def nonzero_select(mask2d, window, u, without_replacement=False):
+    """(row, col) int32 [n] of `np.where(mask2d[y0:y1, x0:x1])` at the ranks derived from the uniform draws `u` [n]
+    (coordinates relative to the window), plus the device-side count of nonzeros."""
+    _lib.require_cuda(mask2d, u)
+    H, W = mask2d.shape
+    y0, y1, x0, x1 = window
+    n = u.numel()
+    L = _lib.lib()
+    dev = mask2d.device
+    row = torch.empty(n, dtype=torch.int32, device=dev)
+    col = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _ws(L.ia_nonzero_select_workspace_bytes(y1 - y0, n), dev)
+    m = mask2d.float().contiguous()
+    uu = u.float().contiguous()
+    _lib.check(L.ia_nonzero_select(_lib.ptr(m), H, W, y0, y1, x0, x1, _lib.ptr(uu), n, int(without_replacement), _lib.ptr(row),
+                                   _lib.ptr(col), _lib.ptr(count), _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_nonzero_select")
+    return row, col, count
+
+
+class EdgeSampler:
+    """instant_avatar/utils/sampler.py:5-46: num_mask pixels inside the mask, num_edge pixels of the band between the
+    eroded and the dilated mask, the rest anywhere."""
+
+    def __init__(self, num_sample, ratio_mask=0.6, ratio_edge=0.3, kernel_size=32):
+        assert ratio_mask >= 0.0 and ratio_edge >= 0.0 and ratio_edge + ratio_mask <= 1.0
+        self.kernel_size = int(kernel_size)
+        self.num_mask = int(num_sample * ratio_mask)
+        self.num_edge = int(num_sample * ratio_edge)
+        self.num_rand = num_sample - self.num_mask - self.num_edge
+
+    def edge_band(self, mask2d):
+        """cv2.dilate(mask, ones(k,k)) - cv2.erode(mask, ones(k,k))  (:25-28)"""
+        _lib.require_cuda(mask2d)
+        H, W = mask2d.shape
+        L = _lib.lib()
+        m = mask2d.float().contiguous()
+        edge = torch.empty_like(m)
+        ws = _ws(L.ia_mask_edge_workspace_bytes(H, W), m.device)
+        _lib.check(L.ia_mask_edge(_lib.ptr(m), H, W, self.kernel_size, _lib.ptr(edge), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "ia_mask_edge")
+        return edge
+
+    def sample_indices(self, mask2d, draws=None, generator=None):
+        """flat pixel indices int32 [num_sample] in the reference's order: mask, edge, random (:33-41)."""
+        H, W = mask2d.shape
+        dev = mask2d.device
+        n = self.num_mask + self.num_edge + self.num_rand
+        if draws is None:
+            draws = torch.rand(n, device=dev, generator=generator)
+        u_m, u_e, u_r = draws[:self.num_mask], draws[self.num_mask:self.num_mask + self.num_edge], draws[self.num_mask + self.num_edge:n]
+        r_m, c_m, _ = nonzero_select(mask2d, (0, H, 0, W), u_m)
+        r_e, c_e, _ = nonzero_select(self.edge_band(mask2d), (0, H, 0, W), u_e)
+        rand_idx = torch.clamp((u_r.float() * float(H * W)).floor(), max=H * W - 1).to(torch.int32)
+        return torch.cat([r_m * W + c_m, r_e * W + c_e, rand_idx])
+
+    def sample(self, mask, *args, draws=None, generator=None):
+        mask2d = mask if mask.dim() == 2 else mask.reshape(mask.shape[0], -1)
+        idx = self.sample_indices(mask2d, draws=draws, generator=generator).long()
+        flat = mask2d.reshape(-1)
+        out = [flat[idx]]
+        for d in args:
+            out.append(d.reshape(flat.numel(), -1)[idx])
+        return out
+
+
+class PatchSampler:
+    """instant_avatar/utils/sampler.py:48-82: num_patch square patches; with probability ratio_mask their anchor pixels
+    are drawn (without replacement) from the mask cropped by half a patch, else uniformly."""
+
+    def __init__(self, num_patch=4, patch_size=20, ratio_mask=0.9, dilate=0):
+        self.n = num_patch
+        self.patch_size = patch_size
+        self.p = ratio_mask
+        self.dilate = dilate
+        assert self.patch_size % 2 == 0, "patch size has to be even"
+        if dilate > 0:
+            raise NotImplementedError("PatchSampler(dilate > 0) is not used by any shipped configuration (confs/sampler/patch.yaml: 0)")
+
+    def sample_corners(self, mask2d, draws=None, generator=None):
+        """(row, col) int32 [num_patch] of the patches' top-left corners.  draws: [1 + 2 * num_patch] uniform numbers --
+        the branch coin (:60), then the anchor draws (mask branch: the first num_patch; uniform branch: rows then columns)."""
+        H, W = mask2d.shape
+        dev = mask2d.device
+        P = self.patch_size
+        if draws is None:
+            draws = torch.rand(1 + 2 * self.n, device=dev, generator=generator)
+        coin, rest = draws[0], draws[1:]
+        o = P // 2
+        # both branches are evaluated on the device and blended by the coin: no host read of a random number
+        r_m, c_m, count = nonzero_select(mask2d, (o, H - o, o, W - o), rest[:self.n], without_replacement=True)
+        r_u = torch.clamp((rest[:self.n].float() * float(H - P)).floor(), max=H - P - 1).to(torch.int32)   # np.random.randint(0, H - P)
+        c_u = torch.clamp((rest[self.n:2 * self.n].float() * float(W - P)).floor(), max=W - P - 1).to(torch.int32)
+        use_mask = coin < self.p
+        return torch.where(use_mask, r_m, r_u), torch.where(use_mask, c_m, c_u)
+
+    def sample(self, mask, *args, draws=None, generator=None):
+        mask2d = mask.reshape(mask.shape[0], mask.shape[1])
+        rows, cols = self.sample_corners(mask2d, draws=draws, generator=generator)
+        P = self.patch_size
+        ar = torch.arange(P, device=mask.device)
+        yy = (rows.long()[:, None, None] + ar[None, :, None]).expand(-1, P, P)
+        xx = (cols.long()[:, None, None] + ar[None, None, :]).expand(-1, P, P)
+        out = []
+        for d in (mask, *args):
+            p = d[yy, xx]
+            if p.shape[-1] == 1 and p.dim() == 4:
+                p = p.squeeze(-1)
+            out.append(p)
+        return out

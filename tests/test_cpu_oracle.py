@@ -418,3 +418,32 @@ def test_tcnn_param_vector_sizes_and_loader_messages(oracle, monkeypatch):
     monkeypatch.setenv("IA_TCNN_LEVEL3_RES", "55")             # the suite-wide switch
     assert NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])).encoder.params.numel() == sizes[55]
     assert int(oracle.hash_desc().res[3]) == 55
+
+
+# ---------------------------------------------------------------- f4: data-side checker
+def test_data_oracle_erode_dilate_match_scipy_and_sampler_semantics():
+    """oracle/data_oracle.py: the cv2.erode / cv2.dilate restatement against scipy.ndimage (an independent box
+    min / max filter with the same anchor and ignored borders), and the sampler index rules of sampler.py:22-41,56-73."""
+    from scipy import ndimage
+    from oracle import data_oracle as do
+    rng = np.random.RandomState(0)
+    m = np.zeros((60, 47), np.float32)
+    m[15:40, 10:30] = 1
+    m[5:9, 35:44] = 1
+    m += (rng.rand(60, 47) > 0.995)
+    for k in (3, 4, 16):
+        e = ndimage.minimum_filter(m, size=k, mode="constant", cval=np.inf)
+        d = ndimage.maximum_filter(m, size=k, mode="constant", cval=-np.inf)
+        assert np.array_equal(do.erode(m, k), e) and np.array_equal(do.dilate(m, k), d), k
+    draws = rng.rand(200).astype(np.float32)
+    idx = do.edge_sampler_indices(m, draws, num_sample=200, ratio_mask=0.6, ratio_edge=0.3, kernel_size=4)
+    flat, band = m.reshape(-1), (do.dilate(m, 4) - do.erode(m, 4)).reshape(-1)
+    assert (flat[idx[:120]] != 0).all() and (band[idx[120:180]] != 0).all() and len(idx) == 200
+    # anchors of the mask branch: distinct, and a patch of size P anchored there is centred on a mask pixel
+    x, y = do.patch_sampler_corners(m, np.r_[0.0, rng.rand(8)].astype(np.float32), num_patch=4, patch_size=8, ratio_mask=1)
+    assert len(set(zip(x.tolist(), y.tolist()))) == 4 and all(m[a + 4, b + 4] > 0 for a, b in zip(x, y))
+    x, y = do.patch_sampler_corners(m, np.r_[0.99, rng.rand(8)].astype(np.float32), num_patch=4, patch_size=8, ratio_mask=0.5)
+    assert (x >= 0).all() and (x < 60 - 8).all() and (y < 47 - 8).all()
+    K = np.array([[900.0, 0, 23.5], [0, 900.0, 30.0], [0, 0, 1]])
+    o, d = do.make_rays(K, np.eye(4), 60, 47)
+    assert o.shape == (60, 47, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1, atol=1e-6) and abs(d[30, 23, 2] - 1) < 1e-3
