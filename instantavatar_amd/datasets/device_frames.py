@@ -92,7 +92,8 @@ class DeviceFrames:
         if self.near is not None and self.far is not None:
             near, far = torch.full(shape, float(self.near), device=dev), torch.full(shape, float(self.far), device=dev)
         else:  # distance from the camera to the mid-hip (:146-150)
-            dist = torch.sqrt(torch.square(transl).sum(-1))
+            sq = torch.square(transl)
+            dist = torch.sqrt((sq[0] + sq[1]) + sq[2])   # numpy's summation order for three float32 terms
             near, far = (dist - 1).expand(shape).contiguous(), (dist + 1).expand(shape).contiguous()
         return {
             "rgb": rgb.reshape(1, *shape, 3), "rays_o": ro.reshape(1, *shape, 3), "rays_d": rd.reshape(1, *shape, 3),
