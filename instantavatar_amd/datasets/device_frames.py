@@ -99,5 +99,6 @@ class DeviceFrames:
             "rgb": rgb.reshape(1, *shape, 3), "rays_o": ro.reshape(1, *shape, 3), "rays_d": rd.reshape(1, *shape, 3),
             "betas": p["betas"][0][None], "global_orient": p["global_orient"][idx][None], "body_pose": p["body_pose"][idx][None],
             "transl": transl[None], "alpha": alpha.reshape(1, *shape), "bg_color": bg.reshape(1, *shape, 3),
-            "idx": torch.tensor([idx], device=dev), "near": near[None], "far": far[None],
+            "idx": torch.tensor([idx]),   # host tensor: the trainer reads it as a Python int (renderer.idx) without a device sync
+            "near": near[None], "far": far[None],
         }

@@ -1,0 +1,117 @@
+"""`fit.py` without Lightning / Hydra (reference: fit.py:15-75, confs/SNARF_NGP_fitting.yaml): the stage of the
+Neuman pipeline (bash/run-neuman-demo.sh:6) that optimises the per-frame SMPL parameters TOGETHER with a field through
+the `SMPLDeformer` plugin (deformer=smpl), on patch batches (sampler=patch) with NGPLoss, and writes the optimised
+parameters to `<out>/poses/train.npz` for the train stage.
+
+    python -m instantavatar_amd.drivers.fit --synthetic --steps 200 --out /tmp/seq
+
+`fit_sequence(...)` takes any `DeviceFrames` (instantavatar_amd/datasets/device_frames.py); `--synthetic` builds one
+from the synthetic avatar with perturbed initial poses (no dataset ships with this package).  The LPIPS term of the
+reference's loss needs pretrained VGG weights and is not available offline (NGPLoss raises when asked for it).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .. import synthetic
+from ..datasets.device_frames import DeviceFrames
+from ..deformers.smpl_deformer import SMPLDeformer
+from ..deformers.smplx import SMPL
+from ..models.networks.ngp import NeRFNGPNet
+from ..models.structures.body_model_param import SMPLParamEmbedding
+from ..pipeline import AvatarModel, build_synthetic_model, make_batch
+from ..renderers.raymarcher_acc import Raymarcher
+from ..training import NGPLoss, configure_optimizer, configure_scheduler, training_step
+from ..utils.sampler import PatchSampler
+
+
+def build_fit_model(frames, body_model, device, threshold=0.05, n_levels=16):
+    """DNeRFModel.__init__ for the fitting configuration (DNeRF.py:18-30): NeRFNGPNet + SMPLDeformer + Raymarcher and
+    the SMPL parameter embedding initialised from the dataset (datamodule.trainset.get_SMPL_params())."""
+    deformer = SMPLDeformer(None, "neutral", threshold=threshold, k=1, body_model=body_model)
+    net = NeRFNGPNet(dict(center=[0, -0.3, 0], scale=[2.5, 2.5, 2.5]), n_levels=n_levels).to(device)
+    renderer = Raymarcher(256, 291600).to(device)
+    renderer.initialize(len(frames))
+    model = AvatarModel(deformer, net, renderer).to(device)
+    model.SMPL_param = SMPLParamEmbedding(**{k: v.detach().cpu() for k, v in frames.smpl_params.items()}).to(device)
+    return model
+
+
+def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, loss_opt=None, log_every=50, out=sys.stdout,
+                 generator=None):
+    """The optimisation loop of fit.py (trainer.fit with SNARF_NGP_fitting.yaml: Adam lr 1e-3, SMPL tables lr 1e-4,
+    LambdaLR per epoch, one frame per step).  Returns the last losses."""
+    opt = configure_optimizer(model, lr=lr, smpl_lr=smpl_lr)
+    sched = configure_scheduler(opt, max_epochs)
+    loss_fn = NGPLoss(loss_opt or dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
+    model.train()
+    n = len(frames)
+    order = torch.randperm(n, generator=generator).tolist()
+    t0 = time.perf_counter()
+    losses = None
+    for it in range(steps):
+        if it % n == 0 and it > 0:
+            sched.step()
+            order = torch.randperm(n, generator=generator).tolist()   # DataLoader(shuffle=True)
+        losses = training_step(model, frames.batch(order[it % n]), opt, loss_fn)
+        if log_every and (it + 1) % log_every == 0:
+            torch.cuda.synchronize()
+            print("fit step %d  loss %.5f  mse %.5f  %.1f it/s" % (it + 1, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
+                                                                   (it + 1) / (time.perf_counter() - t0)), file=out)
+    return losses
+
+
+def export_params(model, out_dir):
+    """fit.py:48-64: optimised SMPL tables -> <out_dir>/poses/train.npz"""
+    root = os.path.join(out_dir, "poses")
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, "train.npz")
+    np.savez(path, **model.SMPL_param.export())
+    return path
+
+
+def synthetic_frames(device, res=128, n_frames=4, noise=0.02, seed=0, patch=32):
+    """Frames rendered from the synthetic avatar; the SMPL parameters handed to the fit stage are perturbed."""
+    teacher, body, _ = build_synthetic_model(device, resolution=64)
+    poses, tr = synthetic.procedural_pose_track(max(n_frames, 8))
+    imgs, masks = [], []
+    with torch.no_grad():
+        for f in range(n_frames):
+            rgb, _, alpha, _ = teacher.render_image_fast(make_batch(device, res, poses[f], tr[f]), (res, res))
+            imgs.append((rgb[0].clamp(0, 1) * 255).round().to(torch.uint8))
+            masks.append((alpha[0] > 0.5).float())
+    rng = np.random.RandomState(seed)
+    K = np.array([[2000.0 * res / 1080, 0, res / 2], [0, 2000.0 * res / 1080, res / 2], [0, 0, 1]])
+    true = dict(betas=np.zeros((1, 10), np.float32), body_pose=poses[:n_frames, 3:].copy(), global_orient=poses[:n_frames, :3].copy(),
+                transl=tr[:n_frames].copy())
+    init = {k: v.copy() for k, v in true.items()}
+    init["body_pose"] += rng.randn(*init["body_pose"].shape).astype(np.float32) * noise
+    init["transl"] += rng.randn(*init["transl"].shape).astype(np.float32) * noise * 0.5
+    frames = DeviceFrames(torch.stack(imgs), torch.stack(masks), K, np.eye(4), init, PatchSampler(num_patch=4, patch_size=patch, ratio_mask=1))
+    return frames, SMPL.from_dict(body).to(device), true
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--synthetic", action="store_true", required=True)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--out", default="outputs/fit")
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("fit: needs a GPU (the product path has no CPU fallback)")
+    device = torch.device("cuda", 0)
+    frames, body_model, _ = synthetic_frames(device, res=args.res)
+    model = build_fit_model(frames, body_model, device)
+    losses = fit_sequence(model, frames, args.steps)
+    path = export_params(model, args.out)
+    print("saved %s (mse %.5f)" % (path, float(losses["mse_loss"])))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

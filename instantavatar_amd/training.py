@@ -232,14 +232,45 @@ class NeRFLoss(torch.nn.Module):
         return losses
 
 
-def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
-    """DNeRFModel.configure_optimizers (DNeRF.py:32-59): one Adam, hash encoding and
-    the rest in separate groups."""
-    enc, rest = [], []
+class NGPLoss(NeRFLoss):
+    """instant_avatar/utils/loss.py:8-50: NeRFLoss + (on patch batches [1, n_patch, P, P, 3]) the depth-variance
+    regulariser; the LPIPS term needs the pretrained VGG weights of third_parties/lpips, which cannot be fetched
+    offline -- `w_lpips > 0` raises instead of silently training without it."""
+
+    def __init__(self, opt=None, fused=True):
+        super().__init__(opt, fused=fused)
+        self.w_lpips = _opt.get(opt, "w_lpips", 0)
+        self.w_depth_reg = _opt.get(opt, "w_depth_reg", 0)
+        if self.w_lpips > 0:
+            raise NotImplementedError("NGPLoss: w_lpips > 0 needs the pretrained LPIPS/VGG weights (not available offline); set w_lpips=0")
+
+    def forward(self, predicts, targets):
+        losses = super().forward(predicts, targets)
+        if self.w_depth_reg > 0 and predicts["rgb_coarse"].dim() == 5:       # loss.py:33-39
+            a, d = predicts["alpha_coarse"], predicts["depth_coarse"]
+            alpha_sum = a.sum(dim=(-1, -2))
+            depth_avg = (d * a).sum(dim=(-1, -2)) / (alpha_sum + 1e-3)
+            reg = (a * (d - depth_avg[..., None, None]).abs()).mean()
+            losses["loss_depth_reg"] = reg
+            losses["loss"] = losses["loss"] + self.w_depth_reg * reg
+        return losses
+
+
+def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=5e-4):
+    """DNeRFModel.configure_optimizers (DNeRF.py:32-59): one Adam; hash encoding, the rest, and -- when the model
+    carries a `SMPL_param` embedding (optimize_SMPL.enable) -- the SMPL tables with their own learning rate."""
+    enc, rest, body = [], [], []
     for name, p in model.named_parameters():
-        (enc if "encoder" in name else rest).append(p)
-    opt = torch.optim.Adam([{"params": enc}, {"params": rest}], lr=lr, betas=betas, eps=eps,
-                           fused=bool(enc and enc[0].is_cuda))
+        if name.startswith("loss_fn"):
+            continue
+        if name.startswith("SMPL_param"):
+            body.append(p)
+        else:
+            (enc if "encoder" in name else rest).append(p)
+    groups = [{"params": enc}, {"params": rest}]
+    if body:
+        groups.append({"params": body, "lr": smpl_lr})
+    opt = torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps, fused=bool(enc and enc[0].is_cuda))
     return opt
 
 
@@ -319,6 +350,17 @@ def update_density_grid(model, world_size=1, jitter=None):
 def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False):
     """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs."""
     from . import parallel
+    if getattr(model, "SMPL_param", None) is not None:            # DNeRF.py:113-128 (optimize_SMPL.enable)
+        batch = dict(batch)
+        body_params = model.SMPL_param(batch["idx"].reshape(-1).long().to(model.SMPL_param.betas.weight.device))
+        for k in ("global_orient", "body_pose", "transl"):
+            batch[k] = body_params[k]
+        from .deformers.smpl_deformer import SMPLDeformer
+        if isinstance(model.deformer, SMPLDeformer):
+            batch["betas"] = body_params["betas"]
+        dist = torch.norm(batch["transl"], dim=-1, keepdim=True).detach()   # near / far follow the refined translation
+        batch["near"] = (dist - 1).reshape(1, *([1] * (batch["near"].dim() - 1))).expand_as(batch["near"]).contiguous()
+        batch["far"] = (dist + 1).reshape(1, *([1] * (batch["far"].dim() - 1))).expand_as(batch["far"]).contiguous()
     model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
     model.deformer.prepare_deformer(batch)
     reducer = parallel.GradReducer(world_size)
