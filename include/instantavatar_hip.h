@@ -224,6 +224,10 @@ int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
  * (input of ia_hashgrid_bwd) and the five weight gradients, ACCUMULATED in fp32 into
  * g_* (tcnn layouts [out][in]; caller zero-fills) -- per-workgroup partial sums in `ws`, added
  * up in a fixed order: no atomics, bitwise reproducible.  Needs field->mlp_frags.          */
+/* The scale for ia_field_bwd: *scale = 1024 / max(|d_rgb * rgb (1 - rgb)|, |d_sigma|) over the live samples, in one
+ * launch without a host read.  state2: DEVICE uint32[2], zero on first use, left zero by every call.            */
+int ia_field_grad_scale(const float *rgb, const float *d_rgb, const float *d_sigma, int V,
+                        const int32_t *n_dev, uint32_t *state2, float *scale, void *stream);
 size_t ia_field_bwd_workspace_bytes(int V, int n_levels);
 int ia_field_bwd(const uint16_t *acts, const float *rgb, const float *d_rgb,
                  const float *d_sigma, int V, const int32_t *n_dev, const float *scale,

@@ -1010,6 +1010,55 @@ __global__ __launch_bounds__(256) void k_field_bwd_reduce(const float *__restric
   *dst += tot * (1.0f / *scale);
 }
 
+// Per-call gradient scale of the fused MLP backward: S = 1024 / max(|dL/drgb * rgb (1 - rgb)|, |dL/dsigma|) over the
+// LIVE samples (tcnn relies on a fixed 1024x loss scale, DNeRF.py:58; here the largest incoming gradient is placed at
+// 2^10 before the cast to half).  One launch, no host read: block maxima meet in an atomicMax on the float's bit
+// pattern (non-negative floats order like integers), the last block to arrive (ticket) writes S and leaves the two
+// state words zero for the next call.  Replaces five elementwise / reduction launches over the capacity-sized buffers.
+__global__ __launch_bounds__(256) void k_grad_scale(const float *__restrict__ rgb, const float *__restrict__ d_rgb,
+                                                    const float *__restrict__ d_sigma, int V, const int32_t *__restrict__ n_dev,
+                                                    uint32_t *__restrict__ state /*[2]: max bits, tickets*/, float *__restrict__ scale) {
+  if (n_dev) V = min(V, *n_dev);
+  float m = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float y = rgb[(size_t)i * 3 + c];
+      const float g = fabsf(d_rgb[(size_t)i * 3 + c] * y * (1.0f - y));
+      m = (g > m || isnan(g)) ? g : m;   // NaN propagates: the step is skipped by the non-finite check downstream
+    }
+    const float gs = fabsf(d_sigma[i]);
+    m = (gs > m || isnan(gs)) ? gs : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o, 64); m = (t > m || isnan(t)) ? t : m; }
+  __shared__ float s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) m = (s_m[w] > m || isnan(s_m[w])) ? s_m[w] : m;
+    atomicMax(&state[0], isnan(m) ? 0x7fc00000u : __float_as_uint(m));   // NaN's bit pattern is above every finite value's
+    __threadfence();
+    const uint32_t t = atomicAdd(&state[1], 1u);
+    if (t == gridDim.x - 1) {
+      const float amax = __uint_as_float(atomicExch(&state[0], 0u));
+      atomicExch(&state[1], 0u);
+      *scale = 1024.0f / fmaxf(amax, 1e-30f);  // NaN in -> NaN out
+    }
+  }
+}
+
+extern "C" int ia_field_grad_scale(const float *rgb, const float *d_rgb, const float *d_sigma, int V, const int32_t *n_dev,
+                                   uint32_t *state2, float *scale, void *stream) {
+  IA_CHECK_ARG(V >= 0 && state2 && scale, "ia_field_grad_scale: bad arguments");
+  IA_CHECK_ARG(V == 0 || (rgb && d_rgb && d_sigma), "ia_field_grad_scale: null pointer");
+  int blocks = (V + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  hipLaunchKernelGGL(k_grad_scale, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, d_rgb, d_sigma, V, n_dev, state2, scale);
+  IA_LAUNCH_CHECK("k_grad_scale");
+  return IA_OK;
+}
+
 static int ia_field_bwd_nblocks(int V) {
   const int n_tiles = (V + 31) / 32, per = IA_BWD_THREADS / 64;
   int nb = (n_tiles + per - 1) / per;

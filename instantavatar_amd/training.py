@@ -79,13 +79,17 @@ class _FieldFn(torch.autograd.Function):
         d_rgb = d_rgb.reshape(V, 3).float().contiguous()
         d_sigma = d_sigma.reshape(V).float().contiguous()
         # gradients are rescaled per call so that their largest magnitude sits at 2^10 before the
-        # cast to half (tcnn relies on a fixed 1024x loss scale, DNeRF.py:58); device scalar, no sync
-        amax = torch.maximum((d_rgb * rgb * (1 - rgb)).abs().max(), d_sigma.abs().max()).clamp(min=1e-30)
-        S = (1024.0 / amax).reshape(1)
+        # cast to half (tcnn relies on a fixed 1024x loss scale, DNeRF.py:58); device scalar, no sync, one launch
+        L = _lib.lib()
+        S = torch.empty(1, device=xc.device)
+        state = getattr(net, "_grad_scale_state", None)
+        if state is None or state.device != xc.device:
+            state = net._grad_scale_state = torch.zeros(2, dtype=torch.int32, device=xc.device)
+        _lib.check(L.ia_field_grad_scale(_lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V, _lib.ptr(ctx.n_dev), _lib.ptr(state),
+                                         _lib.ptr(S), _lib.stream()), "ia_field_grad_scale")
         g_enc = _grad_buffer(net.encoder.params)
         g_col = _grad_buffer(net.color_net.params)
         n1 = net.sig_w1_size
-        L = _lib.lib()
         if FUSED_MLP_BACKWARD:
             dfeat = torch.empty((V, nf), device=xc.device)
             base_e, base_c = g_enc.data_ptr(), g_col.data_ptr()
