@@ -421,6 +421,15 @@ int ia_candidate_gather_fwd(const float *cand_rgb, const float *cand_sigma, cons
 int ia_candidate_gather_bwd(const float *d_rgb, const float *d_sigma, const int32_t *arg, int P,
                             float *d_cand_rgb, float *d_cand_sigma, void *stream);
 
+/* ---- Raymarcher(smpl_init=True): mesh bootstrap of the training occupancy grid ----------------
+ * (density_grid.py:53-75).  sdf[i] = (inside ? -1 : +1) * distance of pts[i] to the triangle mesh
+ * (verts [V,3], faces int32 [F,3], watertight); replaces kaolin's point_to_mesh_distance + check_sign
+ * (absent: restated from their definitions, floating-point parity with kaolin unpinned).                 */
+int ia_mesh_signed_distance(const float *pts, long N, const float *verts, const int32_t *faces,
+                            int n_faces, float *sdf, void *stream);
+/* cell centres denormalize(coords + 0.5 / G, aabb) of a G^3 grid (density_grid.py:55); aabb: DEVICE [6]. */
+int ia_grid_cell_centres(int G, const float *aabb, float *pts, void *stream);
+
 /* ---- f4: the data side of a training step, on the device ----------------------
  * make_rays (instant_avatar/datasets/peoplesnapshot.py:12-25): rays_o / rays_d [H*W,3] fp32 of a pinhole
  * camera, evaluated in fp64 like the reference's numpy code.  K_inv [9], c2w_R [9] (row-major), c2w_t [3]:

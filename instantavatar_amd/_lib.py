@@ -59,6 +59,8 @@ _SIGS = {
     "ia_hashgrid_bwd_levels": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, C.c_int, C.c_int, _VP]),
     "ia_candidate_gather_fwd": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP]),
     "ia_candidate_gather_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    "ia_mesh_signed_distance": (C.c_int, [_VP, C.c_long, _VP, _VP, C.c_int, _VP, _VP]),
+    "ia_grid_cell_centres": (C.c_int, [C.c_int, _VP, _VP, _VP]),
     "ia_make_rays": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, _VP, _VP, _VP]),
     "ia_mask_edge_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_mask_edge": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),

@@ -135,6 +135,24 @@ class DensityGrid(torch.nn.Module):
         self.density_probe = density
         self._postprocess(density)
 
+    def mesh_signed_distance(self, vertices, faces):
+        """signed distance [G,G,G] of the cell centres (coords + 0.5 / G, density_grid.py:55) to the triangle mesh
+        (`ia_mesh_signed_distance`; the reference calls kaolin's point_to_mesh_distance and check_sign, :62-70)."""
+        G = self.grid_size
+        dev = self.density_cached.device
+        v = vertices.detach().reshape(-1, 3).float().contiguous()
+        f = faces.reshape(-1, 3).to(device=dev, dtype=torch.int32).contiguous()
+        if f.numel() == 0:
+            raise ValueError("smpl_init needs the body model's triangle faces (body_model.faces_tensor is empty)")
+        _lib.require_cuda(v)
+        L = _lib.lib()
+        pts = torch.empty((G * G * G, 3), device=dev)
+        sd = torch.empty(G * G * G, device=dev)
+        _lib.check(L.ia_grid_cell_centres(G, _lib.ptr(self.aabb_tensor()), _lib.ptr(pts), _lib.stream()), "ia_grid_cell_centres")
+        _lib.check(L.ia_mesh_signed_distance(_lib.ptr(pts), G * G * G, _lib.ptr(v), _lib.ptr(f), f.shape[0], _lib.ptr(sd), _lib.stream()),
+                   "ia_mesh_signed_distance")
+        return sd.reshape(G, G, G)
+
     # -- training-time grid ---------------------------------------------------------
     def update(self, deformer, net, step, reduce_hook=None, jitter=None):
         """density_grid.py:46-92.  `reduce_hook(density_cached)` (optional) runs between the EMA update
@@ -150,11 +168,19 @@ class DensityGrid(torch.nn.Module):
         density = density.clip(min=0).reshape(coords.shape[:-1])
         old = self.density_field
         if step < 500 and self.smpl_init:
-            raise NotImplementedError("smpl_init occupancy bootstrap (kaolin mesh distances) is out of scope")
-        self.density_cached = torch.maximum(self.density_cached * 0.8, density.detach())
-        if reduce_hook is not None:
-            reduce_hook(self.density_cached)
-        self._postprocess(self.density_cached)
+            # density_grid.py:53-75: for the first 500 steps the grid is the posed SMPL mesh (+1 cm), set once
+            if not self.initialized:
+                sd = self.mesh_signed_distance(deformer.vertices, deformer.body_model.faces_tensor)
+                self.density_field = sd < 0.01
+                opacity = -torch.log(1 - self.density_field.float()) * 100
+                self.density_cached = torch.maximum(self.density_cached * 0.8, opacity)
+                self.pack_bits()
+                self.initialized = True
+        else:
+            self.density_cached = torch.maximum(self.density_cached * 0.8, density.detach())
+            if reduce_hook is not None:
+                reduce_hook(self.density_cached)
+            self._postprocess(self.density_cached)
         density = 1 - torch.exp(0.01 * -F.relu(density))
         valid = self.density_field if step < 500 else old
         return density, valid

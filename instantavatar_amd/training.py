@@ -335,7 +335,7 @@ def update_density_grid(model, world_size=1, jitter=None):
     """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the cached densities are
     MAX-reduced between the EMA update and the thresholding (DensityGrid.update's reduce hook), so every
     rank thresholds -- and regularises with -- the same field, once."""
-    N = 20
+    N = 1 if getattr(model.renderer, "smpl_init", False) else 20   # DNeRF.py:100
     if model.global_step % N != 0:
         return None
     grid = model.renderer.density_grid_train

@@ -798,3 +798,92 @@ void orc_smpl_nn_deform(const float *pts, long P, const float *verts, int Vn,
 }
 
 int orc_version(void) { return 1; }
+
+
+/* ------------------------------------------------------------------------ */
+/* smpl_init bootstrap (models/structures/density_grid.py:53-75): signed      */
+/* distance of points to a watertight triangle mesh.  kaolin (the reference's */
+/* provider of point_to_mesh_distance / check_sign) is absent: restated from  */
+/* the definitions -- closest point on a triangle by its Voronoi regions,     */
+/* inside = odd number of crossings of the +x ray (projected test in double,  */
+/* half-open edge rule).  Parity with kaolin's arithmetic is unpinned; the    */
+/* CPU suite checks this restatement against the analytic distance of a box.  */
+/* ------------------------------------------------------------------------ */
+static float orc_tri_dist2(const float *p, const float *a, const float *b, const float *c) {
+  float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  float ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]}, q[3];
+#define ODOT(u, v) ((u)[0] * (v)[0] + (u)[1] * (v)[1] + (u)[2] * (v)[2])
+  float d1 = ODOT(ab, ap), d2 = ODOT(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) { q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; }
+  else {
+    float bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+    float d3 = ODOT(ab, bp), d4 = ODOT(ac, bp);
+    if (d3 >= 0.f && d4 <= d3) { q[0] = b[0]; q[1] = b[1]; q[2] = b[2]; }
+    else {
+      float vc = d1 * d4 - d3 * d2;
+      if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+        float v = d1 / (d1 - d3);
+        for (int k = 0; k < 3; k++) q[k] = a[k] + v * ab[k];
+      } else {
+        float cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+        float d5 = ODOT(ab, cp), d6 = ODOT(ac, cp);
+        if (d6 >= 0.f && d5 <= d6) { q[0] = c[0]; q[1] = c[1]; q[2] = c[2]; }
+        else {
+          float vb = d5 * d2 - d1 * d6;
+          if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+            float w = d2 / (d2 - d6);
+            for (int k = 0; k < 3; k++) q[k] = a[k] + w * ac[k];
+          } else {
+            float va = d3 * d6 - d5 * d4;
+            if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+              float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+              for (int k = 0; k < 3; k++) q[k] = b[k] + w * (c[k] - b[k]);
+            } else {
+              float denom = 1.f / (va + vb + vc);
+              float v = vb * denom, w = vc * denom;
+              for (int k = 0; k < 3; k++) q[k] = a[k] + ab[k] * v + ac[k] * w;
+            }
+          }
+        }
+      }
+    }
+  }
+#undef ODOT
+  float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+static int orc_ray_x_crosses(const float *p, const float *a, const float *b, const float *c) {
+  double py = p[1], pz = p[2];
+  const float *u[3] = {a, b, c}, *v[3] = {b, c, a};
+  double e[3]; int tl[3];
+  for (int k = 0; k < 3; k++) {
+    double uy = u[k][1], uz = u[k][2], vy = v[k][1], vz = v[k][2];
+    e[k] = (vy - uy) * (pz - uz) - (vz - uz) * (py - uy);
+    tl[k] = (vz == uz) ? (vy < uy) : (vz < uz);
+  }
+  double area = ((double)b[1] - a[1]) * ((double)c[2] - a[2]) - ((double)b[2] - a[2]) * ((double)c[1] - a[1]);
+  if (area == 0.0) return 0;
+  double s = area > 0.0 ? 1.0 : -1.0;
+  for (int k = 0; k < 3; k++) { e[k] *= s; if (area < 0.0) tl[k] = !tl[k]; }
+  for (int k = 0; k < 3; k++) if (!(e[k] > 0.0 || (e[k] == 0.0 && tl[k]))) return 0;
+  double A = fabs(area);
+  double x = (e[1] * a[0] + e[2] * b[0] + e[0] * c[0]) / A;
+  return x > (double)p[0];
+}
+
+void orc_mesh_sdf(const float *pts, long N, const float *verts, const int *faces, int F, float *sdf) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long i = 0; i < N; i++) {
+    const float *p = pts + i * 3;
+    float best = INFINITY;
+    int crossings = 0;
+    for (int f = 0; f < F; f++) {
+      const float *a = verts + (long)faces[f * 3] * 3, *b = verts + (long)faces[f * 3 + 1] * 3, *c = verts + (long)faces[f * 3 + 2] * 3;
+      float d = orc_tri_dist2(p, a, b, c);
+      best = d < best ? d : best;
+      crossings += orc_ray_x_crosses(p, a, b, c);
+    }
+    sdf[i] = ((crossings & 1) ? -1.f : 1.f) * sqrtf(best);
+  }
+}

@@ -339,6 +339,31 @@ def density_grid_update(world, density_cached, density_field_old, jitter, step, 
                 density=dens_out.reshape(G, G, G), valid=valid.reshape(G, G, G))
 
 
+def mesh_signed_distance(pts, verts, faces):
+    """kaolin point_to_mesh_distance(...).sqrt() * (1 - 2 * check_sign(...)) as used at density_grid.py:62-70
+    (restated from the definitions; kaolin itself is absent)."""
+    pts, verts = _f32(pts).reshape(-1, 3), _f32(verts).reshape(-1, 3)
+    faces = np.ascontiguousarray(faces, np.int32).reshape(-1, 3)
+    out = np.empty(len(pts), np.float32)
+    lib().orc_mesh_sdf(_p(pts), C.c_long(len(pts)), _p(verts), _p(faces), C.c_int(len(faces)), _p(out))
+    return out
+
+
+def density_grid_smpl_init(verts, faces, density_cached, G=64, aabb=TRAIN_AABB):
+    """DensityGrid.update, first call of the `smpl_init` branch (density_grid.py:53-75): cells whose centre lies inside the
+    posed mesh or within 1 cm of it start occupied; their cached density becomes +inf (-log(1 - 1) * 100)."""
+    idx = np.arange(G, dtype=np.float32)
+    cx, cy, cz = np.meshgrid(idx, idx, idx, indexing="ij")
+    coords0 = (np.stack([cx, cy, cz], -1).reshape(-1, 3) / np.float32(G)).astype(np.float32)
+    coords = ((coords0 + np.float32(0.5) / np.float32(G)) * (aabb[1] - aabb[0]) + aabb[0]).astype(np.float32)
+    sd = mesh_signed_distance(coords, verts, faces)
+    field = sd < np.float32(0.01)
+    with np.errstate(divide="ignore"):
+        opacity = (-np.log(np.float32(1) - field.astype(np.float32)) * np.float32(100)).astype(np.float32)
+    cached = np.maximum(_f32(density_cached).reshape(-1) * np.float32(0.8), opacity)
+    return dict(signed_distance=sd.reshape(G, G, G), density_field=field.reshape(G, G, G), density_cached=cached.reshape(G, G, G))
+
+
 def update_density_grid_reg(density, valid, step, N=20):
     """DNeRFModel.update_density_grid (DNeRF.py:99-110): reg = N * mean(density outside the grid)
     (+ 0.5 * mean(density) for the first 500 steps)."""

@@ -447,3 +447,52 @@ def test_data_oracle_erode_dilate_match_scipy_and_sampler_semantics():
     K = np.array([[900.0, 0, 23.5], [0, 900.0, 30.0], [0, 0, 1]])
     o, d = do.make_rays(K, np.eye(4), 60, 47)
     assert o.shape == (60, 47, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1, atol=1e-6) and abs(d[30, 23, 2] - 1) < 1e-3
+
+
+# ---------------------------------------------------------------- smpl_init: mesh signed distance
+def _cube_mesh(h=0.5):
+    v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    f = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], np.int32)
+    return v, f
+
+
+def _uv_sphere(r=0.6, n_lat=24, n_lon=48, scale=(1.0, 1.3, 0.8), centre=(0.05, -0.2, 0.1)):
+    """closed triangle mesh of an ellipsoid (poles as single vertices)"""
+    vs = [(0, 0, r)]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            vs.append((r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), r * np.cos(th)))
+    vs.append((0, 0, -r))
+    v = (np.array(vs, np.float32) * np.array(scale, np.float32) + np.array(centre, np.float32)).astype(np.float32)
+    f = []
+    ring = lambda i, j: 1 + (i - 1) * n_lon + j % n_lon
+    for j in range(n_lon):
+        f.append((0, ring(1, j), ring(1, j + 1)))
+        f.append((len(vs) - 1, ring(n_lat - 1, j + 1), ring(n_lat - 1, j)))
+    for i in range(1, n_lat - 1):
+        for j in range(n_lon):
+            f.append((ring(i, j), ring(i + 1, j), ring(i + 1, j + 1)))
+            f.append((ring(i, j), ring(i + 1, j + 1), ring(i, j + 1)))
+    return v, np.array(f, np.int32)
+
+
+def test_mesh_signed_distance_oracle_against_analytic_shapes(oracle):
+    """oracle.mesh_signed_distance (the stand-in for kaolin's point_to_mesh_distance + check_sign, density_grid.py:62-70)
+    against shapes whose signed distance is known in closed form: a box exactly, a sphere up to its faceting."""
+    rng = np.random.RandomState(0)
+    p = (rng.rand(20000, 3) * 2 - 1).astype(np.float32)
+    v, f = _cube_mesh(0.5)
+    sd = oracle.mesh_signed_distance(p, v, f)
+    q = np.abs(p) - 0.5
+    ana = np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(1), 0)
+    assert np.abs(sd - ana).max() < 1e-6 and (np.sign(sd) == np.sign(ana)).all()
+    v, f = _uv_sphere(0.6, 48, 96, scale=(1, 1, 1), centre=(0, 0, 0))
+    sd = oracle.mesh_signed_distance(p, v, f)
+    ana = np.linalg.norm(p, axis=1) - 0.6
+    assert np.abs(sd - ana).max() < 2e-3 and ((sd < 0) == (ana < 0))[np.abs(ana) > 2e-3].all()
+    out = oracle.density_grid_smpl_init(v, f, np.zeros((16, 16, 16), np.float32), G=16)
+    assert out["density_field"].any() and np.isinf(out["density_cached"][out["density_field"]]).all()
+    assert (out["density_cached"][~out["density_field"]] == 0).all()

@@ -128,3 +128,42 @@ def test_voxelise_kernel_matches_oracle_deformer_initialize(oracle):
     assert np.abs(fd.scale_kernel.reshape(3).cpu().numpy() - init["scale_kernel"]).max() < 1e-5
     assert np.abs(model.deformer.bbox.cpu().numpy() - init["bbox"]).max() < 1e-6
     assert np.abs(model.deformer.tfs_inv_t[0].cpu().numpy() - init["tfs_inv_t"]).max() < 1e-5
+
+
+def test_smpl_init_mesh_bootstrap_matches_oracle(oracle):
+    """Raymarcher(smpl_init=True) / DensityGrid(smpl_init=True): the occupancy grid of the first 500 steps is the posed
+    body mesh (+1 cm), computed once (density_grid.py:53-75).  `ia_mesh_signed_distance` vs the oracle on closed meshes,
+    then the update() semantics: set once, untouched until step 500, the normal EMA branch afterwards."""
+    from test_cpu_oracle import _cube_mesh, _uv_sphere
+    G = 32
+    aabb = torch.tensor([[-1.25, -1.55, -1.25], [1.25, 0.95, 1.25]], device=DEV)
+    for name, (v, f) in (("cube", _cube_mesh(0.4)), ("ellipsoid", _uv_sphere())):
+        grid = DensityGrid(G, aabb=aabb, smpl_init=True).to(DEV)
+        grid.aabb = aabb
+        sd = grid.mesh_signed_distance(torch.as_tensor(v, device=DEV)[None], torch.as_tensor(f.astype(np.int64), device=DEV)).cpu().numpy()
+        ref = oracle.density_grid_smpl_init(v, f, np.zeros((G, G, G), np.float32), G=G)
+        err = np.abs(sd - ref["signed_distance"])
+        print(name, "max |sdf err| %.2e, sign flips %d, occupied %d" % (err.max(), int((np.sign(sd) != np.sign(ref["signed_distance"])).sum()), int(ref["density_field"].sum())))
+        assert err.max() < 1e-6 and (np.sign(sd) == np.sign(ref["signed_distance"])).all()
+
+        class _D:  # what DensityGrid.update reads from the deformer in this branch
+            vertices = torch.as_tensor(v, device=DEV)[None]
+            body_model = type("B", (), {"faces_tensor": torch.as_tensor(f.astype(np.int64), device=DEV)})()
+
+            def __call__(self, pts, net, eval_mode=True):
+                return torch.zeros_like(pts), torch.full((pts.shape[0],), 3.0, device=pts.device, requires_grad=True) * 1.0
+
+        density, valid = grid.update(_D(), None, step=0)
+        assert np.array_equal(grid.density_field.cpu().numpy(), ref["density_field"]) and torch.equal(valid, grid.density_field)
+        assert np.array_equal(grid.density_cached.cpu().numpy(), ref["density_cached"])
+        bits = grid.occ_bits[:G ** 3 // 32].cpu().numpy().view(np.uint32)
+        unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)[None]) & 1).astype(bool).reshape(G, G, G)
+        assert np.array_equal(unpacked, ref["density_field"])
+        field0 = grid.density_field.clone()
+        grid.update(_D(), None, step=20)                      # still < 500: nothing moves (:53-75 runs once)
+        assert torch.equal(grid.density_field, field0)
+        density, valid = grid.update(_D(), None, step=500)    # EMA branch (:76-85): inf * 0.8 stays inf inside, 3.0 elsewhere
+        assert torch.equal(valid, field0) and torch.isinf(grid.density_cached[field0]).all()
+        assert (grid.density_cached[~field0] == 3.0).all()
+    with pytest.raises(ValueError):
+        DensityGrid(G, aabb=aabb, smpl_init=True).to(DEV).mesh_signed_distance(torch.zeros((1, 4, 3), device=DEV), torch.zeros((0, 3), dtype=torch.int64))
