@@ -4,7 +4,7 @@
 f=$1; shift
 for flags in "$@"; do
   ( cd instantavatar_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -x hip -c $f -o $f.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so ia_error.cpp.o ia_snarf.hip.o ia_field.hip.o ia_render.hip.o ia_prof.hip.o ia_voxelise.hip.o ia_loss.hip.o ia_smpl_nn.hip.o )
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so *.o )
   for i in 1 2; do timeout 120 python bench.py --steps 40 --warmup 5 --cpu-frames 0 --train-steps 0 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); o=d['roofline']['other']; print('[$flags]', round(d['value'],1), 'fps', round(d['ms_per_step'],3), 'ms  k_search', round(o['k_search']['avg_launch_us'],1), 'us  k_field', round(o['k_field']['avg_launch_us'],1), 'us')"; done
 done

@@ -2,7 +2,7 @@
 # A/B helper (dev tool): rebuild ia_field.hip with extra -D flags on the GPU box, run tools/bench_field.py
 for flags in "$@"; do
   ( cd instantavatar_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -x hip -c ia_field.hip -o ia_field.hip.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so ia_error.cpp.o ia_snarf.hip.o ia_field.hip.o ia_render.hip.o ia_prof.hip.o ia_voxelise.hip.o ia_loss.hip.o ia_smpl_nn.hip.o )
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so *.o )
   echo "=== [$flags]"
   python tools/bench_field.py 2>&1 | grep -E "uniform.*(65536|262144|1048576)"
 done
