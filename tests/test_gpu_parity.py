@@ -208,12 +208,11 @@ def test_occupancy_postprocess_bit_exact(oracle, gpu_world):
     assert grid.density_field.sum().item() == 0
 
 
-def test_occupancy_components_lds_path_and_fallback(oracle, gpu_world):
-    """The occupancy post-process has two routes with identical results: one workgroup in LDS (up to 16 384
-    occupied cells -- every posed body) and the global-memory union-find (anything larger, e.g. an untrained
-    field).  Cases: two components of EQUAL size (torch.mode keeps the smaller label), diagonal-only (26-)
-    connectivity, a component touching the border (border flag), sparse noise with hundreds of components,
-    and sizes on both sides of the LDS capacity.  density_grid.py:104-125."""
+def test_occupancy_components_adversarial_cases(oracle, gpu_world):
+    """The occupancy post-process (density_grid.py:104-125) on adversarial inputs: two components of EQUAL size
+    (torch.mode keeps the smaller label), diagonal-only (26-) connectivity, a component touching the border (border
+    flag), sparse noise with hundreds of components, large blobs, an almost full grid, runs at the column ends; 64^3
+    grids take the run-based union kernels, other sizes the cell-based one."""
     model = gpu_world[0]
     G = 64
     grid = model.renderer.density_grid_test
@@ -246,14 +245,24 @@ def test_occupancy_components_lds_path_and_fallback(oracle, gpu_world):
     d = (rng.rand(G, G, G) > 0.9995).astype(np.float32) * 70                # ~130 isolated seeds -> many 27-cell components
     d[30:36, 30:36, 30:36] = 90
     check(d, "noise")
-    for side, what in ((22, "below the LDS capacity"), (24, "above the LDS capacity")):   # (side + 2)^3 cells after dilation
+    for side in (22, 24):                                                    # (side + 2)^3 cells after dilation
         d = np.zeros((G, G, G), np.float32)
         d[8:8 + side, 8:8 + side, 8:8 + side] = rng.rand(side, side, side) * 200 + 50
         d[50:53, 50:53, 50:53] = 60
-        n = check(d, what)
-        assert (n <= 16384) == (side == 22), (side, n)
+        assert check(d, "blob %d" % side) == (side + 2) ** 3
     d = rng.rand(G, G, G).astype(np.float32) * 100                          # untrained-field-like: most of the grid occupied
     check(d, "dense")
+    d = np.zeros((G, G, G), np.float32)                                      # runs that only touch diagonally across columns / at z = 0, 63
+    d[10, 10, 0:3] = 50; d[13, 13, 5:9] = 50; d[16, 15, 60:64] = 50; d[19, 17, 0:64] = 50; d[22, 20, 31:33] = 50
+    check(d, "column ends")
+    # other grid sizes take the cell-based union kernel (the run-based one needs a z-column to be exactly one wave)
+    from instantavatar_amd.models.structures.density_grid import DensityGrid
+    g32 = DensityGrid(32).to(DEV)
+    d = np.zeros((32, 32, 32), np.float32)
+    d[4:14, 6:20, 3:9] = rng.rand(10, 14, 6) * 100 + 20
+    d[24:27, 24:27, 24:27] = 70
+    g32._postprocess(torch.as_tensor(d, device=DEV))
+    assert np.array_equal(g32.density_field.cpu().numpy(), oracle.occupancy_from_density(d, 32).astype(bool))
 
 
 def test_raymarch_and_composite_kernels(oracle, gpu_world):
