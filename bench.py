@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying the captured HIP "
                     "graph (eager: ~110 launches per frame from Python, a few hundred microseconds slower and jittery)")
-    ap.add_argument("--train-steps", type=int, default=100, help="training iterations timed after the render loop (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=None,
+                    help="training iterations timed after the render loop (0 = skip).  Default: 100 on one GPU; 0 on several -- the "
+                         "frames/s line of a scaling run must not depend on a second workload (use --train-only, or pass a count)")
     return ap.parse_args()
 
 
@@ -102,8 +104,10 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             rgb, _, alpha, _ = model.render_image_fast(b, (res, res))
             targets.append((b, rgb.reshape(1, -1, 3), alpha.reshape(1, -1)))
     trainee, _, _ = build_synthetic_model(dev, resolution=128, n_levels=16)
-    trainee.net_coarse.reset_parameters()   # identical seed on every rank -> identical replicas
+    trainee.net_coarse.reset_parameters()
     trainee.train()
+    from instantavatar_amd.parallel import broadcast_module_state
+    broadcast_module_state(trainee, world_size)   # replicas identical to rank 0 (parameters and buffers), not by seed
     opt = configure_optimizer(trainee)
     loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -305,6 +309,8 @@ def _profile_json(*names):
 
 def main():
     args = parse()
+    if args.train_steps is None:
+        args.train_steps = 100 if args.gpus == 1 else 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(relaunch_distributed(args))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -560,7 +566,10 @@ def main():
         if mj is not None:
             result["mfma"] = dict(mj, source=msrc)
     if args.train_steps > 0:
-        result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res)
+        try:
+            result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res)
+        except Exception as e:  # the headline line must survive a failure of the secondary workload
+            result["train"] = {"error": repr(e)[:300]}
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:
         result["cpu_baseline"] = cpu_baseline(body, fp, model, poses, tr, res, args.cpu_frames)
     if rank == 0:

@@ -151,6 +151,18 @@ def test_train_driver_checkpoint_feeds_animate_driver(tmp_path):
     missing, unexpected = ck.load_checkpoint(model, ckpt, map_location=DEV)
     assert not unexpected and model.global_step == 60
     assert not torch.equal(before, model.net_coarse.encoder.params)
+    # --resume continues the interrupted run: Adam moments, step counters and the LR-scheduler epoch come from the checkpoint
+    # (a resumed run used to restart Adam from zero moments)
+    st = sd["optimizer_states"][0]["state"]
+    assert all(float(v["step"]) == 60 for v in st.values()) and "lr_schedulers" in sd
+    m0 = {k: v["exp_avg"].clone() for k, v in st.items()}
+    assert train.main(["--synthetic", "--steps", "8", "--res", "128", "--ckpt", ckpt, "--resume", "--steps-per-epoch", "4"]) == 0
+    sd2 = torch.load(ckpt, weights_only=False)
+    assert sd2["global_step"] == 68
+    st2 = sd2["optimizer_states"][0]["state"]
+    assert all(float(v["step"]) == 68 for v in st2.values())       # 60 + 8: counters continued, not restarted at 8
+    assert all(not torch.equal(m0[k].to(st2[k]["exp_avg"].device), st2[k]["exp_avg"]) for k in st2)
+    assert sd2["lr_schedulers"][0]["last_epoch"] == sd["lr_schedulers"][0]["last_epoch"] + 2
     out = str(tmp_path / "anim")
     assert animate.main(["--synthetic", "--ckpt", ckpt, "--max-frames", "2", "--downscale", "8", "--out", out, "--no-gif"]) == 0
     im = np.asarray(Image.open(os.path.join(out, "0.png")))
