@@ -395,7 +395,7 @@ def main():
                 pb["global_orient"], pb["body_pose"], pb["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
                 pb["near"], pb["far"] = torch.full_like(batches[0]["near"], d - 1), torch.full_like(batches[0]["far"], d + 1)
                 probes.append(pb)
-            graphed = GraphedRenderer(model, batches[0], (res, res), margin=2, probe_batches=probes)
+            graphed = GraphedRenderer(model, batches[0], (res, res), margin=1, probe_batches=probes)
 
             def frame(i):  # noqa: F811  (same work, replayed from the captured HIP graph)
                 f = my[i % n_total] % len(poses)

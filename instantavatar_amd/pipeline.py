@@ -60,7 +60,7 @@ class GraphedRenderer:
     def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False, probe_batches=()):
         """probe_batches: further batches (other poses of the sequence) rendered once eagerly to measure
         how many wave-front iterations the sequence needs; with a representative sample a small
-        `margin` is enough (every idle iteration costs six empty launches per frame)."""
+        `margin` is enough (every idle iteration costs five empty launches per frame)."""
         self.model, self.img_size, self.sync_check = model, img_size, sync_check
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         r = model.renderer
@@ -71,7 +71,7 @@ class GraphedRenderer:
         for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration count
             model.render_image_fast(self.static, img_size)
             need = max(need, r.iters_executed())
-        r._iters_hint = need + margin + ((need + margin) & 1)
+        r._iters_hint = need + margin   # (no parity constraint: the alive lists ping-pong on the absolute iteration index)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         r._graph_capture = True

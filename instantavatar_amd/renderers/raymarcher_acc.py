@@ -111,7 +111,7 @@ class Raymarcher(torch.nn.Module):
         self.idx = 0
         self._fused = None
         self._ws = None
-        self._iters_hint = 8     # loop iterations enqueued per call (even); adapted per frame
+        self._iters_hint = 8     # loop iterations enqueued per call; adapted per frame
         self._n_alive_host = None
         self.last_iters = 0
 
