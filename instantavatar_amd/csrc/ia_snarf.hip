@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
     // precompute.cu:51-59: J[c] accumulates over j in joint order
     // (requesting all 24 planes before the first use was measured: 193 VGPRs, 98 -> 115 us; one voxel per thread with
     // all 24 four-byte loads in flight and LDS-transposed, fully coalesced stores: 180 us -- 4-byte-per-lane plane
-    // loads stream at half the rate of 16-byte ones)
+    // loads stream at half the rate of 16-byte ones; groups of 4 / 6 / 8 / 12 planes explicitly in flight (the
+    // compiler otherwise waits after every load): 122 / 115 / 119 / 112 us against 93 us -- more requests in flight
+    // make it slower; channel-LAST weights (96 contiguous bytes per voxel, six 16-byte loads per lane): 170 us, the
+    // strided lanes are served one at a time; padding the 2 MiB plane stride: no effect.  Counters: TCP pending-stall
+    // 88 % of the launch, 2.1 M L2 requests of which 1.3 M are the 16-byte pieces of the channel-last stores.)
 #ifndef IA_PRE_UNROLL
 #define IA_PRE_UNROLL 4  // joint planes in flight per thread: 2 / 4 / 6 / 8 measured 98.7 / 92.8 / 96.6 / 105.1 us
 #endif
