@@ -108,7 +108,8 @@ def test_state_dict_surface_matches_reference_keys(gw):
     """Checkpoint keys on the path: names and shapes of the reference's tcnn modules."""
     model = gw[0]
     sd = model.state_dict()
-    assert sd["net_coarse.encoder.params"].shape == (3072 + 13026992,)
+    grid_params = 13026992 if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "54" else 13044816   # tcnn level-3 resolution 54 / 55
+    assert sd["net_coarse.encoder.params"].shape == (3072 + grid_params,)
     assert sd["net_coarse.color_net.params"].shape == (6144,)
     for k in ("net_coarse.center", "net_coarse.scale", "renderer.density_grid_test.density_cached",
               "renderer.density_grid_test.density_field"):
