@@ -109,14 +109,12 @@ class _FieldFn(torch.autograd.Function):
         if last and dx is None:
             # level groups, finest first; each finished slice of the table gradient goes to RCCL while the next
             # group is scattered.  The MLP weight gradients travel with the last (small, dense-level) bucket.
-            off = [int(o) for o in net.hash_desc.offset[:net.n_levels + 1]]
             red.reduce_async(g_col)
-            for l0, l1 in _level_groups(net.n_levels):
+            for (l0, l1), (lo, hi) in gradient_buckets(net):
                 _lib.check(L.ia_hashgrid_bwd_levels(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
                                                     _lib.ptr(dfeat), dtable.data_ptr(), l0, l1, _lib.stream()),
                            "ia_hashgrid_bwd_levels")
-                lo = w_end + 2 * off[l0] if l0 > 0 else 0   # the bucket of the coarsest group starts at the MLP weights
-                red.reduce_async(g_enc[lo:w_end + 2 * off[l1]])
+                red.reduce_async(g_enc[lo:hi])
         else:
             _lib.check(L.ia_hashgrid_bwd(_lib.ptr(xc), V, _lib.ptr(ctx.n_dev), C.byref(net.field_desc()),
                                          _lib.ptr(dfeat), dtable.data_ptr(), _lib.ptr(dx), _lib.stream()),
@@ -129,6 +127,20 @@ def _grad_buffer(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
+
+
+def gradient_buckets(net, n_groups=4):
+    """[((l0, l1), (lo, hi))]: level groups in scatter order (finest first) with the slice [lo, hi) of `encoder.params.grad`
+    that is complete once levels [l0, l1) have been scattered.  encoder.params = [W1 | W2 | level 0 | ... | level L-1]; the
+    slice of the coarsest group starts at 0, so the MLP weight gradients travel with the last (smallest) bucket.  The slices
+    are disjoint and cover the whole vector."""
+    off = [int(o) for o in net.hash_desc.offset[:net.n_levels + 1]]
+    w_end = net.sig_w1_size + 1024
+    out = []
+    for l0, l1 in _level_groups(net.n_levels, n_groups):
+        lo = w_end + 2 * off[l0] if l0 > 0 else 0
+        out.append(((l0, l1), (lo, w_end + 2 * off[l1])))
+    return out
 
 
 def _level_groups(n_levels, n_groups=4):

@@ -255,3 +255,24 @@ def test_gloo_world2_real_training_step_plumbing():
         assert skipped and same_after_skip, "a non-finite gradient must skip the optimiser step on every rank"
         assert gstep == 23 and updates == 24   # 23 steps + the start-up broadcast
     assert res[0][5] == res[1][5], "start-up broadcast did not equalise the replicas"
+
+
+def test_gradient_buckets_tile_the_encoder_gradient():
+    """The slices of `encoder.params.grad` handed to the all-reduce from inside the hash-grid backward (one per level
+    group, finest first) must be disjoint and cover the vector exactly, for both grid depths and both tcnn layouts."""
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    from instantavatar_amd.training import gradient_buckets
+    for n_levels in (16, 8):
+        for r3 in (54, 55):
+            net = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), n_levels=n_levels, level3_res=r3)
+            b = gradient_buckets(net)
+            levels = [lv for lv, _ in b]
+            assert levels == sorted(levels, reverse=True) and levels[-1][0] == 0 and levels[0][1] == n_levels
+            assert all(levels[i][0] == levels[i + 1][1] for i in range(len(levels) - 1))          # contiguous level ranges
+            spans = sorted(s for _, s in b)
+            assert spans[0][0] == 0 and spans[-1][1] == net.encoder.params.numel()
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))             # disjoint, no gap
+            w_end = net.sig_w1_size + 1024
+            off = [int(o) for o in net.hash_desc.offset[:n_levels + 1]]
+            for (l0, l1), (lo, hi) in b:                                                            # a slice holds exactly its levels (+ the MLP weights)
+                assert hi == w_end + 2 * off[l1] and lo == (0 if l0 == 0 else w_end + 2 * off[l0])
