@@ -232,8 +232,8 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
   const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
 #ifndef IA_FETCH_GROUP
-#define IA_FETCH_GROUP 4  // corners whose loads are in flight together (two round trips, 48 data VGPRs)
-#endif
+#define IA_FETCH_GROUP 2  // corners whose loads are in flight together (four round trips, 24 data VGPRs): with 32 points per
+#endif                    // workgroup this buys a fifth wave per SIMD (r02: 376 -> 391 frames/s; group 4 with 32 points: 325)
   // accumulators as float2 pairs: the 12 FMAs of a corner become 6 v_pk_fma_f32 (IEEE fma per half)
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 acc[6];
@@ -303,11 +303,14 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 // Afterwards the workgroup runs the duplicate filter and either writes the dense
 // reference layout (MODE 0) or compacts the surviving roots (MODE 1).
 // ---------------------------------------------------------------------------
-// Measured on MI355X (512^2 frame, graph mode): 256 threads x 128 points 3.86 ms, 128 x 64 3.70 ms,
-// 64 x 32 3.79 ms, 64 x 64 4.07 ms, 128 x 128 4.19 ms -- two lanes per point keep enough waves in
-// flight, the smaller workgroup shortens the wait at the barrier before the filter.
+// Measured on MI355X (512^2 frame, graph mode), round 1 with 4 corners in flight (116 VGPRs, 4 waves per SIMD):
+// 256 threads x 128 points 3.86 ms, 128 x 64 3.70 ms, 64 x 32 3.79 ms, 64 x 64 4.07 ms, 128 x 128 4.19 ms.
+// Round 2: occupancy was bound twice at 16 waves per CU (registers AND 18 KB of LDS per workgroup); 2 corners in flight
+// (91 VGPRs -> 5 waves per SIMD) together with 32 points per workgroup (9.5 KB -> the LDS allows them): 128 x 32 with
+// group 2 = 2.55 ms against 2.66 ms; group 2 alone 2.71, 32 points alone (group 4) 3.08, group 1 (82 VGPRs, still 5
+// waves) 2.67, forcing 6 waves per SIMD (spills) 2.86, 64 x 32 2.67, 64 x 16 2.58, 256 x 32 2.68, 256 x 64 2.62.
 #ifndef IA_SEARCH_NP
-#define IA_SEARCH_NP 64        // points per workgroup (power of two, <= 128)
+#define IA_SEARCH_NP 32        // points per workgroup (power of two, <= 128): 9.6 KB of LDS, 16 workgroups per CU
 #endif
 #ifndef IA_SEARCH_THREADS
 #define IA_SEARCH_THREADS 128  // multiple of IA_SEARCH_NP
