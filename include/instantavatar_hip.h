@@ -441,6 +441,9 @@ int ia_make_rays(const double *K_inv, const double *c2w_R, const double *c2w_t, 
 size_t ia_mask_edge_workspace_bytes(int H, int W);
 int ia_mask_edge(const float *mask, int H, int W, int kernel_size, float *edge, void *ws,
                  size_t ws_bytes, void *stream);
+/* cv2.dilate(mask, ones(k,k)) alone: PatchSampler(dilate=k) (sampler.py:62-65).  Same workspace as ia_mask_edge. */
+int ia_mask_dilate(const float *mask, int H, int W, int kernel_size, float *dilated, void *ws,
+                   size_t ws_bytes, void *stream);
 /* np.where(mask[y0:y1, x0:x1])[rank] for n ranks derived from uniform draws u [n] in [0,1) on the device:
  * with replacement rank = floor(u * count) (np.random.randint, sampler.py:33-35); without replacement the
  * floor(u_i * (count - i))-th element not chosen before (np.random.choice(replace=False), sampler.py:69).

@@ -64,6 +64,7 @@ _SIGS = {
     "ia_make_rays": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, _VP, _VP, _VP]),
     "ia_mask_edge_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_mask_edge": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
+    "ia_mask_dilate": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
     "ia_nonzero_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_nonzero_select": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, _VP,
                                     _VP, C.c_size_t, _VP]),

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_minmax_rows(const float *__restrict__ m
 }
 
 __global__ __launch_bounds__(256) void k_minmax_cols(const float *__restrict__ mn, const float *__restrict__ mx, int H, int W,
-                                                     int k, float *__restrict__ edge) {
+                                                     int k, float *__restrict__ edge, float *__restrict__ dilated) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= H * W) return;
   const int y = i / W, x = i - y * W, a = k / 2;
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_minmax_cols(const float *__restrict__ m
     if (yy < 0 || yy >= H) continue;
     lo = fminf(lo, mn[yy * W + x]); hi = fmaxf(hi, mx[yy * W + x]);
   }
-  edge[i] = hi - lo;  // mask_o - mask_i
+  if (edge) edge[i] = hi - lo;  // mask_o - mask_i
+  if (dilated) dilated[i] = hi;
 }
 
 extern "C" size_t ia_mask_edge_workspace_bytes(int H, int W) { return 2 * ia_align((size_t)H * W * 4) + 256; }
@@ -90,8 +91,22 @@ extern "C" int ia_mask_edge(const float *mask, int H, int W, int kernel_size, fl
   float *mn = w.take<float>((size_t)H * W), *mx = w.take<float>((size_t)H * W);
   const dim3 g(ia_div_up((long)H * W, 256)), b(256);
   hipLaunchKernelGGL(k_minmax_rows, g, b, 0, (hipStream_t)stream, mask, H, W, kernel_size, mn, mx);
-  hipLaunchKernelGGL(k_minmax_cols, g, b, 0, (hipStream_t)stream, mn, mx, H, W, kernel_size, edge);
+  hipLaunchKernelGGL(k_minmax_cols, g, b, 0, (hipStream_t)stream, mn, mx, H, W, kernel_size, edge, (float *)nullptr);
   IA_LAUNCH_CHECK("ia_mask_edge");
+  return IA_OK;
+}
+
+// cv2.dilate(mask, ones(k, k)) alone (PatchSampler(dilate = k), sampler.py:62-65; `sampler.dilate=8` in bash/run-neuman-demo.sh)
+extern "C" int ia_mask_dilate(const float *mask, int H, int W, int kernel_size, float *dilated, void *ws, size_t ws_bytes,
+                              void *stream) {
+  IA_CHECK_ARG(mask && dilated && ws && H > 0 && W > 0 && kernel_size > 0, "ia_mask_dilate: bad arguments");
+  if (ws_bytes < ia_mask_edge_workspace_bytes(H, W)) return ia_set_error(IA_ERR_WORKSPACE, "ia_mask_dilate: workspace too small");
+  WsCarver w(ws, ws_bytes);
+  float *mn = w.take<float>((size_t)H * W), *mx = w.take<float>((size_t)H * W);
+  const dim3 g(ia_div_up((long)H * W, 256)), b(256);
+  hipLaunchKernelGGL(k_minmax_rows, g, b, 0, (hipStream_t)stream, mask, H, W, kernel_size, mn, mx);
+  hipLaunchKernelGGL(k_minmax_cols, g, b, 0, (hipStream_t)stream, mn, mx, H, W, kernel_size, (float *)nullptr, dilated);
+  IA_LAUNCH_CHECK("ia_mask_dilate");
   return IA_OK;
 }
 

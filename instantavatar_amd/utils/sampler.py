@@ -94,8 +94,19 @@ class PatchSampler:
         self.p = ratio_mask
         self.dilate = dilate
         assert self.patch_size % 2 == 0, "patch size has to be even"
-        if dilate > 0:
-            raise NotImplementedError("PatchSampler(dilate > 0) is not used by any shipped configuration (confs/sampler/patch.yaml: 0)")
+
+    def _candidates(self, mask2d):
+        """the mask the anchors are drawn from: cv2.dilate(mask, ones(dilate, dilate)) > 0 when dilate > 0 (:62-65)"""
+        if self.dilate <= 0:
+            return mask2d
+        _lib.require_cuda(mask2d)
+        H, W = mask2d.shape
+        L = _lib.lib()
+        m = mask2d.float().contiguous()
+        out = torch.empty_like(m)
+        ws = _ws(L.ia_mask_edge_workspace_bytes(H, W), m.device)
+        _lib.check(L.ia_mask_dilate(_lib.ptr(m), H, W, int(self.dilate), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_mask_dilate")
+        return (out > 0).float()
 
     def sample_corners(self, mask2d, draws=None, generator=None):
         """(row, col) int32 [num_patch] of the patches' top-left corners.  draws: [1 + 2 * num_patch] uniform numbers --
@@ -108,7 +119,7 @@ class PatchSampler:
         coin, rest = draws[0], draws[1:]
         o = P // 2
         # both branches are evaluated on the device and blended by the coin: no host read of a random number
-        r_m, c_m, count = nonzero_select(mask2d, (o, H - o, o, W - o), rest[:self.n], without_replacement=True)
+        r_m, c_m, count = nonzero_select(self._candidates(mask2d), (o, H - o, o, W - o), rest[:self.n], without_replacement=True)
         r_u = torch.clamp((rest[:self.n].float() * float(H - P)).floor(), max=H - P - 1).to(torch.int32)   # np.random.randint(0, H - P)
         c_u = torch.clamp((rest[self.n:2 * self.n].float() * float(W - P)).floor(), max=W - P - 1).to(torch.int32)
         use_mask = coin < self.p

@@ -65,7 +65,7 @@ def edge_sampler_sample(mask2d, args, draws, **kw):
     return [mask[idx]] + [np.asarray(d).reshape(len(mask), -1)[idx] for d in args]
 
 
-def patch_sampler_corners(mask2d, draws, num_patch=4, patch_size=20, ratio_mask=0.9):
+def patch_sampler_corners(mask2d, draws, num_patch=4, patch_size=20, ratio_mask=0.9, dilate_k=0):
     """PatchSampler.sample's anchors (sampler.py:56-73).  draws [1 + 2*num_patch]: the coin of :60, then the anchor draws
     (mask branch: np.random.choice(replace=False) as sequential draws from the remaining candidates)."""
     u = np.asarray(draws, np.float32)
@@ -73,7 +73,8 @@ def patch_sampler_corners(mask2d, draws, num_patch=4, patch_size=20, ratio_mask=
     P = patch_size
     if u[0] < np.float32(ratio_mask):
         o = P // 2
-        xs, ys = np.where(np.asarray(mask2d)[o:-o, o:-o] > 0)
+        m = dilate(mask2d, dilate_k) > 0 if dilate_k > 0 else np.asarray(mask2d)   # sampler.py:62-65
+        xs, ys = np.where(m[o:-o, o:-o] > 0)
         remaining = list(range(len(xs)))
         pick = []
         for i in range(num_patch):

@@ -100,6 +100,13 @@ def test_patch_sampler_matches_oracle_both_branches():
         ref = do.patch_sampler_sample(masks[0], [img], draws, 4, 32, ratio)
         assert out[0].shape == (4, 32, 32) and out[1].shape == (4, 32, 32, 3)
         assert np.array_equal(out[0].cpu().numpy(), ref[0]) and np.array_equal(out[1].cpu().numpy(), ref[1])
+    # PatchSampler(dilate=8): anchors from the dilated mask (bash/run-neuman-demo.sh: sampler.dilate=8)
+    s = PatchSampler(num_patch=4, patch_size=32, ratio_mask=1, dilate=8)
+    draws = np.r_[0.0, rng.rand(8)].astype(np.float32)
+    rows, cols = s.sample_corners(m, draws=torch.as_tensor(draws, device=DEV))
+    x, y = do.patch_sampler_corners(masks[0], draws, 4, 32, 1, dilate_k=8)
+    assert np.array_equal(rows.cpu().numpy(), x) and np.array_equal(cols.cpu().numpy(), y)
+    assert np.array_equal(s._candidates(m).cpu().numpy() > 0, do.dilate(masks[0], 8) > 0)
 
 
 @pytest.mark.parametrize("kind", ["edge", "patch"])
