@@ -534,7 +534,7 @@ def main():
             keep = ("l1_hit_rate", "l2_hit_rate", "tcp_accesses_per_clk_per_cu_at_2.4GHz", "wave_cycle_split", "avg_launch_us_in_pass", "launches")
             roof["counters"] = {v: {k: cj[v][k] for k in keep if k in cj[v]} for v in ("k_search/probe", "k_search/render") if v in cj}
             roof["counters"]["source"] = csrc
-            roof["counters"]["vgprs"], roof["counters"]["waves_per_simd"] = 116, 4
+            roof["counters"]["vgprs"], roof["counters"]["waves_per_simd"] = 91, 5
 
     frames = args.steps * world_size
     fps = frames / dt

@@ -109,7 +109,7 @@ def main(root, out_dir):
             acc_, l2req = g(k, "TCP_TOTAL_CACHE_ACCESSES_sum"), g(k, "TCP_TCC_READ_REQ_sum")
             h, m = g(k, "TCC_HIT_sum"), g(k, "TCC_MISS_sum")
             search[k] = {"l1_hit_rate": (1.0 - l2req / acc_) if acc_ else None, "l2_hit_rate": (h / (h + m)) if h is not None and m is not None and h + m > 0 else None}
-    search["_note"] = ("registers / occupancy of k_search<1>: 116 VGPRs, 18.2 KB LDS per 128-thread workgroup -> 4 waves per SIMD "
+    search["_note"] = ("registers / occupancy of k_search<1>: 91 VGPRs, 9.5 KB LDS per 128-thread workgroup -> 5 waves per SIMD "
                        "(hipcc -Rpass-analysis=kernel-resource-usage); counters are sums over the chip per launch, averaged over the launches")
     # ---- MFMA
     mfma = {}
