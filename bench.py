@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--spinup-max-ms", type=float, default=4000.0,
                     help="upper bound of the adaptive, untimed and REPORTED spin-up: 10-frame windows are run until three "
                          "consecutive windows agree within 3 %% (reported as spinup_ms / value_first_window / value_steady)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent frames in flight per GPU (one captured graph and one HIP stream each; 1 = strictly one frame "
+                         "after the other).  The frames of a sequence are independent units (animate.py)")
     ap.add_argument("--train-only", action="store_true", help="headline = training throughput (rays/s over all ranks)")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises launch, frame sharding and the "
                     "collectives on the gloo backend (CPU test of the N > 1 plumbing)")
@@ -370,14 +373,27 @@ def main():
     pose_t = torch.as_tensor(poses, device=dev)
     tr_t = torch.as_tensor(tr, device=dev)
 
-    def frame(i):
+    # near / far per frame: constant tensors per distinct camera distance, made once (no fill kernels in the frame loop)
+    _nf = {}
+
+    def near_far(d):
+        key = round(d, 6)
+        if key not in _nf:
+            _nf[key] = (torch.full_like(batches[0]["near"], d - 1), torch.full_like(batches[0]["far"], d + 1))
+        return _nf[key]
+
+    frame_inputs = [dict(batches[0]) for _ in range(max(args.in_flight, 1))]  # one input dict per frame in flight
+
+    def frame(i, consume=None):
         f = my[i % n_total] % len(poses)
         b = batches[i % len(batches)]
         b["global_orient"], b["body_pose"], b["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
         d = float(np.sqrt((tr[f] ** 2).sum()))
-        b["near"].fill_(d - 1)
-        b["far"].fill_(d + 1)
-        return model.render_image_fast(b, (res, res))
+        b["near"], b["far"] = near_far(d)
+        out = model.render_image_fast(b, (res, res))
+        if consume is not None:
+            consume(out, 0)
+        return out, 0
 
     L = _lib.lib()
     eager_frame = frame
@@ -395,31 +411,43 @@ def main():
                 pb["global_orient"], pb["body_pose"], pb["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
                 pb["near"], pb["far"] = torch.full_like(batches[0]["near"], d - 1), torch.full_like(batches[0]["far"], d + 1)
                 probes.append(pb)
-            graphed = GraphedRenderer(model, batches[0], (res, res), margin=1, probe_batches=probes)
+            if args.in_flight > 1:
+                from instantavatar_amd.pipeline import PipelinedRenderer
+                graphed = PipelinedRenderer(model, batches[0], (res, res), n_in_flight=args.in_flight, margin=1, probe_batches=probes)
+            else:
+                graphed = GraphedRenderer(model, batches[0], (res, res), margin=1, probe_batches=probes)
 
-            def frame(i):  # noqa: F811  (same work, replayed from the captured HIP graph)
+            def frame(i, consume=None):  # noqa: F811  (same work, replayed from the captured HIP graph(s))
                 f = my[i % n_total] % len(poses)
                 d = float(np.sqrt((tr[f] ** 2).sum()))
-                b = batches[0]
+                b = frame_inputs[i % len(frame_inputs)]
                 b["global_orient"], b["body_pose"], b["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
-                b["near"].fill_(d - 1)
-                b["far"].fill_(d + 1)
-                return graphed(b)
-            mode = "hip_graph"
+                b["near"], b["far"] = near_far(d)
+                if args.in_flight > 1:
+                    return graphed(b, consume)
+                out = graphed(b)
+                if consume is not None:
+                    consume(out, 0)
+                return out, 0
+            mode = "hip_graph" if args.in_flight == 1 else "hip_graph x%d in flight" % args.in_flight
         except Exception as e:  # capture not possible on this stack: stay eager (still the HIP path)
             print("graph capture failed, running eagerly:", repr(e)[:200], file=sys.stderr)
             frame = eager_frame
 
-    cnt_sum = torch.zeros((), device=dev)
-    cov_sum = torch.zeros((), device=dev)
+    n_acc = max(args.in_flight, 1)
+    cnt_sum = torch.zeros(n_acc, device=dev)   # one accumulator per replica / stream: no cross-stream read-modify-write
+    cov_sum = torch.zeros(n_acc, device=dev)
+
+    def stats(out, k):
+        rgb, depth, alpha, counter = out
+        cnt_sum[k:k + 1].add_(counter.mean())
+        cov_sum[k:k + 1].add_((alpha > 0.5).float().mean())
 
     def run_frames(i0, n):
-        """the loop body of the timed region (frame + the two statistics reductions), used unchanged by the
-        spin-up windows and the warm-up, so that nothing is executed for the first time inside the timed region"""
+        """the loop body of the timed region (frame + the two statistics reductions, executed on the frame's stream), used
+        unchanged by the spin-up windows and the warm-up, so that nothing is executed for the first time inside the timed region"""
         for i in range(i0, i0 + n):
-            rgb, depth, alpha, counter = frame(i)
-            cnt_sum.add_(counter.mean())
-            cov_sum.add_((alpha > 0.5).float().mean())
+            frame(i, stats)
 
     # Adaptive spin-up, untimed but REPORTED.  A GPU that idled through model construction, the first
     # replays of a freshly instantiated graph and the first launches of the statistics kernels are all
@@ -464,6 +492,21 @@ def main():
             eager_frame(args.warmup)
         torch.cuda.synchronize()
         dt += time.perf_counter() - t_re
+    # with several frames in flight the per-frame LATENCY is not ms_per_step: replay ONE replica's graph back to back
+    one_fps = None
+    if graphed is not None and args.in_flight > 1:
+        g0 = graphed.graphs[0]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            f = my[i % n_total] % len(poses)
+            b = frame_inputs[0]
+            b["global_orient"], b["body_pose"], b["transl"] = pose_t[f:f + 1, :3], pose_t[f:f + 1, 3:], tr_t[f:f + 1]
+            b["near"], b["far"] = near_far(float(np.sqrt((tr[f] ** 2).sum())))
+            g0(b)
+        torch.cuda.synchronize()
+        one_fps = args.steps / (time.perf_counter() - t1)
+        g0.finish()
     # per-kernel timing for the roofline block: HIP events around every launch of the two dominant
     # stages on the stream they run on.  Recording ~50 events per frame costs ~10 % of the frame,
     # so `value` comes from the un-instrumented pass above and the SAME K frames are then launched
@@ -550,8 +593,10 @@ def main():
                    "frames_sharded_over": world_size},
         "rays_per_sec": fps * res * res,
         "frames_per_rank": frames_per_rank,
-        "samples_per_ray": float(cnt_sum.item()) / args.steps,
-        "alpha_coverage": float(cov_sum.item()) / args.steps,
+        "samples_per_ray": float(cnt_sum.sum().item()) / args.steps,
+        "alpha_coverage": float(cov_sum.sum().item()) / args.steps,
+        "frames_in_flight": (args.in_flight if graphed is not None else 1),
+        "one_frame_in_flight": ({"frames_per_s": one_fps * world_size, "frame_latency_ms": 1e3 / one_fps} if one_fps else None),
         "render_loop_iters": model.renderer.last_iters, "launch_mode": mode,
         "spinup_ms": spinup_ms, "spinup_windows": len(windows),
         "value_first_window": windows[0] * world_size, "value_steady": float(np.mean(windows[-3:])) * world_size,

@@ -37,6 +37,16 @@ class ForwardDeformer(torch.nn.Module):
         self._grid_c = None
         self._frame = None
 
+    def clone_shared(self):
+        """A second deformer on the SAME skinning-weight volume (buffers shared by reference) with its own per-frame
+        outputs (voxel_J / voxel_d / bbox): see pipeline.PipelinedRenderer."""
+        other = ForwardDeformer(self.opt)
+        other.device = self.device
+        for name in ("scale", "offset", "offset_kernel", "scale_kernel", "lbs_voxel_final", "grid_denorm"):
+            other.register_buffer(name, getattr(self, name))
+        other.resolution, other.ratio, other.bbox = self.resolution, self.ratio, self.bbox
+        return other
+
     # -- one-time voxelisation of the skinning weights (deformer_torch.py:130-186)
     def switch_to_explicit(self, resolution=32, smpl_verts=None, smpl_weights=None, use_smpl=False):
         if not use_smpl:

@@ -96,6 +96,21 @@ class SNARFDeformer():
         self.dtype = torch.float32
         self._ws = None
 
+    def clone_shared(self):
+        """A second deformer for the same subject: body model, weight voxels and rest-pose constants shared by reference,
+        per-frame state (tfs, w2s, voxel transforms) its own.  Requires an initialised deformer."""
+        assert self.initialized, "clone_shared: initialise the deformer first"
+        other = SNARFDeformer.__new__(SNARFDeformer)
+        other.body_model, other.opt, other.dtype, other._ws = self.body_model, self.opt, self.dtype, None
+        other.deformer = self.deformer.clone_shared()
+        other.initialized = True
+        for k in ("tfs_inv_t", "vs_template", "bbox", "_joints_rest", "_parents32"):
+            setattr(other, k, getattr(self, k))
+        dev = self.tfs_inv_t.device
+        other._frame_out = dict(tfs=torch.empty((1, 24, 4, 4), device=dev), w2s=torch.empty((1, 4, 4), device=dev),
+                                A=torch.empty((1, 24, 4, 4), device=dev))
+        return other
+
     # ------------------------------------------------------------------ init
     def initialize(self, betas, device):
         cano = _opt.get(self.opt, "cano_pose", "A_pose")

@@ -57,6 +57,23 @@ class NeRFNGPNet(nn.Module):
         self._desc = None
         self.reset_parameters()
 
+    def clone_shared(self):
+        """A second handle on the SAME weights (the two `_TcnnParams` modules and the centre / scale buffers are shared by
+        reference) with its own kernel-side scratch: fp16 shadow cache, MFMA fragment image, sharded-encoding planes and
+        C descriptor.  Lets two frames be in flight on two streams (pipeline.PipelinedRenderer) without sharing scratch."""
+        other = NeRFNGPNet.__new__(NeRFNGPNet)
+        nn.Module.__init__(other)
+        other.n_levels, other.log2_T, other.hash_desc = self.n_levels, self.log2_T, self.hash_desc
+        other.n_entries, other.sig_w1_size = self.n_entries, self.sig_w1_size
+        other.encoder, other.color_net = self.encoder, self.color_net
+        other.register_buffer("center", self.center)
+        other.register_buffer("scale", self.scale)
+        other.opt = self.opt
+        other._half = other._half_key = other._desc = None
+        if hasattr(self, "bbox"):
+            other.bbox = self.bbox
+        return other
+
     def reset_parameters(self, seed=1337):
         """tcnn defaults: hash table U(-1e-4, 1e-4), MLP weights Xavier-uniform."""
         g = torch.Generator().manual_seed(seed)
@@ -129,19 +146,34 @@ class NeRFNGPNet(nn.Module):
 
     # -- fp16 shadow + C descriptor ------------------------------------------
     def mark_updated(self):
-        """Invalidate the fp16 shadow.  Call after an optimizer step: fused / foreach
+        """Mark the fp16 shadow stale.  Call after an optimizer step: fused / foreach
         optimizers update parameters without bumping Tensor._version."""
-        self._half = None
-        self._desc = None
+        self._dirty = True
 
     def _half_params(self):
+        """fp16 shadow of the two parameter vectors.  It is refreshed IN PLACE (same device pointers) whenever the master
+        weights changed, and so is the MFMA fragment image: a captured HIP graph (pipeline.GraphedRenderer) has these
+        pointers baked in and sees new weights after the next eager `field_desc()` / `refresh()` call."""
         key = (self.encoder.params._version, self.color_net.params._version, self.encoder.params.data_ptr())
-        if self._half is None or self._half_key != key:
+        stale = getattr(self, "_dirty", False) or self._half_key != key
+        if self._half is None or self._half[0].device != self.encoder.params.device:
             self._half = (self.encoder.params.detach().to(torch.float16).contiguous(),
                           self.color_net.params.detach().to(torch.float16).contiguous())
-            self._half_key = key
             self._desc = None
+        elif stale:
+            with torch.no_grad():
+                self._half[0].copy_(self.encoder.params.detach())
+                self._half[1].copy_(self.color_net.params.detach())
+            if self._desc is not None and getattr(self, "_frags", None) is not None:
+                _lib.check(_lib.lib().ia_field_prepare(C.byref(self._desc), _lib.ptr(self._frags), _lib.stream()), "ia_field_prepare")
+        self._half_key = key
+        self._dirty = False
         return self._half
+
+    def refresh(self):
+        """bring the kernel-side copies (fp16 shadow, MFMA fragments) up to date now, on the current stream"""
+        self.mark_updated()
+        return self.field_desc()
 
     #: upper bound of the XCD-sharded encoding scratch (64 B per sample); larger calls use the
     #: single fused kernel.  0 disables the sharded path.

@@ -124,6 +124,77 @@ class GraphedRenderer:
         return self.incomplete
 
 
+def clone_for_stream(model):
+    """A second AvatarModel for the same avatar: network weights, body model and skinning-weight voxels are SHARED by
+    reference, everything a frame writes (per-frame deformer state, occupancy grid, render workspaces, encoder scratch) is
+    its own -- so that two frames can be in flight on two streams."""
+    renderer = Raymarcher(model.renderer.MAX_SAMPLES, model.renderer.MAX_BATCH_SIZE, smpl_init=model.renderer.smpl_init)
+    renderer = renderer.to(model.renderer.aabb.device)
+    renderer.initialize(1)
+    return AvatarModel(model.deformer.clone_shared(), model.net_coarse.clone_shared(), renderer)
+
+
+class PipelinedRenderer:
+    """`n_in_flight` frames in flight: one captured HIP graph per replica (GraphedRenderer), replayed round-robin on its own
+    stream.  A frame is a chain of ~60 dependent launches of which only the Broyden search and the encoder fill the chip;
+    the marcher, the compositor, the occupancy post-process and the small first / last wave-front iterations are latency
+    bound and leave most CUs idle -- a second, independent frame (animate.py renders independent frames: BASELINE config 3)
+    runs in those gaps.  Measured on MI355X: 395 -> 483 frames/s with two frames in flight; per-frame latency rises from
+    2.5 to ~4.1 ms.  Outputs of call i stay valid until call i + n_in_flight (same replica, same stream: no extra ordering needed)."""
+
+    def __init__(self, model, batch, img_size, n_in_flight=2, margin=1, probe_batches=()):
+        self.replicas = [model] + [clone_for_stream(model) for _ in range(n_in_flight - 1)]
+        self.streams = [torch.cuda.Stream(device=batch["rays_o"].device) for _ in self.replicas]
+        self.graphs = []
+        for m, s in zip(self.replicas, self.streams):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.graphs.append(GraphedRenderer(m, batch, img_size, margin=margin, probe_batches=probe_batches))
+            torch.cuda.current_stream().wait_stream(s)
+        self.events = [torch.cuda.Event() for _ in self.replicas]
+        self.calls = 0
+
+    def __call__(self, batch, consume=None):
+        """Launch one frame on the next replica's stream and return (outputs, replica index) without making any other
+        stream wait.  `consume(outputs, k)`, if given, is executed right behind the frame ON THAT STREAM (reductions,
+        copies into a frame buffer, encoding ...): the outputs are only ordered with respect to that stream; anybody else
+        waits on `self.events[k]` (recorded behind `consume`) or calls `synchronize()`.  The replica's stream first waits
+        for what the CALLER's stream has enqueued so far (the producers of `batch`; keep frame consumers off that stream,
+        or the frames serialise behind them)."""
+        k = self.calls % len(self.graphs)
+        self.streams[k].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.streams[k]):
+            out = self.graphs[k](batch)
+            for key in ("global_orient", "body_pose", "transl", "near", "far"):   # read on this stream: tell the allocator, or a
+                if torch.is_tensor(batch.get(key)):                                # freed input could be reused before the copy ran
+                    batch[key].record_stream(self.streams[k])
+            if consume is not None:
+                consume(out, k)
+            self.events[k].record()
+        self.calls += 1
+        return out, k
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def refresh_weights(self):
+        """after the (shared) master weights changed: update every replica's fp16 shadow and MFMA fragments in place, on the
+        replica's stream, so that the captured graphs render with the new weights from their next replay on"""
+        for m, s in zip(self.replicas, self.streams):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                m.net_coarse.refresh()
+
+    @property
+    def incomplete_calls(self):
+        n = len(self.graphs)
+        return sorted(c * n + k for k, g in enumerate(self.graphs) for c in g.incomplete_calls)
+
+    def finish(self):
+        return sum(g.finish() for g in self.graphs)
+
+
 def build_synthetic_model(device, resolution=128, n_levels=16, max_samples=256, max_batch=291600, seed=42,
                           cano_pose="A_pose"):
     """Synthetic body + field wired into the three plugins.

@@ -86,6 +86,39 @@ def test_bench_configuration_parity_512_eager_and_graph(oracle, bench_world):
         assert g.finish() == 0
     finally:
         grid.initialize = orig
+    # two frames in flight (what bench.py times by default): every replica's frames against the oracle as well
+    import instantavatar_amd.pipeline as P
+    from instantavatar_amd.pipeline import PipelinedRenderer
+    jit_a, jit_b = (torch.as_tensor(jits[i], device=DEV).clone() for i in (1, 5))
+    patched, real_clone = [], P.clone_for_stream
+
+    def patch(m, jit_dev):
+        gr = m.renderer.density_grid_test
+        o = gr.initialize
+        gr.initialize = lambda deformer, net, iters=5, jitter=None, _o=o: _o(deformer, net, iters=iters, jitter=jit_dev)
+        patched.append((gr, o))
+
+    def patched_clone(m):
+        c = real_clone(m)
+        patch(c, jit_b)          # replica 1 always renders pose 5 below, replica 0 pose 1
+        return c
+    patch(model, jit_a)
+    P.clone_for_stream = patched_clone
+    try:
+        pr = PipelinedRenderer(model, make_batch(DEV, res, poses[1], tr[1]), (res, res), n_in_flight=2)
+        got = []
+        keep = [make_batch(DEV, res, poses[i], tr[i]) for i in (1, 5, 1, 5)]
+        for b in keep:
+            pr(b, consume=lambda out, k: got.append(([t.clone() for t in out], pr.replicas[k].renderer.density_grid_test.density_field.clone())))
+        pr.synchronize()
+        assert pr.finish() == 0
+        for n, i in enumerate((1, 5, 1, 5)):
+            out, occ = got[n]
+            _check(out[0], out[2], out[3], occ, refs[i], "512^2 two in flight, call %d pose %d" % (n, i))
+    finally:
+        P.clone_for_stream = real_clone
+        for gr, o in patched:
+            gr.initialize = o
 
 
 def test_bench_configuration_parity_1024(oracle, bench_world):

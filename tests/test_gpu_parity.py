@@ -412,3 +412,62 @@ def test_hip_graph_replay_equals_eager(gpu_world):
         assert g.finish() == 0
     finally:
         grid.initialize = orig
+
+
+def test_pipelined_renderer_two_frames_in_flight_equal_eager(gpu_world):
+    """PipelinedRenderer: two replicas (shared weights, own workspaces), one captured graph and one stream each.  Every
+    frame must equal the eager render bit for bit whichever replica rendered it, and both replicas must see a weight
+    update (the network parameters are shared by reference, not copied)."""
+    from instantavatar_amd.pipeline import PipelinedRenderer, clone_for_stream
+    model, body, fp, init, poses, tr = gpu_world
+    res = 96
+    jit = torch.rand((5, 64 ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(21))
+    clone = clone_for_stream(model)
+    assert clone.net_coarse.encoder.params is model.net_coarse.encoder.params
+    assert clone.deformer.deformer.lbs_voxel_final.data_ptr() == model.deformer.deformer.lbs_voxel_final.data_ptr()
+    origs = []
+    try:
+        pr = None
+        # fixed jitter for every replica's occupancy grid (the graphs read it from a static buffer)
+        def patch(m):
+            g = m.renderer.density_grid_test
+            o = g.initialize
+            g.initialize = lambda deformer, net, iters=5, jitter=None, _o=o: _o(deformer, net, iters=iters, jitter=jit)
+            origs.append((g, o))
+        patch(model)
+        import instantavatar_amd.pipeline as P
+        real_clone = P.clone_for_stream
+
+        def patched_clone(m):
+            c = real_clone(m)
+            patch(c)
+            return c
+        P.clone_for_stream = patched_clone
+        try:
+            pr = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=2)
+        finally:
+            P.clone_for_stream = real_clone
+        outs = []
+        for i in (1, 4, 6, 2):
+            o, k = pr(make_batch(DEV, res, poses[i], tr[i]), consume=lambda out, k: outs.append([t.clone() for t in out]))
+        pr.synchronize()
+        assert pr.calls == 4 and pr.finish() == 0
+        for n, i in enumerate((1, 4, 6, 2)):
+            ref = model.render_image_fast(make_batch(DEV, res, poses[i], tr[i]), (res, res))
+            for a, e in zip(outs[n], ref):
+                assert torch.equal(a, e), (n, i, float((a.float() - e.float()).abs().max()), int((a != e).sum()))
+        # shared weights: an in-place change of the master parameters reaches both replicas
+        with torch.no_grad():
+            model.net_coarse.color_net.params.mul_(0.5)
+        pr.refresh_weights()
+        a, _ = pr(make_batch(DEV, res, poses[1], tr[1]))
+        b, _ = pr(make_batch(DEV, res, poses[1], tr[1]))
+        pr.synchronize()
+        assert torch.equal(a[0], b[0]) and not torch.equal(a[0], outs[0][0])
+    finally:
+        with torch.no_grad():
+            model.net_coarse.color_net.params.mul_(2.0)
+        model.net_coarse.refresh()
+        torch.cuda.synchronize()
+        for g, o in origs:
+            g.initialize = o
