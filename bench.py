@@ -93,12 +93,12 @@ def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
             "seconds": dt}
 
 
-def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, n_rays=4096, warmup=3):
+def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, n_rays=4096, warmup=3, graphed=True):
     """train.py analogue (configs 2/4): one frame + 4096 rays per step and rank
     (confs/sampler/patch.yaml: 4 x 32 x 32), targets rendered from the synthetic field,
     Adam(lr 1e-2), occupancy update every 20 steps, gradient all-reduce over RCCL."""
     from instantavatar_amd.pipeline import build_synthetic_model, make_batch
-    from instantavatar_amd.training import NeRFLoss, configure_optimizer, training_step
+    from instantavatar_amd.training import GraphedTrainStep, NeRFLoss, configure_optimizer
     n_frames = 4
     targets = []
     with torch.no_grad():
@@ -114,6 +114,10 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
     opt = configure_optimizer(trainee)
     loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    # one rank: the step is replayed from a captured HIP graph (every 20th step, the occupancy update, runs eagerly);
+    # several ranks: eager steps with the bucketed RCCL all-reduce started from inside the backward
+    stepper = GraphedTrainStep(trainee, opt, loss_fn, world_size=world_size, enabled=graphed)
+    bg = torch.ones((1, n_rays, 3), device=dev)
 
     def step(i):
         b, rgb, alpha = targets[(i + rank) % n_frames]
@@ -124,10 +128,10 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
         for k in ("near", "far"):
             batch[k] = b[k][:, sel]
         batch["rgb"], batch["alpha"] = rgb[:, sel], alpha[:, sel]
-        batch["bg_color"] = torch.ones_like(batch["rgb"])
-        return training_step(trainee, batch, opt, loss_fn, world_size=world_size)
+        batch["bg_color"] = bg
+        return stepper(batch)
 
-    for i in range(warmup):
+    for i in range(max(warmup, 3)):
         step(i)
     torch.cuda.synchronize()
     if world_size > 1:
@@ -137,7 +141,7 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
     for i in range(n_steps):
         out = step(warmup + i)
         if i == 0:
-            first = out["mse_loss"].detach()
+            first = out["mse_loss"].detach().clone()   # (a replayed step returns static output tensors)
         last = out["mse_loss"].detach()
     torch.cuda.synchronize()
     if world_size > 1:
@@ -149,6 +153,8 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
         dt = float(t.item())
     return {"it_per_sec": n_steps / dt, "rays_per_sec": n_steps * n_rays * world_size / dt, "steps": n_steps,
             "rays_per_step_per_gpu": n_rays, "mse_first": float(first), "mse_last": float(last),
+            "launch_mode": ("hip_graph (%d replays, %d eager steps)" % (stepper.replays, stepper.eager_steps)) if stepper.replays
+                           else "eager", "graph_capture_error": stepper.capture_error,
             "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
@@ -184,6 +190,24 @@ def _time_encode(net, x, reps=20):
     return a.elapsed_time(b) / reps * 1e3  # us
 
 
+def _morton_order(x, bb):
+    """Permutation that sorts the points by the 30-bit Morton code of their position in the box, and the time of
+    building it (quantise + interleave + sort, torch ops) in microseconds."""
+    def spread(v):  # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    q = ((x - bb[0]) / (bb[1] - bb[0]) * 1023.0).clamp_(0, 1023).to(torch.int64)
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    order = torch.argsort(code)
+    torch.cuda.synchronize()
+    return order, (time.perf_counter() - t0) * 1e6
+
+
 def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512):
     """The hash-grid lookup in isolation (north_star: fraction of the HBM roofline on the hash-grid
     lookup): the XCD-sharded encoding kernel timed with events on the launch stream, (a) on 2^20 uniformly
@@ -212,6 +236,17 @@ def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512)
                                                  "every hit ray, ray-major), as the render loop feeds them to the encoder"}
         except Exception as e:  # never let the auxiliary figure kill the bench line
             out["frame_coherent"] = {"error": repr(e)[:200]}
+    try:
+        # cell binning (SURVEY 7 / VERDICT r01 weak 5): the same random points in 30-bit Morton order, so that the
+        # lanes of a wave sit in one small cube -- what binning can buy at most; the sort is timed beside it
+        order, sort_us = _morton_order(x, bb)
+        usm = _time_encode(net, x[order].contiguous(), reps)
+        gm = n * 512 / (usm * 1e-6) / 1e9
+        out["morton_binned"] = {"avg_launch_us": usm, "Gsamples_per_s": n / usm * 1e-3, "achieved": gm, "frac": gm / HBM_PEAK_GBS,
+                                "binning_us_torch_sort": sort_us,
+                                "what": "the same 2^20 random points sorted by Morton code first (the sort is not part of avg_launch_us)"}
+    except Exception as e:
+        out["morton_binned"] = {"error": repr(e)[:200]}
     cj, src = _profile_json("r02_pmc_encode.json", "r01_pmc_encode.json")
     if cj is not None:
         try:
@@ -351,7 +386,8 @@ def main():
         return x
 
     if args.train_only:
-        tr_res = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3))
+        tr_res = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3),
+                                  graphed=not args.no_graph)
         if rank == 0:
             print(json.dumps({"metric": "train_rays_per_sec", "value": tr_res["rays_per_sec"], "unit": "rays/s", "n_gpus": world_size,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / tr_res["it_per_sec"],
@@ -612,7 +648,7 @@ def main():
             result["mfma"] = dict(mj, source=msrc)
     if args.train_steps > 0:
         try:
-            result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res)
+            result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph)
         except Exception as e:  # the headline line must survive a failure of the secondary workload
             result["train"] = {"error": repr(e)[:300]}
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:

@@ -47,6 +47,8 @@ _SIGS = {
     "ia_voxelise_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ia_voxelise_weights": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
+    "ia_precompute_workspace_bytes": (C.c_size_t, [C.POINTER(SnarfGrid)]),
+    "ia_precompute_ws": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP, C.c_size_t, _VP]),
     "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
                                   C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
     "ia_snarf_search_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
@@ -154,7 +156,10 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the one kernels are launched on; inside
+    `torch.cuda.graph` it is the capturing stream).  The raw getter costs ~0.3 us, `torch.cuda.current_stream()`
+    ~12 us -- nine calls per training step."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def require_cuda(*ts):

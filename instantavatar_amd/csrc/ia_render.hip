@@ -1150,7 +1150,9 @@ __global__ __launch_bounds__(64 * IA_CT_RAYS) void k_composite_train_fwd(
     // (candidates past the capacity of the candidate arrays were dropped by the search: never read)
     const int po = pt_off[s], pc = max(0, min((int)pt_cnt[s], cand_cap - po));
     cand_max_train(cand_sigma, po, pc, n_init, sg, arg);
-    if (noise) sg += noise_scale * noise[s];               // raymarcher_acc.py:166-167
+    // raymarcher_acc.py:166-167: randn_like(sigma_vals), a [n_rays, MAX_SAMPLES] tensor -> the draw of (ray, slot); the
+    // compact index s depends on the order in which the march kernel's waves allocated their runs
+    if (noise) sg += noise_scale * noise[(size_t)n * max_samples + s_slot[s]];
     const float tau = fmaxf(sg, 0.f) * dt;                 // relu(sigma) * dists
     const float a = 1.0f - expf(-tau);
     s_arg[s] = arg; s_sigma[s] = sg; s_alpha[s] = a;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
                                                     const float *__restrict__ tfs,
                                                     float *__restrict__ voxel_J,
                                                     float *__restrict__ voxel_d,
-                                                    float *__restrict__ bbox, SnarfGridDev g) {
+                                                    float *__restrict__ bbox, float *__restrict__ partial,
+                                                    SnarfGridDev g) {
   // VPT consecutive voxels (along W) per thread: one (4*VPT)-byte load per joint plane and 48*VPT
   // contiguous bytes of output per thread.  W % VPT == 0 is checked by the host.
   typedef typename PreVec<VPT>::type vec_t;
@@ -197,12 +198,48 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
         for (int v = 0; v < VPT; v++) voxel_d[(size_t)i0 * n + index0 + v] = xi[i0][v];
     }
   }
-  if (bbox) {
+  // Bounding box of the deformed voxel centres.  With a `partial` buffer every workgroup writes its six extrema
+  // (k_bbox_reduce folds them): no two workgroups touch the same address.  The atomic route (partial == nullptr, kept
+  // for callers without a workspace) sends 2 048 waves x 6 agent-scope loads + atomics to SIX addresses, which
+  // serialise in one memory channel: measured r02 93 us for the kernel with it against 19 us without.
+  if (partial) {
+    __shared__ float s_red[4][6];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float a = ia_wave_min(mn[c]), b = ia_wave_max(mx[c]);
+      if (ia_lane() == 0) { s_red[threadIdx.x >> 6][c] = a; s_red[threadIdx.x >> 6][3 + c] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      float r = s_red[0][threadIdx.x];
+      for (int w = 1; w < 4; w++) r = threadIdx.x < 3 ? fminf(r, s_red[w][threadIdx.x]) : fmaxf(r, s_red[w][threadIdx.x]);
+      partial[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+    }
+  } else if (bbox) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const float a = ia_wave_min(mn[c]), b = ia_wave_max(mx[c]);
       if (ia_lane() == 0) { ia_atomic_min_f(bbox + c, a); ia_atomic_max_f(bbox + 3 + c, b); }
     }
+  }
+}
+
+// folds the per-workgroup extrema of k_precompute: one workgroup, component c = threadIdx.x % 6
+__global__ __launch_bounds__(384) void k_bbox_reduce(const float *__restrict__ partial, int n_blocks, float *__restrict__ bbox) {
+  __shared__ float s_red[64][6];
+  const int c = threadIdx.x % 6, r = threadIdx.x / 6;   // 64 rows x 6 components
+  const bool is_min = c < 3;
+  float v = is_min ? INFINITY : -INFINITY;
+  for (int b = r; b < n_blocks; b += 64) {
+    const float p = partial[(size_t)b * 6 + c];
+    v = is_min ? fminf(v, p) : fmaxf(v, p);
+  }
+  s_red[r][c] = v;
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float o = s_red[0][threadIdx.x];
+    for (int k = 1; k < 64; k++) o = threadIdx.x < 3 ? fminf(o, s_red[k][threadIdx.x]) : fmaxf(o, s_red[k][threadIdx.x]);
+    bbox[threadIdx.x] = o;
   }
 }
 
@@ -321,6 +358,25 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 #define IA_SEARCH_ATTR
 #endif
 
+#ifndef IA_REFILL_GROUP
+// lanes refilled together; measured r02 (k_search per launch, frames/s with two frames in flight): 1: 196 us / 485,
+// 2: 220 / 455, 4: 234 / 440, 8: 228 / 444 -- waiting for whole quads idles more lanes than the shared L1 look-ups save
+#define IA_REFILL_GROUP 1
+#endif
+#if IA_REFILL_GROUP == 1
+#define IA_REFILL_GROUP_HEADS 0xFFFFFFFFFFFFFFFFull
+#elif IA_REFILL_GROUP == 2
+#define IA_REFILL_GROUP_HEADS 0x5555555555555555ull
+#elif IA_REFILL_GROUP == 4
+#define IA_REFILL_GROUP_HEADS 0x1111111111111111ull
+#elif IA_REFILL_GROUP == 8
+#define IA_REFILL_GROUP_HEADS 0x0101010101010101ull
+#elif IA_REFILL_GROUP == 16
+#define IA_REFILL_GROUP_HEADS 0x0001000100010001ull
+#else
+#error "IA_REFILL_GROUP: 1, 2, 4, 8 or 16"
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     const float *__restrict__ xd, int P, const int32_t *__restrict__ n_pts_dev,
@@ -402,7 +458,15 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   bool queue_empty = false;
   while (true) {
     if (!queue_empty) {
-      const unsigned long long need = __ballot(!active);
+      // IA_REFILL_GROUP > 1 (experiment, rejected): refill in aligned groups of lanes, a group taking CONSECUTIVE items
+      // (neighbouring samples of a ray under the same init bone) only when all of its lanes are idle, so that the lanes
+      // the L1 looks up together (one access per quad and cache line) keep fetching from the same or adjacent cells.
+      unsigned long long need = __ballot(!active);
+#pragma unroll
+      for (int sft = 1; sft < IA_REFILL_GROUP; sft *= 2) need &= need >> sft;
+      need &= IA_REFILL_GROUP_HEADS;
+#pragma unroll
+      for (int sft = 1; sft < IA_REFILL_GROUP; sft *= 2) need |= need << sft;
       if (need) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_next, __popcll(need));
@@ -564,19 +628,44 @@ extern "C" int ia_smpl_tfs(const float *joints_rest, const int32_t *parents, con
   return IA_OK;
 }
 
-extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxel_J, float *voxel_d,
-                             float *bbox, const ia_snarf_grid *grid, void *stream) {
+static int ia_precompute_blocks(const ia_snarf_grid *grid) {
+  const long nt = (long)grid->D * grid->H * grid->W / IA_PRE_VPT;
+  return (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
+}
+
+extern "C" size_t ia_precompute_workspace_bytes(const ia_snarf_grid *grid) {
+  if (!grid || grid->D < 1 || grid->H < 1 || grid->W < 1) return 0;
+  return (size_t)ia_precompute_blocks(grid) * 6 * sizeof(float);
+}
+
+extern "C" int ia_precompute_ws(const float *voxel_w, const float *tfs, float *voxel_J, float *voxel_d,
+                                float *bbox, const ia_snarf_grid *grid, void *ws, size_t ws_bytes, void *stream) {
   IA_CHECK_ARG(voxel_w && tfs && voxel_J && grid, "ia_precompute: null pointer");
   IA_CHECK_ARG(grid->D > 1 && grid->H > 1 && grid->W > 1 && grid->W % 4 == 0, "ia_precompute: bad grid %d %d %d (W must be a multiple of 4)", grid->D, grid->H, grid->W);
   hipStream_t s = (hipStream_t)stream;
-  const long n = (long)grid->D * grid->H * grid->W;
-  if (bbox) { hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox); IA_LAUNCH_CHECK("k_bbox_init"); }
-  const long nt = n / IA_PRE_VPT;
-  const int blocks = (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
+  const int blocks = ia_precompute_blocks(grid);
+  float *partial = nullptr;
+  if (bbox && ws) {
+    IA_CHECK_ARG(ws_bytes >= ia_precompute_workspace_bytes(grid), "ia_precompute_ws: workspace of %zu bytes, %zu needed", ws_bytes,
+                 ia_precompute_workspace_bytes(grid));
+    partial = (float *)ws;
+  } else if (bbox) {
+    hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
+    IA_LAUNCH_CHECK("k_bbox_init");
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
-                     ia_make_grid_dev(grid));
+                     partial, ia_make_grid_dev(grid));
   IA_LAUNCH_CHECK("k_precompute");
+  if (partial) {
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(384), 0, s, partial, blocks, bbox);
+    IA_LAUNCH_CHECK("k_bbox_reduce");
+  }
   return IA_OK;
+}
+
+extern "C" int ia_precompute(const float *voxel_w, const float *tfs, float *voxel_J, float *voxel_d,
+                             float *bbox, const ia_snarf_grid *grid, void *stream) {
+  return ia_precompute_ws(voxel_w, tfs, voxel_J, voxel_d, bbox, grid, nullptr, 0, stream);
 }
 
 

@@ -101,10 +101,14 @@ class ForwardDeformer(torch.nn.Module):
         if fr is None or fr["J"].device != tfs.device or fr["J"].shape[0] != d:
             mk = lambda *s: torch.empty(s, device=tfs.device, dtype=torch.float32)
             fr = self._frame = dict(J=mk(d, h, w, 12), d=mk(1, 3, d, h, w), bbox=mk(6))
+            # per-workgroup extrema of the bounding-box reduction (own buffer per deformer replica / stream)
+            fr["ws"] = torch.empty(int(_lib.lib().ia_precompute_workspace_bytes(C.byref(self.grid_desc()))), dtype=torch.uint8,
+                                   device=tfs.device)
         tfs_c = tfs.detach().float().contiguous()
-        _lib.check(_lib.lib().ia_precompute(_lib.ptr(self.lbs_voxel_final), _lib.ptr(tfs_c), _lib.ptr(fr["J"]),
-                                            _lib.ptr(fr["d"]) if want_voxel_d else None, _lib.ptr(fr["bbox"]),
-                                            C.byref(self.grid_desc()), _lib.stream()), "ia_precompute")
+        _lib.check(_lib.lib().ia_precompute_ws(_lib.ptr(self.lbs_voxel_final), _lib.ptr(tfs_c), _lib.ptr(fr["J"]),
+                                               _lib.ptr(fr["d"]) if want_voxel_d else None, _lib.ptr(fr["bbox"]),
+                                               C.byref(self.grid_desc()), _lib.ptr(fr["ws"]), fr["ws"].numel(), _lib.stream()),
+                   "ia_precompute_ws")
         self.voxel_J_cl, self.voxel_d, self.bbox_deformed = fr["J"], fr["d"], fr["bbox"]
 
     @property

@@ -292,7 +292,7 @@ class Raymarcher(torch.nn.Module):
         cand_cap = min(cap * k, self.train_cand_capacity)
         st.update(pt_off=sc["pt_off"], pt_cnt=sc["pt_cnt"], n_init=k,
                   bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
-                  noise=torch.randn(cap, device=dev) if noise > 0 else None, noise_scale=float(noise))
+                  noise=torch.randn((n, S), device=dev) if noise > 0 else None, noise_scale=float(noise))   # :167
         from ..training import field_autograd
         rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cand_cap], n_dev=sc["n_cand"])
         self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)
@@ -312,14 +312,30 @@ class Raymarcher(torch.nn.Module):
         if not hasattr(self, "_tc_host"):
             self._tc_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self._tc_host.copy_(torch.cat([n_samples, n_cand]), non_blocking=True)
+        if getattr(self, "_graph_capture", False):
+            return   # recorded into a graph: the replaying caller marks the copy with `_train_counts_posted`
+        self._train_counts_posted(cand_cap)
+
+    def _train_counts_posted(self, cand_cap):
         self._tc_event = torch.cuda.Event()
         self._tc_event.record()
         self._tc_cap = cand_cap
 
+    def _train_counts_peek(self, cand_cap):
+        """Graph-replay variant of the deferred check: look at whatever counts the device has copied to the pinned
+        pair so far -- those of a step one or two replays back -- without waiting for anything."""
+        if not hasattr(self, "_tc_host"):
+            return
+        self.last_train_counts = (int(self._tc_host[0]), int(self._tc_host[1]))
+        if self.last_train_counts[1] > cand_cap:
+            self.train_overflow += 1
+            self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_train_counts[1])
+            self._tc_host[1] = 0   # counted once
+
     def _train_counts_check(self):
         """Deferred look at the previous step's counts (no stall: that step has long finished)."""
         ev = getattr(self, "_tc_event", None)
-        if ev is None:
+        if ev is None or getattr(self, "_graph_capture", False):
             return
         ev.synchronize()
         self._tc_event = None

@@ -297,16 +297,31 @@ def configure_scheduler(optimizer, max_epochs):
 
 
 def _non_finite_flag(params):
-    """float32 device scalar: 1.0 when any gradient holds an inf / NaN (no host synchronisation).
-    sum() propagates both; 52 MB are read once (~10 us)."""
-    tot = None
-    for p in params:
-        if p.grad is not None:
-            t = p.grad.sum()
-            tot = t if tot is None else tot + t
-    if tot is None:
+    """float32 device scalar: 1.0 when any gradient holds an inf / NaN (no host synchronisation).  One
+    multi-tensor launch over all gradients -- the kernel GradScaler.unscale_ uses, with a scale of 1 (the
+    reference's `self.scaler.step`, DNeRF.py:151-154, runs exactly this check before the optimiser)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
         return None
-    return (~torch.isfinite(tot)).float()
+    dev = grads[0].device
+    flag = torch.zeros((), device=dev)
+    one = _ONES.get(dev)
+    if one is None:
+        one = _ONES[dev] = torch.ones((), device=dev)
+    by_dev = {}
+    for g in grads:
+        by_dev.setdefault((g.device, g.dtype), []).append(g)
+    for (d, _), gs in by_dev.items():
+        if d == dev:
+            torch._amp_foreach_non_finite_check_and_unscale_(gs, flag, one)
+        else:  # parameters on another device (not the case in the shipped configurations)
+            f2 = torch.zeros((), device=d)
+            torch._amp_foreach_non_finite_check_and_unscale_(gs, f2, torch.ones((), device=d))
+            flag = torch.maximum(flag, f2.to(dev))
+    return flag
+
+
+_ONES = {}
 
 
 def optimizer_step_skip_non_finite(optimizer, params):
@@ -363,8 +378,10 @@ def update_density_grid(model, world_size=1, jitter=None):
     return reg
 
 
-def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False):
-    """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs."""
+def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False, _capturing=False):
+    """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs.
+    `_capturing`: the call is being recorded into a HIP graph (GraphedTrainStep): nothing executes, so the
+    host-side step counter is left alone."""
     from . import parallel
     if getattr(model, "SMPL_param", None) is not None:            # DNeRF.py:113-128 (optimize_SMPL.enable)
         batch = dict(batch)
@@ -399,5 +416,122 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params)
     if hasattr(model.net_coarse, "mark_updated"):
         model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
-    model.global_step += 1
+    if not _capturing:
+        model.global_step += 1
     return losses
+
+
+class GraphedTrainStep:
+    """`training_step` replayed from a captured HIP graph (torch.cuda.CUDAGraph).
+
+    A training step has no host synchronisation and fixed launch geometry (sample and candidate counts live on
+    the device, buffers are capacity-sized), but it is ~60 launches and a millisecond of Python: measured on
+    MI355X the host needs 1.1-1.3 ms to enqueue a step whose kernels take 0.9 ms.  The whole step -- deformer
+    preparation, march, search, field forward, compositing, loss, backward, non-finite check, fused Adam -- is
+    captured once and replayed; the batch is copied into static input tensors (`inputs`, which callers may
+    also fill in place) and the loss dictionary is returned as static output tensors (overwritten by the
+    next call: clone what must be kept).
+
+    Run eagerly, through `training_step`, are: steps that update the occupancy grid (every 20th, DNeRF.py:100;
+    their regulariser changes the autograd graph), several ranks (the bucketed all-reduce), models with a
+    `SMPL_param` embedding, and any batch whose tensor shapes differ from the captured ones.  One graph is
+    held per (noise on/off, capacity) state; a candidate-capacity overflow (renderer.train_overflow) drops
+    the graphs so that they are captured again with the grown capacity.  Learning rates are turned into
+    device tensors, so that an `lr_scheduler` keeps working across replays."""
+
+    def __init__(self, model, optimizer, loss_fn, world_size=1, is_refine=False, enabled=True):
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.world_size, self.is_refine = world_size, is_refine
+        self.enabled = bool(enabled) and world_size == 1 and getattr(model, "SMPL_param", None) is None
+        self.graphs = {}
+        self.inputs = None
+        self.replays = 0
+        self.eager_steps = 0
+        self.capture_error = None
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _update_period(self):
+        return 1 if getattr(self.model.renderer, "smpl_init", False) else 20
+
+    def _signature(self, batch):
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v) and v.is_cuda)
+
+    def _make_capturable(self):
+        for g in self.optimizer.param_groups:
+            if not g.get("fused"):
+                raise RuntimeError("GraphedTrainStep needs the fused Adam of configure_optimizer")
+            g["capturable"] = True
+            if not torch.is_tensor(g["lr"]):
+                dev = g["params"][0].device
+                g["lr"] = torch.tensor(float(g["lr"]), device=dev)
+                if "initial_lr" in g and not torch.is_tensor(g["initial_lr"]):
+                    g["initial_lr"] = float(g["initial_lr"])
+
+    def _capture(self, key, use_noise):
+        m, r = self.model, self.model.renderer
+        self._make_capturable()
+        if hasattr(m.net_coarse, "mark_updated"):
+            m.net_coarse.mark_updated()   # the fp16 shadow refresh belongs to every replay
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        r._graph_capture = True
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = training_step(m, self.inputs, self.optimizer, self.loss_fn, 1, self.is_refine, _capturing=True)
+        finally:
+            r._graph_capture = False
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        entry = dict(graph=graph, out=out, grads=[p.grad for p in params], params=params, cap=r.train_cand_capacity)
+        self.graphs[key] = entry
+        return entry
+
+    # -- the step --------------------------------------------------------------------------------------
+    def __call__(self, batch=None):
+        m, r = self.model, self.model.renderer
+        if batch is None:
+            batch = self.inputs
+        eager = (not self.enabled) or m.global_step % self._update_period() == 0
+        if not eager and torch.is_tensor(batch.get("idx")) and batch["idx"].is_cuda:
+            eager = True   # the frame index is read on the host (DNeRF.py:113); keep it a host tensor for graph replay
+        if not eager and self.inputs is not None and batch is not self.inputs:
+            eager = self._signature(batch) != self._sig
+        if eager:
+            self.eager_steps += 1
+            return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
+        if self.inputs is None:
+            self.inputs = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in batch.items()}
+            self._sig = self._signature(batch)
+        elif batch is not self.inputs:
+            for k, v in batch.items():
+                dst = self.inputs.get(k)
+                if torch.is_tensor(dst) and dst.is_cuda:
+                    if v is not dst:
+                        dst.copy_(v, non_blocking=True)
+                else:
+                    self.inputs[k] = v
+        if "idx" in self.inputs:
+            r.idx = int(self.inputs["idx"][0])
+        # deferred look at the counts of an earlier step: an overflow grows the capacity -> capture again
+        r._train_counts_check()                      # (pending event of a preceding eager step, if any)
+        r._train_counts_peek(r.train_cand_capacity)
+        use_noise = m.global_step < 1000 and not self.is_refine
+        key = (bool(use_noise), r.train_cand_capacity)
+        entry = self.graphs.get(key)
+        if entry is None:
+            self.graphs = {k: e for k, e in self.graphs.items() if k[1] == r.train_cand_capacity}
+            try:
+                entry = self._capture(key, use_noise)
+            except Exception as e:  # capture not possible on this stack: stay eager (same kernels, host-launched)
+                self.capture_error = repr(e)[:300]
+                self.enabled = False
+                torch.cuda.synchronize()
+                self.eager_steps += 1
+                return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
+        entry["graph"].replay()
+        self.replays += 1
+        for p, g in zip(entry["params"], entry["grads"]):
+            p.grad = g
+        if hasattr(m.net_coarse, "mark_updated"):
+            m.net_coarse.mark_updated()
+        m.global_step += 1
+        return entry["out"]

@@ -67,6 +67,29 @@ def test_precompute_kernel(oracle, gpu_world):
     assert np.array_equal(bb[:3], vdg.min(1).values.cpu().numpy()) and np.array_equal(bb[3:], vdg.max(1).values.cpu().numpy())
 
 
+def test_precompute_bbox_routes_agree(gpu_world):
+    """ia_precompute (float atomics on bbox) and ia_precompute_ws (per-workgroup extrema + k_bbox_reduce) must
+    produce the same six numbers and the same J / voxel_d, bit for bit (min / max are order independent)."""
+    import ctypes as C
+    from instantavatar_amd import _lib
+    model, body, fp, init, poses, tr = gpu_world
+    _prepare(model, poses, tr, 3)
+    fd = model.deformer.deformer
+    tfs = model.deformer.tfs.detach().float().contiguous()
+    L = _lib.lib()
+    J1, d1, b1 = torch.empty_like(fd.voxel_J_cl), torch.empty_like(fd.voxel_d), torch.zeros(6, device=DEV)
+    _lib.check(L.ia_precompute(_lib.ptr(fd.lbs_voxel_final), _lib.ptr(tfs), _lib.ptr(J1), _lib.ptr(d1), _lib.ptr(b1),
+                               C.byref(fd.grid_desc()), _lib.stream()), "ia_precompute")
+    assert torch.equal(J1, fd.voxel_J_cl) and torch.equal(d1, fd.voxel_d)
+    assert torch.equal(b1, fd.bbox_deformed), (b1, fd.bbox_deformed)
+    nb = int(L.ia_precompute_workspace_bytes(C.byref(fd.grid_desc())))
+    assert nb > 0
+    small = torch.empty(nb - 4, dtype=torch.uint8, device=DEV)
+    rc = L.ia_precompute_ws(_lib.ptr(fd.lbs_voxel_final), _lib.ptr(tfs), _lib.ptr(J1), _lib.ptr(d1), _lib.ptr(b1),
+                            C.byref(fd.grid_desc()), _lib.ptr(small), small.numel(), _lib.stream())
+    assert rc != 0 and b"workspace" in L.ia_last_error()
+
+
 def _query_points(model, n, seed):
     rng = np.random.RandomState(seed)
     vd = model.deformer.deformer.voxel_d[0].reshape(3, -1).cpu().numpy()

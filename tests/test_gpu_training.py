@@ -399,20 +399,117 @@ def test_train_render_matches_oracle(oracle, gw):
                 far=batch["far"][:, sel].clone())
     model.deformer.transform_rays_w2s(rays)
     bg = torch.rand((1, n, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
-    torch.manual_seed(11)
-    jitter = torch.rand((n, 256), device=DEV)          # the first (and, without noise, only) draw of the render
-    torch.manual_seed(11)
-    out = model.renderer.render_train_fused(rays, model.deformer, model.net_coarse, 0, bg)
     ow = W.oracle_world(oracle, body, fp, init, poses[i], tr[i])
     c = lambda t: t.detach().reshape(-1, t.shape[-1]).cpu().numpy() if t.dim() > 2 else t.detach().reshape(-1).cpu().numpy()
-    ref = oracle.render_train(c(rays.o), c(rays.d), c(rays.near), c(rays.far), grid.density_field.cpu().numpy(),
-                              grid.aabb.cpu().numpy(), lambda p: oracle.deform_query(p, ow, eval_mode=False),
-                              jitter.cpu().numpy(), bg=c(bg))
-    rgb = out["rgb_coarse"].detach().reshape(-1, 3).cpu().numpy()
-    alpha = out["alpha_coarse"].detach().reshape(-1).cpu().numpy()
-    w = out["weight_coarse"].detach().reshape(n, 256).cpu().numpy()
-    assert (ref["alpha"] > 0.5).mean() > 0.02 and ref["n_field"] > 1000
-    err_rgb, err_a, err_w = np.abs(rgb - ref["rgb"]).max(1), np.abs(alpha - ref["alpha"]), np.abs(w - ref["weights"]).max(1)
-    assert (err_rgb > 1e-3).mean() < 5e-3 and (err_a > 1e-3).mean() < 5e-3 and (err_w > 1e-3).mean() < 5e-3, \
-        ((err_rgb > 1e-3).mean(), (err_a > 1e-3).mean(), (err_w > 1e-3).mean(), err_rgb.max())
-    assert np.median(err_rgb) < 1e-4
+    for noise_scale in (0, 1):
+        torch.manual_seed(11)
+        jitter = torch.rand((n, 256), device=DEV)          # the first draw of the render (raymarcher_acc.py:156)
+        noise = torch.randn((n, 256), device=DEV)          # the second, when noise > 0 (:167): one value per (ray, slot)
+        torch.manual_seed(11)
+        out = model.renderer.render_train_fused(rays, model.deformer, model.net_coarse, noise_scale, bg)
+        ref = oracle.render_train(c(rays.o), c(rays.d), c(rays.near), c(rays.far), grid.density_field.cpu().numpy(),
+                                  grid.aabb.cpu().numpy(), lambda p: oracle.deform_query(p, ow, eval_mode=False),
+                                  jitter.cpu().numpy(), bg=c(bg), noise=(noise * noise_scale).cpu().numpy() if noise_scale else None)
+        rgb = out["rgb_coarse"].detach().reshape(-1, 3).cpu().numpy()
+        alpha = out["alpha_coarse"].detach().reshape(-1).cpu().numpy()
+        w = out["weight_coarse"].detach().reshape(n, 256).cpu().numpy()
+        assert (ref["alpha"] > 0.5).mean() > 0.02 and ref["n_field"] > 1000
+        err_rgb, err_a, err_w = np.abs(rgb - ref["rgb"]).max(1), np.abs(alpha - ref["alpha"]), np.abs(w - ref["weights"]).max(1)
+        assert (err_rgb > 1e-3).mean() < 5e-3 and (err_a > 1e-3).mean() < 5e-3 and (err_w > 1e-3).mean() < 5e-3, \
+            (noise_scale, (err_rgb > 1e-3).mean(), (err_a > 1e-3).mean(), (err_w > 1e-3).mean(), err_rgb.max())
+        assert np.median(err_rgb) < 1e-4
+
+
+def _train_setup(seed_model, res=64, n_rays=4096):
+    from instantavatar_amd.pipeline import build_synthetic_model
+    model, body, fp, init = W.build(DEV, 64, 16)
+    poses, tr = W.poses()
+    torch.manual_seed(seed_model)
+    tmodel, _, _ = build_synthetic_model(DEV, resolution=64, n_levels=16)
+    tmodel.net_coarse.reset_parameters()
+    tmodel.train()
+    batches = []
+    gsel = torch.Generator(device=DEV).manual_seed(5)
+    for f in (1, 2, 3):
+        b = make_batch(DEV, res, poses[f], tr[f])
+        rgb_gt, _, alpha_gt, _ = model.render_image_fast(b, (res, res))
+        sel = torch.randperm(res * res, device=DEV, generator=gsel)[:n_rays]
+        for k in ("rays_o", "rays_d", "near", "far"):
+            b[k] = b[k][:, sel].contiguous()
+        b["rgb"] = rgb_gt.reshape(1, -1, 3)[:, sel].contiguous()
+        b["alpha"] = alpha_gt.reshape(1, -1)[:, sel].contiguous()
+        b["bg_color"] = torch.ones_like(b["rgb"])
+        batches.append(b)
+    return tmodel, batches
+
+
+def test_graphed_train_step_matches_eager_steps(gw):
+    """GraphedTrainStep (the whole step replayed from a captured HIP graph) against `training_step` launched eagerly:
+    same initial weights, same batches, same RNG seed -> the same loss curve (the jitter / noise draws of a replay
+    continue the philox sequence exactly like eager calls; what differs is the order of the scatter atomics)."""
+    from instantavatar_amd.training import GraphedTrainStep
+    n_steps = 14
+    curves = []
+    for graphed in (False, False, True):
+        tmodel, batches = _train_setup(seed_model=3)
+        opt = configure_optimizer(tmodel)
+        loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+        stepper = GraphedTrainStep(tmodel, opt, loss_fn, enabled=graphed)
+        torch.manual_seed(11)
+        ls = []
+        for it in range(n_steps):
+            out = stepper(batches[it % len(batches)])
+            ls.append(float(out["mse_loss"]))
+            assert float(out["skipped_non_finite"]) == 0.0
+        if graphed:
+            assert stepper.capture_error is None, stepper.capture_error
+            assert stepper.replays == n_steps - 1 and stepper.eager_steps == 1, (stepper.replays, stepper.eager_steps)
+            assert tmodel.global_step == n_steps
+            for n, p in tmodel.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
+        curves.append(ls)
+    e0, e, g = np.array(curves[0]), np.array(curves[1]), np.array(curves[2])
+    # two eager runs: identical draws for identical (ray, slot) cells; what is left is the order of float atomics
+    assert np.allclose(e0, e, rtol=5e-3, atol=1e-6), (e0, e)
+    assert e[-1] < e[0] and g[-1] < g[0], (e, g)
+    assert np.allclose(e, g, rtol=2e-2, atol=1e-6), (e, g)
+
+
+def test_graphed_train_step_sees_lr_changes_and_skips_non_finite(gw):
+    """A replay must honour what the host changes between steps: the learning rate (device tensor, written by
+    an lr_scheduler) and a non-finite loss (found_inf flag of the fused Adam: parameters stay untouched)."""
+    from instantavatar_amd.training import GraphedTrainStep, configure_scheduler
+    tmodel, batches = _train_setup(seed_model=4)
+    opt = configure_optimizer(tmodel)
+    sched = configure_scheduler(opt, max_epochs=2)
+    loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+    stepper = GraphedTrainStep(tmodel, opt, loss_fn)
+    for it in range(4):
+        stepper(batches[it % 3])
+    assert stepper.replays == 3 and stepper.capture_error is None, stepper.capture_error
+    p = tmodel.net_coarse.encoder.params
+    before = p.detach().clone()
+    stepper(batches[1])
+    torch.cuda.synchronize()
+    assert not torch.equal(before, p.detach())
+    # epoch 2 of 2: the LambdaLR factor is 0 -> a replayed step must leave the parameters where they are
+    sched.step()
+    sched.step()
+    assert all(float(g["lr"]) == 0.0 for g in opt.param_groups)
+    before = p.detach().clone()
+    stepper(batches[2])
+    torch.cuda.synchronize()
+    assert torch.equal(before, p.detach())
+    for g in opt.param_groups:
+        g["lr"].fill_(1e-2)
+    bad = dict(batches[0])
+    bad["rgb"] = batches[0]["rgb"].clone()
+    bad["rgb"][0, 0, 0] = float("nan")
+    out = stepper(bad)
+    torch.cuda.synchronize()
+    assert float(out["skipped_non_finite"]) == 1.0
+    assert torch.equal(before, p.detach())
+    out = stepper(batches[0])
+    torch.cuda.synchronize()
+    assert float(out["skipped_non_finite"]) == 0.0 and not torch.equal(before, p.detach())
+    assert stepper.eager_steps == 1
