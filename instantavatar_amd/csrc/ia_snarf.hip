@@ -587,6 +587,9 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   if (tid == 0) {
     int tot = 0;
     for (int w = 0; w < IA_SEARCH_THREADS / 64; w++) { const int c = s_wtot[w]; s_wtot[w] = tot; tot += c; }
+    // (one same-address atomic per workgroup; r02: spreading it over 8 / 64 counters 128 bytes apart changes nothing --
+    // 246.6 / 246.6 / 246.2 us on the 213 k sample points of a frame, tools/bench_search.py -- while a SECOND dependent
+    // atomic per workgroup doubles the launch time: its latency sits on every workgroup's critical path)
     s_blockbase = tot > 0 ? atomicAdd(n_cand, tot) : 0;
   }
   __syncthreads();
