@@ -122,10 +122,17 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
     def step(i):
         b, rgb, alpha = targets[(i + rank) % n_frames]
         sel = torch.randint(0, res * res, (n_rays,), device=dev, generator=g)
+        dst = stepper.inputs
+        if dst is not None:   # graph replay: the ray gathers write straight into the static input tensors
+            for k in ("rays_o", "rays_d", "near", "far"):
+                torch.index_select(b[k], 1, sel, out=dst[k])
+            torch.index_select(rgb, 1, sel, out=dst["rgb"])
+            torch.index_select(alpha, 1, sel, out=dst["alpha"])
+            for k in ("global_orient", "body_pose", "transl"):
+                dst[k].copy_(b[k], non_blocking=True)
+            return stepper()
         batch = dict(b)
-        for k in ("rays_o", "rays_d"):
-            batch[k] = b[k][:, sel]
-        for k in ("near", "far"):
+        for k in ("rays_o", "rays_d", "near", "far"):
             batch[k] = b[k][:, sel]
         batch["rgb"], batch["alpha"] = rgb[:, sel], alpha[:, sel]
         batch["bg_color"] = bg

@@ -33,7 +33,9 @@ __global__ void k_smpl_tfs(const float *__restrict__ joints, const int32_t *__re
   __shared__ float chain[24][16];
   __shared__ float A[24][16];
   __shared__ float w2s[16];
+  __shared__ int s_par[24];
   const int j = threadIdx.x;
+  if (j < 24) s_par[j] = parents[j];
   if (j < 24) {
     // batch_rodrigues (lbs.py:295-329)
     float rx = pose[j * 3], ry = pose[j * 3 + 1], rz = pose[j * 3 + 2];
@@ -61,11 +63,20 @@ __global__ void k_smpl_tfs(const float *__restrict__ joints, const int32_t *__re
     tm[j][12] = 0; tm[j][13] = 0; tm[j][14] = 0; tm[j][15] = 1;
   }
   __syncthreads();
-  if (j == 0) {  // sequential chain (lbs.py:384-389); 23 4x4 products
-    for (int k = 0; k < 16; k++) chain[0][k] = tm[0][k];
-    for (int i = 1; i < 24; i++) mat4_mul(chain[parents[i]], tm[i], chain[i]);
-  }
+  // sequential chain (lbs.py:384-389): 23 dependent 4x4 products, lane (a, b) of the first 16 computes element (a, b) with
+  // the summation order of mat4_mul (one thread doing all 16 elements of all 23 products: 24 -> 9 us for the launch)
+  if (j < 16) chain[0][j] = tm[0][j];
   __syncthreads();
+  for (int i = 1; i < 24; i++) {
+    if (j < 16) {
+      const int a = j >> 2, b = j & 3;
+      const float *pa = chain[s_par[i]];   // (from LDS: a global load here is a ~1 us round trip per joint)
+      float acc = 0.f;
+      for (int k = 0; k < 4; k++) acc += pa[a * 4 + k] * tm[i][k * 4 + b];
+      chain[i][j] = acc;
+    }
+    __syncthreads();
+  }
   if (j < 24) {
     // rel_transforms = transforms - pad(transforms @ [J,0])  (lbs.py:396-399)
     float jx = joints[j * 3], jy = joints[j * 3 + 1], jz = joints[j * 3 + 2];

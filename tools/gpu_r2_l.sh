@@ -1,3 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-bash tools/ab_search.sh "" "-DIA_EXP_COUNTERS=8" "-DIA_EXP_COUNTERS=64"
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_training.py -q -m gpu -x 2>&1 | tail -2
+for i in 1 2; do timeout 200 python bench.py --train-only --steps 300 --warmup 10 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); t=d['train']; print(round(t['it_per_sec'],1), 'it/s', t.get('launch_mode'), t['mse_last'])"; done
