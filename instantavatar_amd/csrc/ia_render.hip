@@ -532,10 +532,15 @@ __global__ __launch_bounds__(256) void k_render_init_rays(int R, const float *__
 // march + sample compaction: every alive ray counts its samples (pass 1), the
 // wave reserves a contiguous range with one atomic (prefix sum), pass 2 re-marches
 // and writes positions + depths.  A ray's samples are contiguous and ordered.
+// LDS_BITS: the 64^3 bit grid (32 KB) is staged in LDS by every workgroup that has a ray inside the box, and the
+// occupancy tests of the march read it from there: a wave's 64 divergent 4-byte loads cost the vector L1 one look-up
+// each (the same limit k_search runs into), the LDS serves them in a few clocks.
+#define IA_MARCH_LDS_WORDS (64 * 64 * 64 / 32)
+template <bool LDS_BITS>
 __global__ __launch_bounds__(256) void k_march_compact(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, float *near_w,
     const float *__restrict__ fars, const float *__restrict__ step, const int32_t *__restrict__ alive,
-    RenderState *st, const uint32_t *__restrict__ bits, int G, const float *__restrict__ aabb,
+    RenderState *st, const uint32_t *bits_global, int G, const float *__restrict__ aabb,
     float *__restrict__ s_pts, float *__restrict__ s_t, int32_t *__restrict__ ray_off,
     int32_t *__restrict__ ray_cnt, float *__restrict__ counter, int sample_cap, int max_samples, int max_batch) {
   int n_alive, N_steps;
@@ -546,16 +551,39 @@ __global__ __launch_bounds__(256) void k_march_compact(
     st[1].k_before = st->k_before + N_steps;
     st[1].iters = st->iters + (n_alive > 0 ? 1 : 0);
   }
-  if ((i - ia_lane()) >= n_alive) return;  // whole wave idle
+  if ((i - ia_lane()) >= n_alive) return;  // whole wave idle (exited waves do not take part in the barriers below)
   const bool live = i < n_alive;
   int cnt = 0;
   size_t n = 0;
   MarchRay r;
-  float t0 = 0.f, t_end = 0.f;
+  float t0 = 0.f, t_end = 0.f, t_start = 0.f;
   if (live) {
     n = (size_t)alive[i];
     r = load_ray(rays_o, rays_d, fars, step, n, aabb, aabb + 3, G);
-    float t = near_w[n];
+    t_start = near_w[n];
+  }
+  __shared__ uint32_t s_bits[LDS_BITS ? IA_MARCH_LDS_WORDS : 1];
+  __shared__ int s_any;
+  if (LDS_BITS) {
+    // "does anybody in this workgroup march?" by hand: the idle waves at the end of the workgroup have exited, and a
+    // library work-group reduction (__syncthreads_or) may count on every wave of the workgroup.  Wave 0 is present
+    // whenever any wave is.
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if (__any(live && t_start < r.far) && ia_lane() == 0) s_any = 1;
+    __syncthreads();
+    if (s_any) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(bits_global);
+      uint4 *dst = reinterpret_cast<uint4 *>(s_bits);
+      // only the waves that did not exit above take part: stride = their thread count, not blockDim
+      const int present = min(256, ((n_alive - (int)(blockIdx.x * blockDim.x)) + 63) & ~63);
+      for (int w = threadIdx.x; w < IA_MARCH_LDS_WORDS / 4; w += present) dst[w] = src[w];
+    }
+    __syncthreads();
+  }
+  const uint32_t *bits = LDS_BITS ? s_bits : bits_global;
+  if (live) {
+    float t = t_start;
     t0 = t;
     bool found = false;
     // The reference loop (raymarcher.cu:44-69)
@@ -983,8 +1011,15 @@ extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const fl
     RenderState *st = rw.st + it;
     // upper bounds for the launches: iteration 0 may have R alive rays, later
     // ones never more than the first compaction leaves; keep R (idle waves exit).
-    hipLaunchKernelGGL(k_march_compact, gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, st, occ_bits,
-                       G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap, max_samples, max_batch);
+#ifndef IA_MARCH_LDS
+#define IA_MARCH_LDS 1
+#endif
+    if (IA_MARCH_LDS && G == 64 && ((size_t)occ_bits & 15) == 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march_compact<true>), gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, st, occ_bits,
+                         G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap, max_samples, max_batch);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march_compact<false>), gR, blk, 0, s, rays_o, rays_d, rw.near_w, far, rw.step, cur, st, occ_bits,
+                         G, aabb, rw.s_pts, rw.s_t, rw.ray_off, rw.ray_cnt, rw.counter, rw.sample_cap, max_samples, max_batch);
     rw.q.n_cand = &st->n_cand;  // zeroed with the record: no zero-fill launch per iteration
     rc = query_impl(rw.s_pts, cap, &st->n_samples, voxel_J, tfs, bone_ids, n_init, grid, F, rw.q, s, 0);
     if (rc) return rc;
