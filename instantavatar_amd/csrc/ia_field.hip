@@ -1125,6 +1125,26 @@ extern "C" int ia_field_bwd(const uint16_t *acts, const float *rgb, const float 
 #define IA_HGB_REDUCE_LEVELS 8
 #endif
 
+#ifndef IA_HGB_QUAD
+#define IA_HGB_QUAD 1
+#endif
+// one round of the quad-cooperative scatter: every lane of a quad reads the operands of quad lane R (DPP quad_perm) and
+// adds its own word of that sample's (x0, x1) entry pair
+template <int R>
+__device__ __forceinline__ void ia_hgb_quad_round(float *__restrict__ dtab, int qj, uint32_t i0, uint32_t i1, float q0, float q1,
+                                                  float q2, float q3) {
+  constexpr int CTRL = R * 0x55;   // quad_perm [R, R, R, R]
+#define IA_QB_I(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), CTRL, 0xF, 0xF, false))
+#define IA_QB_F(v) (__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)))
+  const uint32_t b0 = IA_QB_I(i0), b1 = IA_QB_I(i1);
+  const float t0 = IA_QB_F(q0), t1 = IA_QB_F(q1), t2 = IA_QB_F(q2), t3 = IA_QB_F(q3);
+#undef IA_QB_I
+#undef IA_QB_F
+  const uint32_t bi = (qj & 2) ? b1 : b0;
+  const float val = (qj & 2) ? ((qj & 1) ? t3 : t2) : ((qj & 1) ? t1 : t0);
+  if (val != 0.f) unsafeAtomicAdd(dtab + (size_t)bi * 2 + (qj & 1), val);
+}
+
 template <int L>
 __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ x, int V,
                                                       const int32_t *__restrict__ n_dev, FieldDev F,
@@ -1183,6 +1203,10 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
           cont |= c ? (1u << k) : 0u;
         }
       }
+#if IA_HGB_QUAD
+      uint32_t c_index[8];
+      float c_v0[8], c_v1[8];
+#endif
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) {
         const uint32_t cx = g[0] + (idx & 1), cy = g[1] + ((idx >> 1) & 1), cz = g[2] + ((idx >> 2) & 1);
@@ -1205,10 +1229,16 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
             if ((cont >> k) & 1u) { v0 += a0; v1 += a1; }
           }
         }
+#if IA_HGB_QUAD
+        c_index[idx] = index;
+        c_v0[idx] = (live && head) ? v0 : 0.f;   // zero = nothing to add (skipped below)
+        c_v1[idx] = (live && head) ? v1 : 0.f;
+#else
         if (live && head) {
           if (v0 != 0.f) unsafeAtomicAdd(dtab + (size_t)index * 2, v0);
           if (v1 != 0.f) unsafeAtomicAdd(dtab + (size_t)index * 2 + 1, v1);
         }
+#endif
         if (dx && live) {
           union { uint32_t u; half2v h; } c;
           c.u = tab[index];
@@ -1219,6 +1249,27 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
           gx[2] += scale * wx * wy * sz * dot;
         }
       }
+#if IA_HGB_QUAD
+      // ---- quad-cooperative scatter -----------------------------------------------------------------------------------
+      // The atomic units take ~21 G REQUESTS/s whatever they carry, and the lanes of one instruction that hit adjacent
+      // words are one request (tools/ubench/atomics.hip: 21 / 42 / 84 G atomics/s for single words / pairs / 16-byte
+      // quads).  So the four lanes of a quad serve ONE sample per round: lane j adds feature (j & 1) of the x-neighbour
+      // (j >> 1) -- the two features of an entry are 8 contiguous bytes, and the x-neighbour's entry follows directly on
+      // dense levels and on hashed levels when cx is even (the hash differs in bit 0 only): one or two requests per
+      // (sample, y, z) instead of four.  Same additions, same operands; only which lane issues them changes.
+      {
+        const int qj = lane & 3;
+#pragma unroll
+        for (int yz = 0; yz < 4; yz++) {
+          const uint32_t i0 = c_index[2 * yz], i1 = c_index[2 * yz + 1];
+          const float q0 = c_v0[2 * yz], q1 = c_v1[2 * yz], q2 = c_v0[2 * yz + 1], q3 = c_v1[2 * yz + 1];
+          ia_hgb_quad_round<0>(dtab, qj, i0, i1, q0, q1, q2, q3);
+          ia_hgb_quad_round<1>(dtab, qj, i0, i1, q0, q1, q2, q3);
+          ia_hgb_quad_round<2>(dtab, qj, i0, i1, q0, q1, q2, q3);
+          ia_hgb_quad_round<3>(dtab, qj, i0, i1, q0, q1, q2, q3);
+        }
+      }
+#endif
     }
     if (dx && live) {
 #pragma unroll

@@ -1,8 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for fl in "-DIA_MARCH_LDS=0" "-DIA_MARCH_LDS=1"; do
-  ( cd instantavatar_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $fl -x hip -c ia_render.hip -o ia_render.hip.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so *.o )
-  for i in 1 2; do timeout 200 python bench.py --steps 40 --warmup 5 --cpu-frames 0 --train-steps 0 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('[$fl]', round(d['value'],1), 'fps', d.get('one_frame_in_flight'))"; done
-done
+timeout 600 python -m pytest tests/test_gpu_training.py -q -m gpu -x 2>&1 | tail -2
+timeout 200 python tools/bench_hgbwd_patch.py quad 2>&1 | tail -3
+timeout 200 python tools/bench_hgbwd.py 2>&1 | grep -E "V =|all 16|level  0|level  7|level 15"
+for i in 1 2; do timeout 200 python bench.py --train-only --steps 200 --warmup 10 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); t=d['train']; print(round(t['it_per_sec'],1), 'it/s', t.get('launch_mode'), t['samples_candidates_last_step'], t['mse_last'])"; done
