@@ -1257,6 +1257,9 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
       // (j >> 1) -- the two features of an entry are 8 contiguous bytes, and the x-neighbour's entry follows directly on
       // dense levels and on hashed levels when cx is even (the hash differs in bit 0 only): one or two requests per
       // (sample, y, z) instead of four.  Same additions, same operands; only which lane issues them changes.
+      // (Measured on top of this and dropped: the coarse dense levels 0-2 accumulated per workgroup in LDS slabs by a
+      // second kernel -- level 0 alone 222 -> 40 us, but the whole scatter 984 -> 966 us and the training step unchanged:
+      // the same-address traffic of the coarse levels drains under the fine levels' requests, it is not on the critical path.)
       {
         const int qj = lane & 3;
 #pragma unroll

@@ -513,3 +513,47 @@ def test_graphed_train_step_sees_lr_changes_and_skips_non_finite(gw):
     torch.cuda.synchronize()
     assert float(out["skipped_non_finite"]) == 0.0 and not torch.equal(before, p.detach())
     assert stepper.eager_steps == 1
+
+
+def test_hashgrid_backward_is_independent_of_call_granularity(gw):
+    """The scatter forms its sums in a launch-dependent order (in-wave run reduction, quad-cooperative atomics, grid-stride
+    rounds): one call over 150 000 clustered samples (four small boxes, like a patch batch: heavy same-cell traffic) must
+    equal the sum of five 30 000-sample calls up to fp32 summation order -- with and without the input gradient -- and so
+    must the level-range calls of the bucketed all-reduce path."""
+    import ctypes as C
+    from instantavatar_amd import _lib
+    for net in (gw[0].net_coarse, W.build(DEV, 64, 8)[0].net_coarse):
+        L = _lib.lib()
+        g = torch.Generator(device=DEV).manual_seed(9)
+        V, nf = 150000, 2 * net.n_levels
+        bb = gw[0].deformer.bbox
+        centre = torch.rand((4, 3), device=DEV, generator=g) * 0.6 + 0.2
+        box = centre[torch.randint(0, 4, (V,), device=DEV, generator=g)] + (torch.rand((V, 3), device=DEV, generator=g) - 0.5) * 0.08
+        x = (box * (bb[1] - bb[0]) + bb[0]).contiguous()
+        dfeat = torch.randn((V, nf), device=DEV, generator=g) * 1e-2
+        dfeat[torch.rand(V, device=DEV, generator=g) < 0.3] = 0      # candidates without gradient
+        n_tab = 2 * net.n_entries
+        fd = net.field_desc()
+
+        def run(chunks, want_dx):
+            dt = torch.zeros(n_tab, device=DEV)
+            dx = torch.zeros((V, 3), device=DEV) if want_dx else None
+            for a in range(0, V, chunks):
+                b = min(V, a + chunks)
+                _lib.check(L.ia_hashgrid_bwd(_lib.ptr(x[a:b].contiguous()), b - a, None, C.byref(fd), _lib.ptr(dfeat[a:b].contiguous()),
+                                             dt.data_ptr(), _lib.ptr(dx[a:b]) if want_dx else None, _lib.stream()), "ia_hashgrid_bwd")
+            return dt, dx
+
+        ref, dx_ref = run(30000, True)
+        for want_dx in (False, True):
+            got, dx = run(V, want_dx)
+            assert ((got != 0) == (ref != 0)).all()
+            err = (got - ref).abs().max() / ref.abs().max()
+            assert err < 1e-5, (net.n_levels, want_dx, float(err))
+            if want_dx:
+                assert torch.equal(dx, dx_ref)   # the input gradient is lane-local: bit identical
+        # level ranges (the bucketed all-reduce path) add up to the same table
+        parts = torch.zeros(n_tab, device=DEV)
+        for l0, l1 in ((net.n_levels // 2, net.n_levels), (0, net.n_levels // 2)):
+            _lib.check(L.ia_hashgrid_bwd_levels(_lib.ptr(x), V, None, C.byref(fd), _lib.ptr(dfeat), parts.data_ptr(), l0, l1, _lib.stream()))
+        assert (parts - ref).abs().max() / ref.abs().max() < 1e-5
