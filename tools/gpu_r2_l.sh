@@ -1,7 +1,4 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_training.py -q -m gpu -x 2>&1 | tail -12 | cut -c1-250
-timeout 200 python tools/bench_hgbwd_patch.py slab 2>&1 | tail -3
-timeout 200 python tools/bench_hgbwd.py 2>&1 | grep -E "V =|all 16"
-for i in 1 2; do timeout 200 python bench.py --train-only --steps 200 --warmup 10 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); t=d['train']; print(round(t['it_per_sec'],1), 'it/s', t.get('launch_mode'), t['samples_candidates_last_step'], t['mse_last'])"; done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+( cd /tmp && export TMPDIR=/tmp && rm -rf $O/prof_train && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o r -- python $R/bench.py --gpus 1 --train-only --steps 200 --warmup 10 > $O/prof_train.log 2>&1 )
+tail -1 $O/prof_train.log | cut -c1-200
