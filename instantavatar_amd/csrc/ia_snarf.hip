@@ -157,6 +157,10 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
 #pragma unroll
       for (int c = 0; c < 12; c++) J[v][c] = 0.f;
     // precompute.cu:51-59: J[c] accumulates over j in joint order
+    // (NOTE: every variant below was timed while the bounding-box reduction at the end of the kernel still sent
+    // 2 048 waves x 6 float atomics to six addresses -- 74 of the 93 us, see the end of the kernel; they compare the
+    // variants under that tail, not the streams themselves.  With the reduction through per-workgroup extrema the
+    // kernel takes 19-22 us for 75-82 MB, 3.7-3.9 TB/s.)
     // (requesting all 24 planes before the first use was measured: 193 VGPRs, 98 -> 115 us; one voxel per thread with
     // all 24 four-byte loads in flight and LDS-transposed, fully coalesced stores: 180 us -- 4-byte-per-lane plane
     // loads stream at half the rate of 16-byte ones; groups of 4 / 6 / 8 / 12 planes explicitly in flight (the
