@@ -16,7 +16,7 @@ import torch
 
 from .. import synthetic
 from ..pipeline import build_synthetic_model, make_batch
-from ..training import NeRFLoss, configure_optimizer, configure_scheduler, training_step
+from ..training import GraphedTrainStep, NeRFLoss, configure_optimizer, configure_scheduler
 from . import checkpoint as ckpt_io
 
 
@@ -44,10 +44,12 @@ def synthetic_batches(device, teacher, res=256, n_frames=8, n_rays=4096, seed=12
 
 
 def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout, scheduler=None,
-        steps_per_epoch=None, max_epochs=None, world_size=1):
+        steps_per_epoch=None, max_epochs=None, world_size=1, graphed=True):
     """`steps` iterations of training_step; returns (last losses (device tensors), optimizer, scheduler).
     The reference steps its LambdaLR `(1 - epoch / max_epochs) ** 1.5` once per epoch (DNeRF.py:52-55, Lightning's
-    default interval): pass `steps_per_epoch` (= frames of the sequence) and `max_epochs` to get the same decay."""
+    default interval): pass `steps_per_epoch` (= frames of the sequence) and `max_epochs` to get the same decay.
+    graphed: on one rank the step is replayed from a captured HIP graph (training.GraphedTrainStep; it runs the
+    occupancy-update steps eagerly and falls back to eager steps altogether when capture is not possible)."""
     optimizer = optimizer or configure_optimizer(model)
     if scheduler is None and steps_per_epoch and max_epochs:
         scheduler = configure_scheduler(optimizer, max_epochs)
@@ -55,15 +57,16 @@ def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=s
     model.train()
     t0 = time.perf_counter()
     losses = None
+    step = GraphedTrainStep(model, optimizer, loss_fn, world_size=world_size, enabled=graphed)
     for it, batch in zip(range(steps), batches):
-        losses = training_step(model, batch, optimizer, loss_fn, world_size=world_size)
+        losses = step(batch)
         if scheduler is not None and steps_per_epoch and model.global_step % steps_per_epoch == 0:
             scheduler.step()
         if log_every and (it + 1) % log_every == 0:
             torch.cuda.synchronize()
             print("step %d  loss %.5f  mse %.5f  lr %.2e  %.0f it/s" % (
                 model.global_step, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
-                optimizer.param_groups[0]["lr"], (it + 1) / (time.perf_counter() - t0)), file=out)
+                float(optimizer.param_groups[0]["lr"]), (it + 1) / (time.perf_counter() - t0)), file=out)
     return losses, optimizer, scheduler
 
 
@@ -90,7 +93,7 @@ def main(argv=None):
         # parameters, buffers, global_step AND the optimiser moments / LR-scheduler epoch: a resumed run
         # continues the interrupted one instead of restarting Adam from zero moments
         ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, optimizer=opt, scheduler=sched)
-        print("resumed from %s at step %d (lr %.2e)" % (args.ckpt, model.global_step, opt.param_groups[0]["lr"]))
+        print("resumed from %s at step %d (lr %.2e)" % (args.ckpt, model.global_step, float(opt.param_groups[0]["lr"])))
     losses, opt, sched = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps, optimizer=opt, scheduler=sched,
                              steps_per_epoch=args.steps_per_epoch, max_epochs=args.max_epochs)
     os.makedirs(os.path.dirname(os.path.abspath(args.ckpt)), exist_ok=True)
