@@ -132,8 +132,8 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
         frames = DeviceFrames(imgs, masks, K, np.eye(4), smpl, PatchSampler(num_patch=4, patch_size=32, ratio_mask=1, dilate=0))
         assert 4 * 32 * 32 == n_rays
 
-        def step(i):
-            return stepper(frames.batch((i + rank) % n_frames, generator=g))
+        def step(i):   # (after the capture the sampler writes straight into the graph's static input tensors)
+            return stepper(frames.batch((i + rank) % n_frames, generator=g, out=stepper.inputs))
     else:
         bg = torch.ones((1, n_rays, 3), device=dev)
 

@@ -476,6 +476,14 @@ int ia_sample_batch(const uint8_t *img_u8, const float *img_f, const float *mask
                     const float *bg, float *rgb, float *alpha, float *o_out, float *d_out,
                     float *bg_out, int32_t *idx_out, void *stream);
 
+/* PatchSampler's corners (sampler.py:58-75): row_mask / col_mask [n] = the mask branch (ia_nonzero_select without
+ * replacement on the window cropped by patch/2), draws [1 + 2 n] = branch coin, then the anchor draws; the uniform
+ * branch is floor(u * (H - patch)) (np.random.randint(0, H - patch)), chosen when coin >= ratio_mask.  rows / cols [n]. */
+int ia_patch_corners(const int32_t *row_mask, const int32_t *col_mask, const float *draws, int n, int H, int W,
+                     int patch, float ratio_mask, int32_t *rows, int32_t *cols, void *stream);
+/* near / far of a frame's n rays (peoplesnapshot.py:146-150): |transl| -/+ 1, transl: DEVICE float[3].          */
+int ia_near_far(const float *transl, int n, float *near_out, float *far_out, void *stream);
+
 /* ---- measurement hooks (bench.py only) --------------------------------------
  * When enabled, every launch of the Broyden-search kernel (id 0) and of the
  * field kernel (id 1) is bracketed by HIP events on the caller's stream and the

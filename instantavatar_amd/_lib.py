@@ -70,6 +70,8 @@ _SIGS = {
     "ia_nonzero_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_nonzero_select": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, _VP,
                                     _VP, C.c_size_t, _VP]),
+    "ia_patch_corners": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),
+    "ia_near_far": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     "ia_sample_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP,
                                   _VP, _VP, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),

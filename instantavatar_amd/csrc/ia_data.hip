@@ -284,3 +284,53 @@ extern "C" int ia_sample_batch(const uint8_t *img_u8, const float *img_f, const 
   IA_LAUNCH_CHECK("k_sample_batch");
   return IA_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// PatchSampler's corner choice (instant_avatar/utils/sampler.py:58-75) after the mask branch has been evaluated by
+// ia_nonzero_select: the uniform branch np.random.randint(0, H - P) from the same draws and the blend by the branch
+// coin, in one launch instead of a dozen element-wise ones.  draws [1 + 2 n]: coin, then the anchor draws.
+// ---------------------------------------------------------------------------
+__global__ void k_patch_corners(const int32_t *__restrict__ row_mask, const int32_t *__restrict__ col_mask,
+                                const float *__restrict__ draws, int n, int H, int W, int P, float p_mask,
+                                int32_t *__restrict__ rows, int32_t *__restrict__ cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool use_mask = draws[0] < p_mask;
+  // floor(u * (H - P)) clamped to H - P - 1: np.random.randint(0, H - P) (sampler.py:72)
+  const float fr = fminf(floorf(draws[1 + i] * (float)(H - P)), (float)(H - P - 1));
+  const float fc = fminf(floorf(draws[1 + n + i] * (float)(W - P)), (float)(W - P - 1));
+  rows[i] = use_mask ? row_mask[i] : (int32_t)fr;
+  cols[i] = use_mask ? col_mask[i] : (int32_t)fc;
+}
+
+extern "C" int ia_patch_corners(const int32_t *row_mask, const int32_t *col_mask, const float *draws, int n, int H, int W,
+                                int patch, float ratio_mask, int32_t *rows, int32_t *cols, void *stream) {
+  IA_CHECK_ARG(n >= 0, "ia_patch_corners: n < 0");
+  if (n == 0) return IA_OK;
+  IA_CHECK_ARG(row_mask && col_mask && draws && rows && cols && patch > 0 && H > patch && W > patch, "ia_patch_corners: bad arguments");
+  hipLaunchKernelGGL(k_patch_corners, dim3(ia_div_up(n, 64)), dim3(64), 0, (hipStream_t)stream, row_mask, col_mask, draws, n, H, W, patch,
+                     ratio_mask, rows, cols);
+  IA_LAUNCH_CHECK("k_patch_corners");
+  return IA_OK;
+}
+
+// near / far of a frame's rays (peoplesnapshot.py:146-150): distance of the camera (at the origin) to the mid-hip
+// translation -/+ 1, the three squares summed in numpy's order for float32.
+__global__ void k_near_far(const float *__restrict__ transl, int n, float *__restrict__ near_out, float *__restrict__ far_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = transl[0], y = transl[1], z = transl[2];
+  const float d = sqrtf((x * x + y * y) + z * z);
+  near_out[i] = d - 1.f;
+  far_out[i] = d + 1.f;
+}
+
+extern "C" int ia_near_far(const float *transl, int n, float *near_out, float *far_out, void *stream) {
+  IA_CHECK_ARG(n >= 0, "ia_near_far: n < 0");
+  if (n == 0) return IA_OK;
+  IA_CHECK_ARG(transl && near_out && far_out, "ia_near_far: null pointer");
+  hipLaunchKernelGGL(k_near_far, dim3(ia_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, transl, n, near_out, far_out);
+  IA_LAUNCH_CHECK("k_near_far");
+  return IA_OK;
+}

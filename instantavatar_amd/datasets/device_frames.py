@@ -58,8 +58,10 @@ class DeviceFrames:
     def __len__(self):
         return self.N
 
-    def batch(self, idx, draws=None, bg_draws=None, generator=None):
-        """One training batch (leading batch dimension 1, as the reference's DataLoader with batch_size=1 yields)."""
+    def batch(self, idx, draws=None, bg_draws=None, generator=None, out=None):
+        """One training batch (leading batch dimension 1, as the reference's DataLoader with batch_size=1 yields).
+        out: a batch dict returned by an earlier call (or `training.GraphedTrainStep.inputs`, the static input tensors of
+        a captured step): the kernels write into its tensors instead of fresh ones -- no copies afterwards."""
         dev = self.images.device
         L = _lib.lib()
         H, W = self.H, self.W
@@ -75,11 +77,20 @@ class DeviceFrames:
             n, shape = n_patch * P * P, (n_patch, P, P)
         else:
             raise TypeError("DeviceFrames needs an instantavatar_amd.utils.sampler.EdgeSampler / PatchSampler")
+        def dst(key, *shp):
+            """the tensor results are written to: the caller's (if it has the right shape) or a fresh one"""
+            t = out.get(key) if out is not None else None
+            if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == int(np.prod(shp)):
+                return t.view(*shp)
+            return torch.empty(shp, device=dev)
+
+        bg = dst("bg_color", n, 3)
         if bg_draws is None:
-            bg_draws = torch.rand((n, 3), device=dev, generator=generator)    # np.random.rand(*img.shape) at :111, for the sampled pixels
-        bg = bg_draws.reshape(n, 3).float().contiguous()
-        rgb, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev)
-        ro, rd = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
+            bg.uniform_(0.0, 1.0, generator=generator)                       # np.random.rand(*img.shape) at :111, for the sampled pixels
+        else:
+            bg.copy_(bg_draws.reshape(n, 3))
+        rgb, alpha = dst("rgb", n, 3), dst("alpha", n)
+        ro, rd = dst("rays_o", n, 3), dst("rays_d", n, 3)
         img = self.images[idx]
         img_u8 = img if img.dtype == torch.uint8 else None
         img_f = None if img_u8 is not None else img.float().contiguous()
@@ -89,16 +100,29 @@ class DeviceFrames:
                                      _lib.ptr(alpha), _lib.ptr(ro), _lib.ptr(rd), None, None, _lib.stream()), "ia_sample_batch")
         p = self.smpl_params
         transl = p["transl"][idx]
+        near, far = dst("near", n), dst("far", n)
         if self.near is not None and self.far is not None:
-            near, far = torch.full(shape, float(self.near), device=dev), torch.full(shape, float(self.far), device=dev)
-        else:  # distance from the camera to the mid-hip (:146-150)
-            sq = torch.square(transl)
-            dist = torch.sqrt((sq[0] + sq[1]) + sq[2])   # numpy's summation order for three float32 terms
-            near, far = (dist - 1).expand(shape).contiguous(), (dist + 1).expand(shape).contiguous()
-        return {
+            near.fill_(float(self.near))
+            far.fill_(float(self.far))
+        else:  # distance from the camera to the mid-hip (:146-150), one launch
+            _lib.check(L.ia_near_far(_lib.ptr(transl.contiguous()), n, _lib.ptr(near), _lib.ptr(far), _lib.stream()), "ia_near_far")
+        res = {
             "rgb": rgb.reshape(1, *shape, 3), "rays_o": ro.reshape(1, *shape, 3), "rays_d": rd.reshape(1, *shape, 3),
             "betas": p["betas"][0][None], "global_orient": p["global_orient"][idx][None], "body_pose": p["body_pose"][idx][None],
             "transl": transl[None], "alpha": alpha.reshape(1, *shape), "bg_color": bg.reshape(1, *shape, 3),
             "idx": torch.tensor([idx]),   # host tensor: the trainer reads it as a Python int (renderer.idx) without a device sync
-            "near": near[None], "far": far[None],
+            "near": near.reshape(1, *shape), "far": far.reshape(1, *shape),
         }
+        if out is not None:
+            # SMPL parameters of the frame into the caller's tensors too; what was written in place is returned as the
+            # caller's own tensor objects, so that `batch is out`-style identity checks downstream see no copy to make
+            for k in ("betas", "global_orient", "body_pose", "transl"):
+                t = out.get(k)
+                if torch.is_tensor(t) and t.is_cuda and t.shape == res[k].shape:
+                    t.copy_(res[k], non_blocking=True)
+                    res[k] = t
+            for k in ("rgb", "rays_o", "rays_d", "alpha", "bg_color", "near", "far"):
+                t = out.get(k)
+                if torch.is_tensor(t) and t.data_ptr() == res[k].data_ptr() and t.shape == res[k].shape:
+                    res[k] = t
+        return res

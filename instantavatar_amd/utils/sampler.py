@@ -116,14 +116,16 @@ class PatchSampler:
         P = self.patch_size
         if draws is None:
             draws = torch.rand(1 + 2 * self.n, device=dev, generator=generator)
-        coin, rest = draws[0], draws[1:]
+        draws = draws.float().contiguous()
         o = P // 2
-        # both branches are evaluated on the device and blended by the coin: no host read of a random number
-        r_m, c_m, count = nonzero_select(self._candidates(mask2d), (o, H - o, o, W - o), rest[:self.n], without_replacement=True)
-        r_u = torch.clamp((rest[:self.n].float() * float(H - P)).floor(), max=H - P - 1).to(torch.int32)   # np.random.randint(0, H - P)
-        c_u = torch.clamp((rest[self.n:2 * self.n].float() * float(W - P)).floor(), max=W - P - 1).to(torch.int32)
-        use_mask = coin < self.p
-        return torch.where(use_mask, r_m, r_u), torch.where(use_mask, c_m, c_u)
+        # both branches are evaluated on the device and blended by the coin: no host read of a random number.  The
+        # uniform branch (np.random.randint(0, H - P) = floor(u * (H - P))) and the blend are one small kernel.
+        r_m, c_m, count = nonzero_select(self._candidates(mask2d), (o, H - o, o, W - o), draws[1:1 + self.n], without_replacement=True)
+        rows = torch.empty(self.n, dtype=torch.int32, device=dev)
+        cols = torch.empty(self.n, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().ia_patch_corners(_lib.ptr(r_m), _lib.ptr(c_m), _lib.ptr(draws), self.n, H, W, P, float(self.p),
+                                               _lib.ptr(rows), _lib.ptr(cols), _lib.stream()), "ia_patch_corners")
+        return rows, cols
 
     def sample(self, mask, *args, draws=None, generator=None):
         mask2d = mask.reshape(mask.shape[0], mask.shape[1])

@@ -142,6 +142,17 @@ def test_device_batch_equals_reference_getitem(kind):
     for k in ("betas", "global_orient", "body_pose", "transl"):
         assert np.array_equal(got[k][0].cpu().numpy(), ref[k]), k
     assert int(got["idx"][0]) == idx
+    # out=: the next batch is written into the tensors of an earlier one (the static inputs of a captured training step)
+    keep = {k: (v.data_ptr() if torch.is_tensor(v) and v.is_cuda else None) for k, v in got.items()}
+    idx2 = 1
+    ref2 = do.getitem_train(imgs[idx2], masks[idx2], ro, rd, smpl, idx2, fn, bg_full)
+    again = frames.batch(idx2, draws=torch.as_tensor(draws, device=DEV),
+                         bg_draws=torch.as_tensor(np.ascontiguousarray(ref2["bg_color"]).reshape(-1, 3), device=DEV), out=got)
+    for k in ("rgb", "alpha", "bg_color", "near", "far", "rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl"):
+        assert again[k] is got[k] and again[k].data_ptr() == keep[k], k        # written in place, same tensor objects
+    for k in ("rgb", "alpha", "bg_color", "near", "far", "betas", "global_orient", "body_pose", "transl"):
+        assert np.array_equal(again[k][0].cpu().numpy(), np.asarray(ref2[k], np.float32)), k
+    assert int(again["idx"][0]) == idx2
 
 
 def test_device_batches_feed_a_training_step():

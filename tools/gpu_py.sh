@@ -1,4 +1,4 @@
 #!/bin/bash
-# run a python dev tool on the GPU box:  tools/gpu_py.sh tools/<script>.py [args]
+# usage: tools/gpu_py.sh <shell command line>   (runs it from the repo root on the GPU box, output in gpurun_out/py_tool.log)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python "$@" 2>&1 | tee gpurun_out/py_tool.log | tail -60
+bash -c "$*" > gpurun_out/py_tool.log 2>&1; tail -30 gpurun_out/py_tool.log | cut -c1-400
