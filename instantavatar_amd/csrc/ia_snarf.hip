@@ -283,6 +283,9 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
   const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
   const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
+#ifndef IA_FETCH_SKIP_OUTSIDE
+#define IA_FETCH_SKIP_OUTSIDE 1
+#endif
 #ifndef IA_FETCH_GROUP
 #define IA_FETCH_GROUP 2  // corners whose loads are in flight together (four round trips, 24 data VGPRs): with 32 points per
 #endif                    // workgroup this buys a fifth wave per SIMD (r02: 376 -> 391 frames/s; group 4 with 32 points: 325)
@@ -291,6 +294,16 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   f2 acc[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) acc[c] = (f2){0.f, 0.f};
+#if IA_FETCH_SKIP_OUTSIDE
+  // A fetch whose eight corners all lie outside the grid is zero (every weight is 0 and fma(v, 0, +0) = +0 for the finite
+  // table values): the lane sits the loads out -- the L1 looks up active lanes only.  Diverging solves jump far away:
+  // their second fetch is often of this kind.
+  if (!((bx0 || bx1) && (by0 || by1) && (bz0 || bz1))) {
+#pragma unroll
+    for (int c = 0; c < 12; c++) out[c] = 0.f;
+    return;
+  }
+#endif
 #pragma unroll
   for (int k0 = 0; k0 < 8; k0 += IA_FETCH_GROUP) {
     float4 ra[IA_FETCH_GROUP], rb[IA_FETCH_GROUP], rc[IA_FETCH_GROUP];
