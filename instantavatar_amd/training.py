@@ -493,6 +493,8 @@ class GraphedTrainStep:
     def __call__(self, batch=None):
         m, r = self.model, self.model.renderer
         if batch is None:
+            if self.inputs is None:
+                raise ValueError("GraphedTrainStep(): no batch given and no static inputs yet (pass the first batches explicitly)")
             batch = self.inputs
         eager = (not self.enabled) or m.global_step % self._update_period() == 0
         if not eager and torch.is_tensor(batch.get("idx")) and batch["idx"].is_cuda:
