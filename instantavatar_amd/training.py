@@ -253,20 +253,42 @@ class NeRFLoss(torch.nn.Module):
 
 
 class NGPLoss(NeRFLoss):
-    """instant_avatar/utils/loss.py:8-50: NeRFLoss + (on patch batches [1, n_patch, P, P, 3]) the depth-variance
-    regulariser; the LPIPS term needs the pretrained VGG weights of third_parties/lpips, which cannot be fetched
-    offline -- `w_lpips > 0` raises instead of silently training without it."""
+    """instant_avatar/utils/loss.py:8-50: NeRFLoss + (on patch batches [1, n_patch, P, P, 3]) the LPIPS term and the
+    depth-variance regulariser.  LPIPS (`utils.lpips.LPIPS`, VGG-16, v0.1) needs two weight files that cannot be
+    fetched offline -- `opt.lpips_lin_weights` (third_parties/lpips/weights/v0.1/vgg.pth of a reference checkout) and
+    `opt.lpips_vgg_weights` (torchvision's vgg16 feature weights saved with torch.save) -- or a ready module passed as
+    `lpips=`; `w_lpips > 0` without them raises instead of silently training against random features."""
 
-    def __init__(self, opt=None, fused=True):
+    def __init__(self, opt=None, fused=True, lpips=None):
         super().__init__(opt, fused=fused)
         self.w_lpips = _opt.get(opt, "w_lpips", 0)
         self.w_depth_reg = _opt.get(opt, "w_depth_reg", 0)
+        self.lpips = None
         if self.w_lpips > 0:
-            raise NotImplementedError("NGPLoss: w_lpips > 0 needs the pretrained LPIPS/VGG weights (not available offline); set w_lpips=0")
+            if lpips is None:
+                lin, vgg = _opt.get(opt, "lpips_lin_weights", None), _opt.get(opt, "lpips_vgg_weights", None)
+                if not (lin and vgg):
+                    raise NotImplementedError(
+                        "NGPLoss: w_lpips > 0 needs the pretrained LPIPS weights, which are not available offline: give "
+                        "opt.lpips_lin_weights (third_parties/lpips/weights/v0.1/vgg.pth) and opt.lpips_vgg_weights "
+                        "(torch.save(torchvision.models.vgg16(weights='DEFAULT').features.state_dict(), path)), pass a "
+                        "loaded utils.lpips.LPIPS as lpips=, or set w_lpips=0")
+                from .utils.lpips import LPIPS
+                lpips = LPIPS().load_lin_weights(lin).load_trunk_weights(vgg)
+            self.lpips = lpips
+            for p in self.lpips.parameters():
+                p.requires_grad = False                                            # loss.py:12
 
     def forward(self, predicts, targets):
         losses = super().forward(predicts, targets)
-        if self.w_depth_reg > 0 and predicts["rgb_coarse"].dim() == 5:       # loss.py:33-39
+        patches = predicts["rgb_coarse"].dim() == 5
+        if self.w_lpips > 0 and patches:                                           # loss.py:28-32 (BGR order, NCHW, clip)
+            pr = predicts["rgb_coarse"][..., [2, 1, 0]].flatten(0, 1).permute(0, 3, 1, 2).clip(max=1)
+            tg = targets["rgb"][..., [2, 1, 0]].flatten(0, 1).permute(0, 3, 1, 2)
+            lp = self.lpips.to(pr.device)(pr.float(), tg.float()).sum()
+            losses["loss_lpips"] = lp
+            losses["loss"] = losses["loss"] + self.w_lpips * lp
+        if self.w_depth_reg > 0 and patches:                                       # loss.py:33-39
             a, d = predicts["alpha_coarse"], predicts["depth_coarse"]
             alpha_sum = a.sum(dim=(-1, -2))
             depth_avg = (d * a).sum(dim=(-1, -2)) / (alpha_sum + 1e-3)

@@ -496,3 +496,69 @@ def test_mesh_signed_distance_oracle_against_analytic_shapes(oracle):
     out = oracle.density_grid_smpl_init(v, f, np.zeros((16, 16, 16), np.float32), G=16)
     assert out["density_field"].any() and np.isinf(out["density_cached"][out["density_field"]]).all()
     assert (out["density_cached"][~out["density_field"]] == 0).all()
+
+
+def _lpips_formula_weights(shape, salt):
+    """tests/golden/make_lpips_golden.py: the deterministic stand-in trunk weights"""
+    n = int(np.prod(shape))
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(i * 12.9898 + salt * 78.233) * np.sqrt(2.0 / fan_in) * 1.7
+    if len(shape) == 1:
+        v = 0.05 * np.sin(i * 0.7 + salt)
+    import torch
+    return torch.as_tensor(v.reshape(shape), dtype=torch.float32)
+
+
+def test_lpips_module_matches_reference_golden():
+    """utils.lpips.LPIPS against outputs of the REFERENCE's third_parties/lpips module (net="vgg", v0.1, its pretrained
+    lin layers; trunk weights from a closed formula because torchvision's are not available offline): the state-dict
+    layout is the reference's and the per-layer and total distances agree."""
+    import torch
+    from instantavatar_amd.utils.lpips import LPIPS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_golden.npz"))
+    m = LPIPS()
+    m.load_lin_weights({k.replace("__", "."): torch.as_tensor(g[k]) for k in g.files if k.startswith("lin")})
+    names = sorted(n for n, _ in m.net.named_parameters())
+    assert names == [str(s) for s in g["param_order"]]                 # same parameter names as the reference's trunk wrapper
+    with torch.no_grad():
+        for salt, name in enumerate(names):
+            p = dict(m.net.named_parameters())[name]
+            p.copy_(_lpips_formula_weights(tuple(p.shape), salt))
+        val, per = m(torch.as_tensor(g["x"]), torch.as_tensor(g["y"]), per_layer=True)
+    assert np.allclose(val.numpy(), g["val"], rtol=2e-5, atol=1e-7), (val.reshape(-1), g["val"].reshape(-1))
+    for k in range(5):
+        assert np.allclose(per[k].numpy(), g["per"][k], rtol=2e-5, atol=1e-8), k
+    # identical images -> 0; the loader of a torchvision `features` state dict maps onto the sliced layout
+    assert float(m(torch.as_tensor(g["x"]), torch.as_tensor(g["x"])).abs().max()) == 0.0
+    tv_sd = {n.split(".", 1)[1]: p.detach().clone() for n, p in m.net.named_parameters()}
+    m2 = LPIPS().load_lin_weights({k.replace("__", "."): torch.as_tensor(g[k]) for k in g.files if k.startswith("lin")}).load_trunk_weights(tv_sd)
+    with torch.no_grad():
+        assert torch.equal(m2(torch.as_tensor(g["x"]), torch.as_tensor(g["y"])), val)
+    assert m2.weights_loaded == {"trunk": True, "lin": True}
+
+
+def test_ngp_loss_lpips_term_and_missing_weights():
+    """NGPLoss with w_lpips > 0: refuses to run without weight files, and with a loaded module adds
+    w_lpips * sum(LPIPS(pred[BGR], target[BGR])) on patch batches (loss.py:28-32)."""
+    import torch
+    from instantavatar_amd.training import NGPLoss
+    from instantavatar_amd.utils.lpips import LPIPS
+    with pytest.raises(NotImplementedError, match="lpips_lin_weights"):
+        NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.01))
+    torch.manual_seed(0)
+    lp = LPIPS()
+    loss = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.01), fused=False, lpips=lp)
+    base = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1), fused=False)
+    pred = {"rgb_coarse": torch.rand(1, 2, 32, 32, 3, requires_grad=True), "alpha_coarse": torch.rand(1, 2, 32, 32),
+            "depth_coarse": torch.rand(1, 2, 32, 32), "weight_coarse": torch.rand(1, 2, 32, 32, 8)}
+    tgt = {"rgb": torch.rand(1, 2, 32, 32, 3), "alpha": torch.rand(1, 2, 32, 32)}
+    a, b = loss(pred, tgt), base(pred, tgt)
+    want = lp(pred["rgb_coarse"][0][..., [2, 1, 0]].permute(0, 3, 1, 2).clip(max=1), tgt["rgb"][0][..., [2, 1, 0]].permute(0, 3, 1, 2)).sum()
+    assert torch.allclose(a["loss_lpips"], want) and torch.allclose(a["loss"], b["loss"] + 0.01 * want)
+    a["loss"].backward()
+    assert pred["rgb_coarse"].grad is not None and torch.isfinite(pred["rgb_coarse"].grad).all()
+    assert all(not p.requires_grad for p in lp.parameters())
+    # flat (non-patch) batches skip the term, as the reference does
+    flat = {k: v.reshape(1, -1, *v.shape[4:]) for k, v in pred.items()}
+    assert "loss_lpips" not in loss(flat, {k: v.reshape(1, -1, *v.shape[4:]) for k, v in tgt.items()})
