@@ -681,6 +681,9 @@ def main():
             u = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph,
                                  sampler="uniform")
             result["train"]["uniform_rays"] = {k: u[k] for k in ("it_per_sec", "rays_per_sec", "mse_last", "samples_candidates_last_step", "launch_mode")}
+            hj, hsrc = _profile_json("r02_pmc_hgbwd.json")
+            if hj is not None:   # the training step's dominant kernel against the measured atomic-request ceiling (committed PMC pass)
+                result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc)
         except Exception as e:  # the headline line must survive a failure of the secondary workload
             result["train"] = {"error": repr(e)[:300]}
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:

@@ -1165,7 +1165,10 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd(const float *__restrict__ 
     float xn[3] = {0.f, 0.f, 0.f};
     if (live) normalise(F, x, (size_t)i, xn);
     float gx[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
+#ifndef IA_HGB_LEVEL_UNROLL
+#define IA_HGB_LEVEL_UNROLL 1
+#endif
+#pragma unroll IA_HGB_LEVEL_UNROLL
     for (int l = l_begin; l < l_end; l++) {
       const float scale = F.lv.scale[l];
       const uint32_t res = F.lv.res[l], size = F.lv.size[l];
