@@ -300,8 +300,11 @@ __global__ void k_patch_corners(const int32_t *__restrict__ row_mask, const int3
   // floor(u * (H - P)) clamped to H - P - 1: np.random.randint(0, H - P) (sampler.py:72)
   const float fr = fminf(floorf(draws[1 + i] * (float)(H - P)), (float)(H - P - 1));
   const float fc = fminf(floorf(draws[1 + n + i] * (float)(W - P)), (float)(W - P - 1));
-  rows[i] = use_mask ? row_mask[i] : (int32_t)fr;
-  cols[i] = use_mask ? col_mask[i] : (int32_t)fc;
+  // an empty (cropped) mask gives -1 from ia_nonzero_select -- np.random.choice raises there; here the patch falls back to
+  // the uniform branch instead of handing a negative pixel index to the gather
+  const bool from_mask = use_mask && row_mask[i] >= 0 && col_mask[i] >= 0;
+  rows[i] = from_mask ? row_mask[i] : (int32_t)fr;
+  cols[i] = from_mask ? col_mask[i] : (int32_t)fc;
 }
 
 extern "C" int ia_patch_corners(const int32_t *row_mask, const int32_t *col_mask, const float *draws, int n, int H, int W,

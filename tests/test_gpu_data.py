@@ -184,3 +184,16 @@ def test_device_batches_feed_a_training_step():
         first = v if first is None else first
         last = v
     assert np.isfinite(last) and last < first, (first, last)
+
+
+def test_patch_sampler_empty_mask_falls_back_to_uniform_corners():
+    """np.random.choice raises on an empty mask; the device sampler must not hand a negative pixel index to the gather:
+    the corners then come from the uniform branch (always inside the image)."""
+    H = W = 96
+    m = torch.zeros((H, W), device=DEV)
+    s = PatchSampler(num_patch=4, patch_size=32, ratio_mask=1)
+    draws = torch.as_tensor(np.r_[0.0, np.linspace(0.05, 0.95, 8)].astype(np.float32), device=DEV)
+    rows, cols = s.sample_corners(m, draws=draws)
+    r, c = rows.cpu().numpy(), cols.cpu().numpy()
+    assert (r >= 0).all() and (r < H - 32).all() and (c >= 0).all() and (c < W - 32).all()
+    assert np.array_equal(r, np.floor(np.linspace(0.05, 0.95, 8)[:4].astype(np.float32) * np.float32(H - 32)).astype(np.int32))
