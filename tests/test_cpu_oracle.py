@@ -562,3 +562,21 @@ def test_ngp_loss_lpips_term_and_missing_weights():
     # flat (non-patch) batches skip the term, as the reference does
     flat = {k: v.reshape(1, -1, *v.shape[4:]) for k, v in pred.items()}
     assert "loss_lpips" not in loss(flat, {k: v.reshape(1, -1, *v.shape[4:]) for k, v in tgt.items()})
+
+
+def test_implicit_differentiation_matches_reference_autograd_golden(oracle, small_world):
+    """Row a7 pinned to the REFERENCE: oracle.implicit_diff_grad (the closed form the HIP kernel k_implicit_bwd is tested
+    against) equals the gradient w.r.t. tfs that the reference's own autograd produces for the training branch of
+    ForwardDeformer.forward (deformer_torch.py:50-67) -- golden generated by tests/golden/make_implicit_diff_golden.py, which
+    imports the reference module on the CPU (CUDA extensions and KNN stubbed: they are not on the differentiated path) and
+    feeds it the oracle's roots / J_inv / voxel weights."""
+    body, init, fp, world = small_world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "implicit_diff_golden.npz"))
+    assert np.array_equal(g["tfs"], world["tfs"])                       # same world as the generator built
+    got = oracle.implicit_diff_grad(init, g["xc"], g["J_inv"], g["valid"], g["r"])
+    ref = g["grad_tfs"]
+    assert ref.shape == (24, 4, 4) and np.abs(ref).max() > 1.0 and np.abs(ref[:, 3]).max() == 0
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max(), float(np.abs(got - ref).max())
+    # and the roots the golden was built on are the oracle's Broyden roots of this world
+    x, Jinv, valid = oracle.broyden(g["xd"], world["voxel_J"], world["tfs"], init, syn.INIT_BONES)
+    assert np.array_equal(x, g["xc"]) and np.array_equal(oracle.filter_dup(x, valid).astype(bool), g["valid"])
