@@ -479,6 +479,39 @@ void orc_field_fwd(const orc_field *f, const float *x, long V, float *rgb,
   }
 }
 
+/* The same field cut at the boundary of the two tcnn modules of ngp.py, for the harness that runs the      */
+/* REFERENCE's Python on the CPU with tcnn stubbed (tests/golden/make_pipeline_golden.py):                 */
+/* orc_tcnn_encoder = self.encoder(x) on UNIT coordinates (ngp.py:78; x already normalised and clamped     */
+/* by :75-77) -> the 16 half outputs as floats; orc_tcnn_color = self.color_net(x[..., 1:]) (ngp.py:81).   */
+/* Same arithmetic, step for step, as orc_field_fwd.                                                        */
+void orc_tcnn_encoder(const orc_field *f, const float *xn, long V, float *out16) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < V; i++) {
+    uint16_t feat[32] = {0}, h1[64], o16[16];
+    orc_hash_encode1(&f->hash, f->table, xn + i * 3, feat);
+    orc_dense(f->sig_w1, 64, 2 * f->hash.n_levels, feat, 1, h1);
+    orc_dense(f->sig_w2, 16, 64, h1, 0, o16);
+    for (int k = 0; k < 16; k++) out16[i * 16 + k] = h2f(o16[k]);
+  }
+}
+
+void orc_tcnn_color(const orc_field *f, const float *in15, long V, float *rgb) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < V; i++) {
+    uint16_t cin[16], c1[64], c2[64];
+    for (int k = 0; k < 15; k++) cin[k] = f2h(in15[i * 15 + k]);  /* exact: the inputs are half values */
+    cin[15] = f2h(1.0f);
+    orc_dense(f->col_w1, 64, 16, cin, 1, c1);
+    orc_dense(f->col_w2, 64, 64, c1, 1, c2);
+    for (int o = 0; o < 3; o++) {
+      float acc = 0.f;
+      for (int k = 0; k < 64; k++) acc += h2f(f->col_w3[o * 64 + k]) * h2f(c2[k]);
+      float s = 1.0f / (1.0f + expf(-acc));
+      rgb[i * 3 + o] = h2f(f2h(s));
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------ */
 /* a6 deform_test tail (snarf_deformer.py:130-141): nan_to_num(0,0,0) on the  */
 /* valid candidates, max over candidates (first max wins), gather rgb.        */

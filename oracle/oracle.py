@@ -262,6 +262,22 @@ def field_fwd(field, x):
     return rgb, sig
 
 
+def tcnn_encoder(field, xn):
+    """ngp.py:78 `self.encoder(x)` on unit coordinates -> [n,16] (float values of the half outputs)."""
+    xn = _f32(xn).reshape(-1, 3)
+    out = np.empty((len(xn), 16), np.float32)
+    lib().orc_tcnn_encoder(C.byref(field), _p(xn), C.c_long(len(xn)), _p(out))
+    return out
+
+
+def tcnn_color(field, in15):
+    """ngp.py:81 `self.color_net(x[..., 1:])` -> [n,3]."""
+    in15 = _f32(in15).reshape(-1, 15)
+    out = np.empty((len(in15), 3), np.float32)
+    lib().orc_tcnn_color(C.byref(field), _p(in15), C.c_long(len(in15)), _p(out))
+    return out
+
+
 def hashgrid(field, x):
     x = _f32(x).reshape(-1, 3)
     feat = np.zeros((len(x), 32), np.uint16)

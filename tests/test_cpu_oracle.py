@@ -580,3 +580,64 @@ def test_implicit_differentiation_matches_reference_autograd_golden(oracle, smal
     # and the roots the golden was built on are the oracle's Broyden roots of this world
     x, Jinv, valid = oracle.broyden(g["xd"], world["voxel_J"], world["tfs"], init, syn.INIT_BONES)
     assert np.array_equal(x, g["xc"]) and np.array_equal(oracle.filter_dup(x, valid).astype(bool), g["valid"])
+
+
+def test_oracle_pipeline_matches_reference_python_golden(oracle, small_world):
+    """The oracle's restatement of the reference's Python glue against the REFERENCE'S PYTHON EXECUTING
+    (tests/golden/make_pipeline_golden.py + ref_cpu_harness.py: instant_avatar.* imported on the CPU, its native
+    extensions / tcnn replaced by adapters around the oracle's C functions, its random draws taken from seeded numpy
+    streams re-created here):
+      (A) DNeRFModel.render_image_fast: SMPL / LBS -> tfs, w2s; DensityGrid.initialize; Raymarcher.render_test
+      (B) DNeRFModel.update_density_grid x 2 (steps 0 and 500: EMA, post-processing, valid switch, regulariser)
+      (C) DNeRFModel.forward in training mode: Raymarcher.render_train with jitter and sigma noise
+      (D) ForwardDeformer.switch_to_explicit's skinning-weight voxels (KNN + smoothing in torch)."""
+    body, init, fp, _ = small_world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.npz"))
+    seed_init, seed_upd, seed_train = (int(v) for v in g["seeds"])
+    res, frame = int(g["res"]), int(g["frame"])
+    poses, tr = syn.procedural_pose_track(8)
+    world = oracle.make_world(body, init, fp, np.zeros(10, np.float32), poses[frame, 3:], poses[frame, :3], tr[frame], syn.INIT_BONES)
+    # (D) and the per-frame transforms (reference smplx + lbs.py + torch.inverse vs the oracle's numpy chain)
+    assert float(g["D_lbs_max_abs_diff_to_oracle"]) < 1e-6
+    assert np.abs(init["lbs_voxel"].reshape(24, -1)[:, ::97] - g["D_lbs_sample"]).max() < 1e-6
+    assert np.abs(world["tfs"] - g["tfs"]).max() < 2e-6 and np.abs(world["w2s"] - g["w2s"]).max() < 2e-6
+    assert np.abs(init["bbox"] - g["bbox"]).max() < 1e-6
+    # (A)
+    rs = np.random.RandomState(seed_init)
+    jitter = np.stack([rs.rand(64, 64, 64, 3).astype(np.float32).reshape(-1, 3) for _ in range(5)])
+    ro, rd = syn.make_camera_rays(res)
+    out = oracle.render_image_fast(world, ro, rd, jitter)
+    occ_ref = np.unpackbits(g["A_occ"])[:64 ** 3].reshape(64, 64, 64)
+    assert np.abs(out["aabb"] - g["A_aabb"]).max() < 1e-5
+    assert (out["occ"].astype(np.uint8) != occ_ref).mean() < 2e-4          # threshold / component decisions on ~1e-6 differences
+    d_rgb = np.abs(out["rgb"].reshape(res, res, 3) - g["A_rgb"]).max(-1)
+    d_alpha = np.abs(out["alpha"].reshape(res, res) - g["A_alpha"])
+    assert (d_rgb > 1e-4).mean() < 5e-3 and (d_alpha > 1e-4).mean() < 5e-3, ((d_rgb > 1e-4).mean(), d_rgb.max())
+    assert (out["counter"].reshape(res, res) != g["A_counter"]).mean() < 5e-3
+    assert np.median(d_rgb) < 1e-6 and (g["A_alpha"] > 0.5).mean() > 0.03
+    hit = g["A_alpha"] > 0.5
+    assert np.abs(out["depth"].reshape(res, res) - g["A_depth"])[hit].max() < 2e-3
+    # (B)
+    cached, field = np.zeros((64, 64, 64), np.float32), np.zeros((64, 64, 64), bool)
+    for k, step in enumerate((0, 500)):
+        jit = np.random.RandomState(seed_upd + k).rand(64, 64, 64, 3).astype(np.float32)
+        u = oracle.density_grid_update(world, cached, field, jit, step)
+        reg = oracle.update_density_grid_reg(u["density"], u["valid"], step)
+        ref_field = np.unpackbits(g["B%d_field" % k])[:64 ** 3].reshape(64, 64, 64).astype(bool)
+        assert (u["density_field"] != ref_field).mean() < 2e-4, k
+        assert np.abs(u["density_cached"].reshape(-1)[::61] - g["B%d_cached_sample" % k]).max() < 1e-3 * max(1.0, float(g["B%d_cached_sample" % k].max()))
+        assert abs(float(u["density_cached"].astype(np.float64).sum()) - float(g["B%d_cached_sum" % k])) < 1e-4 * float(g["B%d_cached_sum" % k])
+        assert abs(float(reg) - float(g["B%d_reg" % k])) <= 1e-4 * abs(float(g["B%d_reg" % k])) + 1e-9, (k, float(reg), float(g["B%d_reg" % k]))
+        cached, field = u["density_cached"], ref_field          # continue from the reference's state
+    # (C)
+    sel = g["C_sel"]
+    o, d, near, far = oracle.transform_rays_w2s(ro[sel], rd[sel], world["w2s"])
+    rs = np.random.RandomState(seed_train)
+    n = len(sel)
+    jit, noise = rs.rand(n, 256).astype(np.float32), rs.randn(n, 256).astype(np.float32)
+    c = oracle.render_train(o, d, near, far, field, oracle.TRAIN_AABB, lambda p: oracle.deform_query(p, world, eval_mode=False), jit,
+                            bg=g["C_bg"], noise=noise)
+    for key, ref in (("rgb", g["C_rgb"]), ("alpha", g["C_alpha"]), ("depth", g["C_depth"]), ("weights", g["C_weights"])):
+        dd = np.abs(c[key].reshape(ref.shape) - ref)
+        assert (dd > 1e-4).mean() < 5e-3 and np.median(dd) < 1e-6, (key, (dd > 1e-4).mean(), dd.max())
+    assert g["C_alpha"].max() > 0.5
