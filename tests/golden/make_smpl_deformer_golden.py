@@ -1,0 +1,55 @@
+"""Generates tests/golden/smpl_deformer_golden.npz: the REFERENCE's SMPLDeformer (instant_avatar/deformers/smpl_deformer.py)
+executing on the CPU through tests/golden/ref_cpu_harness.py -- initialize, prepare_deformer, deform, deform_test and
+deform_train on seeded points around the posed body (its KNN is the oracle's, pinned to the reference's knn_cpu.cpp; the
+field is the oracle's, cut at the tcnn module boundary).   Run from the repo root:  python tests/golden/make_smpl_deformer_golden.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+OUT = os.path.join(HERE, "smpl_deformer_golden.npz")
+FRAME, SEED, N = 2, 11, 4000
+
+
+def main():
+    import ref_cpu_harness as H
+    from instantavatar_amd import synthetic as syn
+    from oracle import oracle
+    body = syn.make_body()
+    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
+    poses, tr = syn.procedural_pose_track(8)
+    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[FRAME, 3:], poses[FRAME, :3], tr[FRAME])
+    fp = syn.make_field(init["cano_joints"], prep["bbox"])          # field over the SMPLDeformer's (DA-pose) canonical box
+    field, keep = oracle.make_field(fp)
+    R = H.install(oracle, {"field": field})
+    model = H.build_reference_model(R, body, fp, resolution=32)      # (sets up the SMPL stand-in; the net is reused)
+    import instant_avatar.deformers.smpl_deformer as sd
+    sd.SMPL = R.snarf.SMPL
+    dfm = sd.SMPLDeformer("", "neutral", threshold=0.05, k=1)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    params = {"betas": torch.zeros(1, 10), "body_pose": t(poses[FRAME, 3:])[None], "global_orient": t(poses[FRAME, :3])[None],
+              "transl": t(tr[FRAME])[None]}
+    dfm.prepare_deformer(params)
+    rs = np.random.RandomState(SEED)
+    v = dfm.vertices[0].detach().numpy()
+    pts = (v[rs.randint(0, len(v), N)] + rs.randn(N, 3).astype(np.float32) * 0.03).astype(np.float32)
+    net = model.net_coarse
+    with torch.no_grad():
+        cano, valid = dfm.deform(t(pts))
+        rgb_t, sig_t = dfm(t(pts), net, eval_mode=True)
+        rgb_r, sig_r = dfm(t(pts), net, eval_mode=False)
+    print("valid %.3f; sigma test range [%.2f, %.2f]" % (float(valid.float().mean()), float(sig_t.min()), float(sig_t.max())))
+    np.savez_compressed(OUT, frame=np.int32(FRAME), pts=pts, cano=cano.numpy(), valid=valid.numpy(), rgb_test=rgb_t.numpy(), sigma_test=sig_t.numpy(),
+                        rgb_train=rgb_r.numpy(), sigma_train=sig_r.numpy(), T_inv_sample=dfm.T_inv[0].detach().numpy()[::53],
+                        verts_sample=v[::53], w2s=dfm.w2s[0].detach().numpy(), bbox=dfm.bbox.detach().numpy(),
+                        bbox_deformed=dfm.get_bbox_deformed().detach().numpy())
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

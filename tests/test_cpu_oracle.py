@@ -641,3 +641,34 @@ def test_oracle_pipeline_matches_reference_python_golden(oracle, small_world):
         dd = np.abs(c[key].reshape(ref.shape) - ref)
         assert (dd > 1e-4).mean() < 5e-3 and np.median(dd) < 1e-6, (key, (dd > 1e-4).mean(), dd.max())
     assert g["C_alpha"].max() > 0.5
+
+
+def test_smpl_deformer_oracle_matches_reference_python_golden(oracle, small_world):
+    """f2: the oracle's SMPLDeformer restatement (smpl_deformer_prepare / smpl_nn_deform / smpl_deform_query) against
+    the REFERENCE's smpl_deformer.py executing on the CPU (tests/golden/make_smpl_deformer_golden.py): per-vertex inverse
+    transforms, posed vertices, boxes, nearest-vertex deformation, test- and train-mode field queries."""
+    body, init, fp0, _ = small_world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "smpl_deformer_golden.npz"))
+    frame = int(g["frame"])
+    poses, tr = syn.procedural_pose_track(8)
+    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[frame, 3:], poses[frame, :3], tr[frame])
+    assert np.abs(prep["T_inv"][::53] - g["T_inv_sample"]).max() < 5e-6
+    assert np.abs(prep["vertices"][::53] - g["verts_sample"]).max() < 2e-6
+    assert np.abs(prep["w2s"] - g["w2s"]).max() < 2e-6 and np.abs(prep["bbox"] - g["bbox"]).max() < 2e-6
+    assert np.abs(oracle.get_bbox_from_smpl(prep["vertices"]) - g["bbox_deformed"]).max() < 2e-6
+    cano, valid, _ = oracle.smpl_nn_deform(g["pts"], prep["vertices"], prep["T_inv"], 0.05)
+    # a point within 1e-6 of the 5 cm threshold or of a tie between two vertices may flip with the 1e-6 vertex differences
+    assert (valid != g["valid"]).mean() < 2e-3
+    both = valid & g["valid"]
+    d = np.abs(cano - g["cano"])[both].max(-1)
+    assert np.median(d) < 2e-6 and (d > 1e-4).mean() < 2e-3, (np.median(d), (d > 1e-4).mean())
+    field, keep = oracle.make_field(syn.make_field(init["cano_joints"], prep["bbox"]))
+    for mode, kr, ks in ((True, "rgb_test", "sigma_test"), (False, "rgb_train", "sigma_train")):
+        rgb, sigma = oracle.smpl_deform_query(g["pts"], prep, field, eval_mode=mode)
+        same = (valid == g["valid"])
+        ds, dr = np.abs(sigma - g[ks])[same], np.abs(rgb - g[kr])[same].max(-1)
+        # the field is steep (|sigma| up to 120): compare where the canonical points agree to 1e-6
+        tight = same.copy(); tight[both] &= d < 1e-6
+        assert (np.abs(sigma - g[ks])[tight] > 2e-2 * (1 + np.abs(g[ks][tight]))).mean() < 5e-3, mode
+        assert (np.abs(rgb - g[kr])[tight].max(-1) > 2e-3).mean() < 5e-3, mode
+        assert np.array_equal(sigma[~valid & ~g["valid"]], g[ks][~valid & ~g["valid"]])      # fills: 0 (test) / -1e5 (train)
