@@ -50,14 +50,17 @@ class EdgeSampler:
         self.num_rand = num_sample - self.num_mask - self.num_edge
 
     def edge_band(self, mask2d):
-        """cv2.dilate(mask, ones(k,k)) - cv2.erode(mask, ones(k,k))  (:25-28)"""
+        """cv2.dilate(mask, ones(k,k)) - cv2.erode(mask, ones(k,k))  (:25-28) AS THE REFERENCE RUNS IT: `sample` flattens the
+        mask first (:23), and OpenCV takes a 1-D array of length N as an N x 1 image -- the k x k box sees a single column,
+        so the band is computed along the flattened (row-major) pixel index, window [-k//2, k-1-k//2], running across row
+        ends.  The same kernel, called on an (H*W) x 1 image.  Returned in the mask's 2-D shape."""
         _lib.require_cuda(mask2d)
         H, W = mask2d.shape
         L = _lib.lib()
         m = mask2d.float().contiguous()
         edge = torch.empty_like(m)
-        ws = _ws(L.ia_mask_edge_workspace_bytes(H, W), m.device)
-        _lib.check(L.ia_mask_edge(_lib.ptr(m), H, W, self.kernel_size, _lib.ptr(edge), _lib.ptr(ws), ws.numel(), _lib.stream()),
+        ws = _ws(L.ia_mask_edge_workspace_bytes(H * W, 1), m.device)
+        _lib.check(L.ia_mask_edge(_lib.ptr(m), H * W, 1, self.kernel_size, _lib.ptr(edge), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "ia_mask_edge")
         return edge
 

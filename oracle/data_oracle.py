@@ -49,7 +49,11 @@ def edge_sampler_indices(mask2d, draws, num_sample=4096, ratio_mask=0.6, ratio_e
     """EdgeSampler.sample's index computation (sampler.py:22-41) with explicit uniform draws [num_sample]."""
     num_mask, num_edge = int(num_sample * ratio_mask), int(num_sample * ratio_edge)
     mask = np.asarray(mask2d, np.float32).reshape(-1)
-    mask_e = (dilate(mask2d, kernel_size) - erode(mask2d, kernel_size)).reshape(-1)
+    # sampler.py:23-27: the mask is flattened BEFORE cv2.erode / cv2.dilate, and OpenCV takes a 1-D array of length N as
+    # an N x 1 image: the k x k box only ever sees one column, i.e. the band is computed along the flattened (row-major)
+    # index, window [-k//2, k-1-k//2], running across row ends.  Restated literally.
+    col = mask.reshape(-1, 1)
+    mask_e = (dilate(col, kernel_size) - erode(col, kernel_size)).reshape(-1)
     mask_loc, = np.where(mask)
     edge_loc, = np.where(mask_e)
     u = np.asarray(draws, np.float32)

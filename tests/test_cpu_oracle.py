@@ -3,6 +3,7 @@ and that the C-ABI library loads and exports every declared symbol."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -437,7 +438,8 @@ def test_data_oracle_erode_dilate_match_scipy_and_sampler_semantics():
         assert np.array_equal(do.erode(m, k), e) and np.array_equal(do.dilate(m, k), d), k
     draws = rng.rand(200).astype(np.float32)
     idx = do.edge_sampler_indices(m, draws, num_sample=200, ratio_mask=0.6, ratio_edge=0.3, kernel_size=4)
-    flat, band = m.reshape(-1), (do.dilate(m, 4) - do.erode(m, 4)).reshape(-1)
+    col = m.reshape(-1, 1)                      # the reference flattens the mask before the morphology (sampler.py:23-27)
+    flat, band = m.reshape(-1), (do.dilate(col, 4) - do.erode(col, 4)).reshape(-1)
     assert (flat[idx[:120]] != 0).all() and (band[idx[120:180]] != 0).all() and len(idx) == 200
     # anchors of the mask branch: distinct, and a patch of size P anchored there is centred on a mask pixel
     x, y = do.patch_sampler_corners(m, np.r_[0.0, rng.rand(8)].astype(np.float32), num_patch=4, patch_size=8, ratio_mask=1)
@@ -672,3 +674,38 @@ def test_smpl_deformer_oracle_matches_reference_python_golden(oracle, small_worl
         assert (np.abs(sigma - g[ks])[tight] > 2e-2 * (1 + np.abs(g[ks][tight]))).mean() < 5e-3, mode
         assert (np.abs(rgb - g[kr])[tight].max(-1) > 2e-3).mean() < 5e-3, mode
         assert np.array_equal(sigma[~valid & ~g["valid"]], g[ks][~valid & ~g["valid"]])      # fills: 0 (test) / -1e5 (train)
+
+
+def test_data_oracle_matches_reference_python_golden():
+    """f4: oracle/data_oracle.py against the REFERENCE's data side executing on the CPU (tests/golden/make_data_golden.py:
+    peoplesnapshot.make_rays, PeopleSnapshotDataset.__getitem__ (train), EdgeSampler, PatchSampler with / without dilate and
+    its uniform branch; cv2 morphology stood in by scipy filters, numpy's random functions scripted from explicit draws).
+    Includes the reference's flattened-mask edge band: EdgeSampler reshapes the mask to 1-D before cv2.erode / dilate."""
+    from oracle import data_oracle as do
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_data_golden as mk
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_golden.npz"))
+    mask, img, K, c2w, smpl = mk.scene()
+    H, W = mask.shape
+    ro, rd = do.make_rays(K, c2w, H, W)
+    assert np.array_equal(ro, g["rays_o"]) and np.abs(rd - g["rays_d"]).max() <= 6e-8
+    imgf = img.astype(np.float32)
+    out = do.edge_sampler_sample(mask, [imgf, g["rays_o"], g["rays_d"]], g["edge_draws"], num_sample=512, ratio_mask=0.6, ratio_edge=0.3, kernel_size=8)
+    for i, a in enumerate(out):
+        assert np.array_equal(np.asarray(a).reshape(g["edge_out%d" % i].shape), g["edge_out%d" % i]), ("edge", i)
+    # the flattened band differs from a 2-D band: make sure the golden really exercises that
+    band1 = (do.dilate(mask.reshape(-1, 1), 8) - do.erode(mask.reshape(-1, 1), 8)).reshape(-1)
+    band2 = (do.dilate(mask, 8) - do.erode(mask, 8)).reshape(-1)
+    assert (band1 != band2).sum() > 50
+    for tag, dil in (("pm", 0), ("pd", 6), ("pu", 0)):
+        x, y = do.patch_sampler_corners(mask, g[tag + "_draws"], num_patch=4, patch_size=16, ratio_mask=0.9, dilate_k=dil)
+        ref_mask_patches = g[tag + "_out0"]
+        got = np.stack([mask[a:a + 16, b:b + 16] for a, b in zip(x, y)])
+        assert np.array_equal(got, ref_mask_patches), tag
+        got_rays = np.stack([g["rays_d"][a:a + 16, b:b + 16] for a, b in zip(x, y)])
+        assert np.array_equal(got_rays, g[tag + "_out3"]), tag
+    fn = lambda msk, *args: do.patch_sampler_sample(msk, args, g["gi_draws"], 4, 16, 0.9)
+    d = do.getitem_train(img, mask, g["rays_o"], g["rays_d"], smpl, 0, fn, g["gi_bg"])
+    for k in ("rgb", "rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl", "alpha", "bg_color", "near", "far"):
+        assert np.array_equal(np.asarray(d[k], np.float32), np.asarray(g["gi_" + k], np.float32)), k
+    assert int(d["idx"]) == int(g["gi_idx"])

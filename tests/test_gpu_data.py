@@ -73,7 +73,8 @@ def test_edge_sampler_matches_oracle():
     s = EdgeSampler(num_sample=4096, ratio_mask=0.6, ratio_edge=0.3, kernel_size=16)      # confs/sampler/edge.yaml
     m = torch.as_tensor(masks[1], device=DEV)
     band = s.edge_band(m).cpu().numpy()
-    assert np.array_equal(band, do.dilate(masks[1], 16) - do.erode(masks[1], 16))
+    col = masks[1].reshape(-1, 1)     # the reference's band is computed on the FLATTENED mask (sampler.py:23-27): an N x 1 image for OpenCV
+    assert np.array_equal(band.reshape(-1), (do.dilate(col, 16) - do.erode(col, 16)).reshape(-1))
     draws = rng.rand(4096).astype(np.float32)
     idx = s.sample_indices(m, draws=torch.as_tensor(draws, device=DEV)).cpu().numpy()
     ref = do.edge_sampler_indices(masks[1], draws, 4096, 0.6, 0.3, 16)
