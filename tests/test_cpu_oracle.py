@@ -709,3 +709,41 @@ def test_data_oracle_matches_reference_python_golden():
     for k in ("rgb", "rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl", "alpha", "bg_color", "near", "far"):
         assert np.array_equal(np.asarray(d[k], np.float32), np.asarray(g["gi_" + k], np.float32)), k
     assert int(d["idx"]) == int(g["gi_idx"])
+
+
+def test_animate_sequence_matches_reference_animate_dataset_golden():
+    """drivers.animate.AnimateSequence (camera, pose-track handling, per-frame batch) against the REFERENCE's
+    AnimateDataset executing on the CPU on the pose track the reference ships (tests/golden/make_animate_golden.py; the
+    three frames compared travel with the golden)."""
+    from instantavatar_amd.drivers.animate import AnimateSequence
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "animate_golden.npz"))
+    seq = AnimateSequence(g["track_poses"], g["track_trans"], g["betas"], "cpu", downscale=16)
+    assert (seq.H, seq.W) == (int(g["H"]), int(g["W"])) and int(g["n"]) == 320
+    for row, f in enumerate(g["frames"]):
+        b = seq.batch(row)
+        for k in ("rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl", "near", "far"):
+            a, r = b[k][0].numpy(), g["f%d_%s" % (f, k)]
+            assert a.shape == r.shape, (k, a.shape, r.shape)
+            assert np.array_equal(a, r) or np.abs(a - r).max() <= 1.2e-7 * max(1.0, np.abs(r).max()), (int(f), k, np.abs(a - r).max())
+
+
+def test_losses_match_reference_loss_py_golden():
+    """training.NeRFLoss / NGPLoss (torch formulation, fused=False: what the fused HIP kernel is tested against on the GPU)
+    against the REFERENCE's utils/loss.py executing on the CPU (tests/golden/make_loss_golden.py): every reported value and
+    the gradients w.r.t. rgb / alpha / depth / weights."""
+    from instantavatar_amd.training import NGPLoss, NeRFLoss
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_golden.npz"))
+    for tag, loss in (("nerf", NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1), fused=False)),
+                      ("ngp", NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01), fused=False))):
+        pred = {k: torch.tensor(g["%s_in_%s" % (tag, k)], requires_grad=True) for k in ("rgb_coarse", "alpha_coarse", "depth_coarse", "weight_coarse")}
+        tgt = {k: torch.tensor(g["%s_tgt_%s" % (tag, k)]) for k in ("rgb", "alpha")}
+        out = loss(pred, tgt)
+        out["loss"].backward()
+        keys = [k[len(tag) + 1:] for k in g.files if k.startswith(tag + "_") and not k.startswith(tag + "_in_") and not k.startswith(tag + "_grad_") and not k.startswith(tag + "_tgt_")]
+        assert "loss" in keys and "reg_density" in keys and (tag == "nerf" or "loss_depth_reg" in keys)
+        for k in keys:
+            assert abs(float(out[k].detach()) - float(g["%s_%s" % (tag, k)])) <= 2e-6 * max(1.0, abs(float(g["%s_%s" % (tag, k)]))), (tag, k)
+        for k, v in pred.items():
+            ref = g["%s_grad_%s" % (tag, k)]
+            got = v.grad.numpy() if v.grad is not None else np.zeros_like(ref)
+            assert np.abs(got - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max()), (tag, k)
