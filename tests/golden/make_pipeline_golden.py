@@ -87,6 +87,9 @@ def main():
         out.update(C_sel=sel, C_bg=tb["bg_color"].numpy()[0], C_rgb=d["rgb_coarse"].detach().numpy()[0], C_alpha=d["alpha_coarse"].detach().numpy()[0],
                    C_depth=d["depth_coarse"].detach().numpy()[0], C_weights=d["weight_coarse"].detach().numpy()[0])
         print("(C) train render: alpha mean %.4f" % float(d["alpha_coarse"].mean()))
+    # (E) the checkpoint surface: what the reference's modules register (tcnn's two flat vectors are 1-element stand-ins here)
+    sd = model.state_dict()
+    out["E_state_dict"] = np.array(["%s|%s|%s" % (k, "x".join(str(d) for d in v.shape), str(v.dtype)) for k, v in sd.items()])
     np.savez_compressed(OUT, seeds=np.array([SEED_INIT, SEED_UPD, SEED_TRAIN]), res=np.int32(RES), frame=np.int32(FRAME), **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

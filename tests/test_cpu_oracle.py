@@ -747,3 +747,25 @@ def test_losses_match_reference_loss_py_golden():
             ref = g["%s_grad_%s" % (tag, k)]
             got = v.grad.numpy() if v.grad is not None else np.zeros_like(ref)
             assert np.abs(got - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max()), (tag, k)
+
+
+def test_checkpoint_surface_equals_reference_modules_state_dict():
+    """The keys, shapes and dtypes a checkpoint of the path carries: the product's modules against what the REFERENCE's
+    modules register (state_dict() of the reference model built by tests/golden/ref_cpu_harness.py; the two tcnn vectors are
+    stand-ins there, their sizes are covered by test_tcnn_param_vector_sizes_and_loader_messages)."""
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    from instantavatar_amd.pipeline import AvatarModel
+    from instantavatar_amd.renderers.raymarcher_acc import Raymarcher
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.npz"))
+    ref = {}
+    for row in g["E_state_dict"]:
+        k, shape, dtype = str(row).split("|")
+        ref[k] = (shape, dtype)
+    model = AvatarModel(None, NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])), Raymarcher(256, 291600))
+    got = {k: ("x".join(str(d) for d in v.shape), str(v.dtype)) for k, v in model.state_dict().items()}
+    assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
+    for k in ref:
+        if k.endswith(".params"):
+            assert got[k][1] == ref[k][1]                 # flat fp32 vectors, sizes differ from the 1-element stand-ins
+        else:
+            assert got[k] == ref[k], (k, got[k], ref[k])
