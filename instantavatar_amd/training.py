@@ -309,9 +309,9 @@ def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=5e
             body.append(p)
         else:
             (enc if "encoder" in name else rest).append(p)
-    groups = [{"params": enc}, {"params": rest}]
-    if body:
-        groups.append({"params": body, "lr": smpl_lr})
+    # always three groups, the SMPL one possibly empty: that is what DNeRF.py:46-50 builds, and an optimiser state saved
+    # by the reference (Lightning's `optimizer_states`) only loads into an optimiser with the same number of groups
+    groups = [{"params": enc}, {"params": rest}, {"params": body, "lr": smpl_lr}]
     opt = torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps, fused=bool(enc and enc[0].is_cuda))
     return opt
 
@@ -488,7 +488,7 @@ class GraphedTrainStep:
                 raise RuntimeError("GraphedTrainStep needs the fused Adam of configure_optimizer")
             g["capturable"] = True
             if not torch.is_tensor(g["lr"]):
-                dev = g["params"][0].device
+                dev = g["params"][0].device if g["params"] else self.optimizer.param_groups[0]["params"][0].device
                 g["lr"] = torch.tensor(float(g["lr"]), device=dev)
                 if "initial_lr" in g and not torch.is_tensor(g["initial_lr"]):
                     g["initial_lr"] = float(g["initial_lr"])

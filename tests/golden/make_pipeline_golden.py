@@ -87,6 +87,19 @@ def main():
         out.update(C_sel=sel, C_bg=tb["bg_color"].numpy()[0], C_rgb=d["rgb_coarse"].detach().numpy()[0], C_alpha=d["alpha_coarse"].detach().numpy()[0],
                    C_depth=d["depth_coarse"].detach().numpy()[0], C_weights=d["weight_coarse"].detach().numpy()[0])
         print("(C) train render: alpha mean %.4f" % float(d["alpha_coarse"].mean()))
+    # (F) DNeRFModel.configure_optimizers (DNeRF.py:32-59): parameter groups and the LambdaLR schedule
+    model.opt["optimizer"] = H.Opt(lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    model.opt["scheduler"] = H.Opt(max_epochs=30)
+    (optim,), (sched,) = R.dnerf.DNeRFModel.configure_optimizers(model)
+    names = {id(p): n for n, p in model.named_parameters()}
+    out["F_groups"] = np.array(["%s|%g|%s|%g" % (",".join(names[id(p)] for p in g["params"]), g["lr"], g["betas"], g["eps"]) for g in optim.param_groups])
+    fac = []
+    for epoch in range(31):
+        fac.append(optim.param_groups[0]["lr"])
+        optim.step()
+        sched.step()
+    out["F_lr_per_epoch"] = np.array(fac, np.float64)
+    print("(F) groups", list(out["F_groups"]), "lr[0,1,15,29,30]", [fac[i] for i in (0, 1, 15, 29, 30)])
     # (E) the checkpoint surface: what the reference's modules register (tcnn's two flat vectors are 1-element stand-ins here)
     sd = model.state_dict()
     out["E_state_dict"] = np.array(["%s|%s|%s" % (k, "x".join(str(d) for d in v.shape), str(v.dtype)) for k, v in sd.items()])

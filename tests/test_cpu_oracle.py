@@ -769,3 +769,26 @@ def test_checkpoint_surface_equals_reference_modules_state_dict():
             assert got[k][1] == ref[k][1]                 # flat fp32 vectors, sizes differ from the 1-element stand-ins
         else:
             assert got[k] == ref[k], (k, got[k], ref[k])
+
+
+def test_optimizer_groups_and_lr_schedule_equal_reference_configure_optimizers():
+    """training.configure_optimizer / configure_scheduler against DNeRFModel.configure_optimizers of the reference executing
+    (pipeline golden, part F): three Adam groups -- hash encoding, the rest, the (here empty) SMPL tables with their own
+    learning rate -- same hyper-parameters, and the per-epoch learning rate of the LambdaLR (1 - epoch / max_epochs) ** 1.5."""
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+    from instantavatar_amd.pipeline import AvatarModel
+    from instantavatar_amd.renderers.raymarcher_acc import Raymarcher
+    from instantavatar_amd.training import configure_optimizer, configure_scheduler
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.npz"))
+    model = AvatarModel(None, NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])), Raymarcher(256, 291600))
+    opt = configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=5e-4)
+    names = {id(p): n for n, p in model.named_parameters()}
+    got = ["%s|%g|%s|%g" % (",".join(names[id(p)] for p in grp["params"]), grp["lr"], tuple(grp["betas"]), grp["eps"]) for grp in opt.param_groups]
+    assert got == [str(r) for r in g["F_groups"]], (got, list(g["F_groups"]))
+    sched = configure_scheduler(opt, max_epochs=30)
+    lrs = []
+    for epoch in range(31):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    assert np.allclose(lrs, g["F_lr_per_epoch"], rtol=1e-12, atol=0)
