@@ -3,7 +3,7 @@ version 0.1 -- the perceptual term of the reference's NGPLoss (instant_avatar/ut
 `third_parties/lpips.LPIPS(net="vgg", pretrained=True)`).
 
 Not on the hot path: it is a convolutional network over the 4 rendered 32 x 32 patches of a training step and runs as
-library convolutions (MIOpen through torch.nn.functional.conv2d).  What matters here is that a reference user can switch
+library convolutions (MIOpen through torch.nn.Conv2d).  What matters here is that a reference user can switch
 over: parameter names and shapes equal the reference module's (`net.slice{1..5}.{i}.weight/bias`, `lin{0..4}.model.1.weight`,
 buffers `scaling_layer.shift/scale`), so the reference's own weight files load unchanged:
 
@@ -15,7 +15,6 @@ Without both files NGPLoss(w_lpips > 0) refuses to run rather than optimise agai
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 # torchvision's VGG-16 ("configuration D") feature stack up to relu5_3: output channels of the 3x3 convolutions, "M" =
 # 2x2 max-pool.  Module indices follow torchvision's nn.Sequential (conv, relu alternate; a pool takes one index), which

@@ -8,7 +8,6 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-import bench  # noqa: E402
 from instantavatar_amd import synthetic as syn  # noqa: E402
 from instantavatar_amd.pipeline import build_synthetic_model, make_batch  # noqa: E402
 from instantavatar_amd.training import NeRFLoss, configure_optimizer, training_step  # noqa: E402
