@@ -56,6 +56,14 @@ def main():
                    A_occ=np.packbits(g.density_field.numpy().astype(np.uint8)), A_aabb=torch.stack(list(g.aabb)).numpy(),
                    tfs=model.deformer.tfs.numpy()[0], w2s=model.deformer.w2s.numpy()[0], bbox=model.deformer.bbox.numpy())
         print("(A) alpha coverage %.3f, occupied cells %d, samples/ray %.2f" % (float((alpha > 0.5).float().mean()), int(g.density_field.sum()), float(counter.mean())))
+        # ---- (A2): the same frame and occupancy grid with MAX_BATCH_SIZE = 4096, so that the wave-front loop of
+        # Raymarcher.render_test runs many iterations with a changing N_step (4, 5, 6, ... as rays retire) ----
+        model.renderer.MAX_BATCH_SIZE = 4096
+        d2 = R.dnerf.DNeRFModel.forward(model, dict(batch))
+        model.renderer.MAX_BATCH_SIZE = 291600
+        out.update(A2_rgb=d2["rgb_coarse"].numpy()[0], A2_depth=d2["depth_coarse"].numpy()[0], A2_alpha=d2["alpha_coarse"].numpy()[0],
+                   A2_counter=d2["counter_coarse"].numpy()[0])
+        print("(A2) max |rgb - rgb(A)| %.3e, samples/ray %.2f" % (float((d2["rgb_coarse"][0] - rgb[0].reshape(-1, 3)).abs().max()), float(d2["counter_coarse"].mean())))
         # ---- (D) ----
         lbs_ref = model.deformer.deformer.lbs_voxel_final.numpy()[0]
         out["D_lbs_max_abs_diff_to_oracle"] = np.float32(np.abs(lbs_ref - init["lbs_voxel"]).max())

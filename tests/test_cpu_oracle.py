@@ -619,6 +619,12 @@ def test_oracle_pipeline_matches_reference_python_golden(oracle, small_world):
     assert np.median(d_rgb) < 1e-6 and (g["A_alpha"] > 0.5).mean() > 0.03
     hit = g["A_alpha"] > 0.5
     assert np.abs(out["depth"].reshape(res, res) - g["A_depth"])[hit].max() < 2e-3
+    # (A2): same frame, MAX_BATCH_SIZE = 4096 -> many wave-front iterations with a changing N_step (raymarcher_acc.py:107)
+    o_s, d_s, near_s, far_s = oracle.transform_rays_w2s(ro, rd, world["w2s"])
+    a2 = oracle.render_test(o_s, d_s, near_s, far_s, occ_ref, g["A_aabb"], lambda p: oracle.deform_query(p, world, True), MAX_BATCH_SIZE=4096)
+    assert (a2["counter"].reshape(-1) != g["A2_counter"].reshape(-1)).mean() < 5e-3 and g["A2_counter"].sum() < g["A_counter"].sum()
+    assert (np.abs(a2["rgb"].reshape(res, res, 3) - g["A2_rgb"].reshape(res, res, 3)).max(-1) > 1e-4).mean() < 5e-3
+    assert (np.abs(a2["alpha"].reshape(res, res) - g["A2_alpha"].reshape(res, res)) > 1e-4).mean() < 5e-3
     # (B)
     cached, field = np.zeros((64, 64, 64), np.float32), np.zeros((64, 64, 64), bool)
     for k, step in enumerate((0, 500)):
