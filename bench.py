@@ -691,6 +691,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world_size > 1:
+        torch.distributed.barrier()   # rank 0 is still measuring the isolated encoder / printing: leave together
         torch.distributed.destroy_process_group()
 
 
