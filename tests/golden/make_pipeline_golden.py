@@ -22,7 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-OUT = os.path.join(HERE, "pipeline_golden.npz")
+# the hash-grid layout switch (tcnn level-3 resolution 54 / 55) changes the field: one golden per layout
+OUT = os.path.join(HERE, "pipeline_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
 SEED_INIT, SEED_UPD, SEED_TRAIN = 101, 202, 303
 RES, FRAME, N_TRAIN = 32, 1, 192
 

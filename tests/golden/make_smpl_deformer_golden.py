@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-OUT = os.path.join(HERE, "smpl_deformer_golden.npz")
+# the hash-grid layout switch (tcnn level-3 resolution 54 / 55) changes the field: one golden per layout
+OUT = os.path.join(HERE, "smpl_deformer_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
 FRAME, SEED, N = 2, 11, 4000
 
 

@@ -16,6 +16,10 @@ ROOT = os.path.dirname(HERE)
 
 
 # ---------------------------------------------------------------- C ABI / build
+#: goldens that involve the field exist once per hash-grid layout (tcnn level-3 resolution 54 / 55)
+_LAYOUT = "_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""
+
+
 def test_cabi_exports_every_declared_symbol():
     from instantavatar_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "instantavatar_hip.h")).read()
@@ -594,7 +598,7 @@ def test_oracle_pipeline_matches_reference_python_golden(oracle, small_world):
       (C) DNeRFModel.forward in training mode: Raymarcher.render_train with jitter and sigma noise
       (D) ForwardDeformer.switch_to_explicit's skinning-weight voxels (KNN + smoothing in torch)."""
     body, init, fp, _ = small_world
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden%s.npz" % _LAYOUT))
     seed_init, seed_upd, seed_train = (int(v) for v in g["seeds"])
     res, frame = int(g["res"]), int(g["frame"])
     poses, tr = syn.procedural_pose_track(8)
@@ -656,7 +660,7 @@ def test_smpl_deformer_oracle_matches_reference_python_golden(oracle, small_worl
     the REFERENCE's smpl_deformer.py executing on the CPU (tests/golden/make_smpl_deformer_golden.py): per-vertex inverse
     transforms, posed vertices, boxes, nearest-vertex deformation, test- and train-mode field queries."""
     body, init, fp0, _ = small_world
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "smpl_deformer_golden.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "smpl_deformer_golden%s.npz" % _LAYOUT))
     frame = int(g["frame"])
     poses, tr = syn.procedural_pose_track(8)
     prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[frame, 3:], poses[frame, :3], tr[frame])
