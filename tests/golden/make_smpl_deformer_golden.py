@@ -25,7 +25,10 @@ def main():
     init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
     poses, tr = syn.procedural_pose_track(8)
     prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[FRAME, 3:], poses[FRAME, :3], tr[FRAME])
-    fp = syn.make_field(init["cano_joints"], prep["bbox"])          # field over the SMPLDeformer's (DA-pose) canonical box
+    pose_t = np.zeros((1, 69), np.float32)
+    pose_t[:, 2], pose_t[:, 5] = np.pi / 6, -np.pi / 6
+    cano_j = oracle.smpl_forward(body, np.zeros(10, np.float32), pose_t)["joints"]
+    fp = syn.make_field(cano_j, prep["bbox"], seed=42, n_levels=16)   # the field of tests/world.py:build_smpl_deformer_world (DA-pose template)
     field, keep = oracle.make_field(fp)
     R = H.install(oracle, {"field": field})
     model = H.build_reference_model(R, body, fp, resolution=32)      # (sets up the SMPL stand-in; the net is reused)
@@ -45,10 +48,23 @@ def main():
         rgb_t, sig_t = dfm(t(pts), net, eval_mode=True)
         rgb_r, sig_r = dfm(t(pts), net, eval_mode=False)
     print("valid %.3f; sigma test range [%.2f, %.2f]" % (float(valid.float().mean()), float(sig_t.min()), float(sig_t.max())))
+    # a rendered frame through DNeRFModel.render_image_fast with this deformer plugged in (32 x 32, 5 seeded probe sets)
+    ro, rd = syn.make_camera_rays(32)
+    dist = float(np.sqrt((tr[FRAME] ** 2).sum()))
+    batch = dict(params, rays_o=t(ro)[None], rays_d=t(rd)[None], near=torch.full((1, 1024), dist - 1), far=torch.full((1, 1024), dist + 1))
+    model.deformer = dfm
+    model.eval()
+    with H.SeededDraws() as draws:
+        draws.seed(77)
+        f_rgb, f_depth, f_alpha, f_counter = R.dnerf.DNeRFModel.render_image_fast(model, batch, (32, 32))
+    gt = model.renderer.density_grid_test
+    print("frame: alpha coverage %.3f, occupied cells %d" % (float((f_alpha > 0.5).float().mean()), int(gt.density_field.sum())))
     np.savez_compressed(OUT, frame=np.int32(FRAME), pts=pts, cano=cano.numpy(), valid=valid.numpy(), rgb_test=rgb_t.numpy(), sigma_test=sig_t.numpy(),
                         rgb_train=rgb_r.numpy(), sigma_train=sig_r.numpy(), T_inv_sample=dfm.T_inv[0].detach().numpy()[::53],
                         verts_sample=v[::53], w2s=dfm.w2s[0].detach().numpy(), bbox=dfm.bbox.detach().numpy(),
-                        bbox_deformed=dfm.get_bbox_deformed().detach().numpy())
+                        bbox_deformed=dfm.get_bbox_deformed().detach().numpy(), cano_joints=np.asarray(cano_j, np.float32),
+                        F_rgb=f_rgb.numpy()[0], F_depth=f_depth.numpy()[0], F_alpha=f_alpha.numpy()[0], F_counter=f_counter.numpy()[0],
+                        F_occ=np.packbits(gt.density_field.numpy().astype(np.uint8)), F_aabb=torch.stack(list(gt.aabb)).numpy())
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 

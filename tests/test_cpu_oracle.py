@@ -675,7 +675,7 @@ def test_smpl_deformer_oracle_matches_reference_python_golden(oracle, small_worl
     both = valid & g["valid"]
     d = np.abs(cano - g["cano"])[both].max(-1)
     assert np.median(d) < 2e-6 and (d > 1e-4).mean() < 2e-3, (np.median(d), (d > 1e-4).mean())
-    field, keep = oracle.make_field(syn.make_field(init["cano_joints"], prep["bbox"]))
+    field, keep = oracle.make_field(syn.make_field(g["cano_joints"], prep["bbox"], seed=42, n_levels=16))
     for mode, kr, ks in ((True, "rgb_test", "sigma_test"), (False, "rgb_train", "sigma_train")):
         rgb, sigma = oracle.smpl_deform_query(g["pts"], prep, field, eval_mode=mode)
         same = (valid == g["valid"])
@@ -685,6 +685,28 @@ def test_smpl_deformer_oracle_matches_reference_python_golden(oracle, small_worl
         assert (np.abs(sigma - g[ks])[tight] > 2e-2 * (1 + np.abs(g[ks][tight]))).mean() < 5e-3, mode
         assert (np.abs(rgb - g[kr])[tight].max(-1) > 2e-3).mean() < 5e-3, mode
         assert np.array_equal(sigma[~valid & ~g["valid"]], g[ks][~valid & ~g["valid"]])      # fills: 0 (test) / -1e5 (train)
+    # the frame DNeRFModel.render_image_fast renders with this deformer plugged in: occupancy build from get_bbox_deformed,
+    # wave-front loop through the generic deformer(pts, net) closure
+    G = 64
+    rs = np.random.RandomState(77)
+    jit = [rs.rand(G, G, G, 3).astype(np.float32).reshape(-1, 3) for _ in range(5)]
+    query = lambda p: oracle.smpl_deform_query(p, prep, field, eval_mode=True)
+    aabb = oracle.get_bbox_from_smpl(prep["vertices"])
+    idx = np.arange(G, dtype=np.float32)
+    cx, cy, cz = np.meshgrid(idx, idx, idx, indexing="ij")
+    coords0 = (np.stack([cx, cy, cz], -1).reshape(-1, 3) / np.float32(G)).astype(np.float32)
+    density = np.zeros(G ** 3, np.float32)
+    for j in jit:
+        density = np.maximum(density, query(((coords0 + j / np.float32(G)) * (aabb[1] - aabb[0]) + aabb[0]).astype(np.float32))[1])
+    occ = oracle.occupancy_from_density(density, G)
+    occ_ref = np.unpackbits(g["F_occ"])[:G ** 3].reshape(G, G, G)
+    assert np.abs(aabb - g["F_aabb"]).max() < 2e-6 and (occ.astype(np.uint8) != occ_ref).mean() < 3e-4
+    ro, rd = syn.make_camera_rays(32)
+    o, dd, near, far = oracle.transform_rays_w2s(ro, rd, prep["w2s"])
+    ref = oracle.render_test(o, dd, near, far, occ_ref, g["F_aabb"], query)
+    e_rgb = np.abs(ref["rgb"].reshape(32, 32, 3) - g["F_rgb"]).max(-1)
+    assert (e_rgb > 1e-3).mean() < 1e-2 and np.median(e_rgb) < 1e-5, ((e_rgb > 1e-3).mean(), e_rgb.max())
+    assert (np.abs(ref["alpha"].reshape(32, 32) - g["F_alpha"]) > 1e-3).mean() < 1e-2 and (g["F_alpha"] > 0.5).mean() > 0.03
 
 
 def test_data_oracle_matches_reference_python_golden():
