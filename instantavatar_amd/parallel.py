@@ -43,8 +43,13 @@ def broadcast_module_state(module, world_size, src=0):
     if world_size <= 1:
         return
     dist = _dist()
+    # the training occupancy grids are kept in a plain list like the reference's (not in state_dict): name them explicitly
+    extra = []
+    for m in (module.modules() if hasattr(module, "modules") else []):
+        for g in m.__dict__.get("density_grid_train_all", []):
+            extra += list(g.buffers())
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
+        for t in list(module.parameters()) + list(module.buffers()) + extra:
             if t.dtype == torch.bool:  # NCCL has no bool: go through uint8
                 u = t.to(torch.uint8)
                 dist.broadcast(u, src=src)
@@ -52,7 +57,8 @@ def broadcast_module_state(module, world_size, src=0):
             else:
                 dist.broadcast(t.data, src=src)
     if hasattr(module, "modules"):
-        for m in module.modules():
+        grids = [g for m in module.modules() for g in m.__dict__.get("density_grid_train_all", [])]
+        for m in list(module.modules()) + grids:
             if hasattr(m, "mark_updated"):
                 m.mark_updated()       # fp16 shadows / MFMA fragments follow the new master weights
             if hasattr(m, "pack_bits") and getattr(m, "density_field", None) is not None and m.density_field.is_cuda:

@@ -116,12 +116,22 @@ class Raymarcher(torch.nn.Module):
         self.last_iters = 0
 
     def initialize(self, N):
+        """raymarcher_acc.py:66-70: one training grid (N with smpl_init: one per frame), held in a PLAIN list as in the
+        reference -- not a sub-module: the training grids are not part of `state_dict()` (a checkpoint of the reference
+        does not carry them, and its loaders are strict), they restart from zero on resume and are rebuilt by the updates."""
         n = N if self.smpl_init else 1
-        self.density_grid_train_all = torch.nn.ModuleList(
-            [DensityGrid(64, self.aabb, smpl_init=self.smpl_init) for _ in range(n)])
-        self.density_grid_train_all.to(self.aabb.device)
+        dev = self.aabb.device
+        self.density_grid_train_all = [DensityGrid(64, self.aabb, smpl_init=self.smpl_init).to(dev) for _ in range(n)]
         for g in self.density_grid_train_all:
             g.aabb = self.aabb
+
+    def _apply(self, fn, *args, **kwargs):
+        """`.to(device)` / `.cuda()` of the renderer also moves the training grids (they are not registered sub-modules)"""
+        super()._apply(fn, *args, **kwargs)
+        for g in self.__dict__.get("density_grid_train_all", []):
+            g._apply(fn, *args, **kwargs)
+            g.aabb = self.aabb
+        return self
 
     def bind_fused(self, deformer, net):
         self._fused = (deformer, net)

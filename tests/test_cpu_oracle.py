@@ -794,8 +794,11 @@ def test_checkpoint_surface_equals_reference_modules_state_dict():
     for row in g["E_state_dict"]:
         k, shape, dtype = str(row).split("|")
         ref[k] = (shape, dtype)
-    model = AvatarModel(None, NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])), Raymarcher(256, 291600))
-    got = {k: ("x".join(str(d) for d in v.shape), str(v.dtype)) for k, v in model.state_dict().items()}
+    renderer = Raymarcher(256, 291600)
+    renderer.initialize(1)                                   # as DNeRFModel.__init__ does (DNeRF.py:28): the training grid exists ...
+    model = AvatarModel(None, NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])), renderer)
+    assert len(renderer.density_grid_train_all) == 1 and renderer.density_grid_train is renderer.density_grid_train_all[0]
+    got = {k: ("x".join(str(d) for d in v.shape), str(v.dtype)) for k, v in model.state_dict().items()}   # ... but is not checkpointed
     assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
     for k in ref:
         if k.endswith(".params"):

@@ -31,7 +31,7 @@ def test_density_grid_update_matches_oracle(oracle):
     grid = DensityGrid(G, aabb=model.renderer.aabb.clone()).to(DEV)
     grid.aabb = model.renderer.aabb
     saved = model.renderer.density_grid_train_all
-    model.renderer.density_grid_train_all = torch.nn.ModuleList([grid])
+    model.renderer.density_grid_train_all = [grid]
     cached = np.zeros((G, G, G), np.float32)
     field = np.zeros((G, G, G), bool)
     rng = np.random.RandomState(17)
