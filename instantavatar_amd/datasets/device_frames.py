@@ -58,6 +58,38 @@ class DeviceFrames:
     def __len__(self):
         return self.N
 
+    def frame(self, idx):
+        """PeopleSnapshotDataset.__getitem__ for split "val" / "test" (peoplesnapshot.py:112-125): the WHOLE frame, white
+        background, rays / rgb / alpha flattened to [1, H*W, ...] -- what validation_step hands to render_image_fast."""
+        dev = self.images.device
+        L = _lib.lib()
+        H, W = self.H, self.W
+        n = H * W
+        if getattr(self, "_all_pixels", None) is None:
+            self._all_pixels = torch.arange(n, dtype=torch.int32, device=dev)
+        rgb, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev)
+        ro, rd = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
+        bg = torch.empty((n, 3), device=dev)
+        img = self.images[idx]
+        img_u8 = img if img.dtype == torch.uint8 else None
+        img_f = None if img_u8 is not None else img.float().contiguous()
+        m = self.masks[idx].float().contiguous()
+        _lib.check(L.ia_sample_batch(_lib.ptr(img_u8), _lib.ptr(img_f), _lib.ptr(m), _lib.ptr(self.rays_o), _lib.ptr(self.rays_d), H, W,
+                                     _lib.ptr(self._all_pixels), None, None, 0, 0, n, None, _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(ro),
+                                     _lib.ptr(rd), _lib.ptr(bg), None, _lib.stream()), "ia_sample_batch")   # bg NULL = white (:114)
+        p = self.smpl_params
+        transl = p["transl"][idx]
+        near, far = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        if self.near is not None and self.far is not None:
+            near.fill_(float(self.near))
+            far.fill_(float(self.far))
+        else:
+            _lib.check(L.ia_near_far(_lib.ptr(transl.contiguous()), n, _lib.ptr(near), _lib.ptr(far), _lib.stream()), "ia_near_far")
+        return {"rgb": rgb[None], "rays_o": ro[None], "rays_d": rd[None], "betas": p["betas"][0][None],
+                "global_orient": p["global_orient"][idx][None], "body_pose": p["body_pose"][idx][None], "transl": transl[None],
+                "alpha": alpha[None], "bg_color": bg.reshape(1, H, W, 3),   # the reference leaves bg_color un-flattened (:114)
+                "idx": torch.tensor([idx]), "near": near[None], "far": far[None]}
+
     def batch(self, idx, draws=None, bg_draws=None, generator=None, out=None):
         """One training batch (leading batch dimension 1, as the reference's DataLoader with batch_size=1 yields).
         out: a batch dict returned by an earlier call (or `training.GraphedTrainStep.inputs`, the static input tensors of

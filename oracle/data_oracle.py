@@ -121,3 +121,25 @@ def getitem_train(img_u8, msk, rays_o, rays_d, smpl_params, idx, sample_fn, bg_f
         datum["near"] = np.ones_like(rd[..., 0]) * (dist - 1)
         datum["far"] = np.ones_like(rd[..., 0]) * (dist + 1)
     return datum
+
+
+def getitem_eval(img_u8, msk, rays_o, rays_d, smpl_params, idx, near=None, far=None):
+    """PeopleSnapshotDataset.__getitem__ for split "val" / "test" (peoplesnapshot.py:112-125): the whole frame on a white
+    background, everything flattened."""
+    img = (np.asarray(img_u8)[..., :3] / 255).astype(np.float32)
+    msk = np.asarray(msk).astype(np.float32)
+    bg_color = np.ones_like(img).astype(np.float32)
+    img = img * msk[..., None] + (1 - msk[..., None])
+    rd = np.asarray(rays_d).reshape(-1, 3)
+    datum = {"rgb": img.reshape(-1, 3).astype(np.float32), "rays_o": np.asarray(rays_o).reshape(-1, 3), "rays_d": rd,
+             "betas": smpl_params["betas"][0], "global_orient": smpl_params["global_orient"][idx],
+             "body_pose": smpl_params["body_pose"][idx], "transl": smpl_params["transl"][idx], "alpha": msk.reshape(-1),
+             "bg_color": bg_color, "idx": idx}
+    if near is not None and far is not None:
+        datum["near"] = np.ones_like(rd[..., 0]) * near
+        datum["far"] = np.ones_like(rd[..., 0]) * far
+    else:
+        dist = np.sqrt(np.square(smpl_params["transl"][idx]).sum(-1))
+        datum["near"] = np.ones_like(rd[..., 0]) * (dist - 1)
+        datum["far"] = np.ones_like(rd[..., 0]) * (dist + 1)
+    return datum

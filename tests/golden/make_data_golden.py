@@ -136,6 +136,12 @@ def main():
     out["gi_draws"], out["gi_bg"] = d, bg
     for k, v in datum.items():
         out["gi_" + k] = np.asarray(v)
+    # __getitem__ of the "val" split: the whole frame, white background (peoplesnapshot.py:112-125)
+    ds.split = "val"
+    script.feed()
+    datum = ds.__getitem__(2 if len(ds.img_lists) > 2 else 0)
+    for k, v in datum.items():
+        out["ge_" + k] = np.asarray(v)
     np.savez_compressed(OUT, H=np.int32(H), W=np.int32(W), seed=np.int32(SEED), **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", {k: np.asarray(v).shape for k, v in datum.items()})
 

@@ -742,6 +742,11 @@ def test_data_oracle_matches_reference_python_golden():
     for k in ("rgb", "rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl", "alpha", "bg_color", "near", "far"):
         assert np.array_equal(np.asarray(d[k], np.float32), np.asarray(g["gi_" + k], np.float32)), k
     assert int(d["idx"]) == int(g["gi_idx"])
+    # the "val" split: whole frame, white background
+    e = do.getitem_eval(img, mask, g["rays_o"], g["rays_d"], smpl, 0)
+    for k in ("rgb", "rays_o", "rays_d", "betas", "global_orient", "body_pose", "transl", "alpha", "bg_color", "near", "far"):
+        a, r = np.asarray(e[k], np.float32), np.asarray(g["ge_" + k], np.float32)
+        assert a.shape == r.shape and np.array_equal(a, r), k
 
 
 def test_animate_sequence_matches_reference_animate_dataset_golden():

@@ -156,6 +156,24 @@ def test_device_batch_equals_reference_getitem(kind):
     assert int(again["idx"][0]) == idx2
 
 
+def test_device_eval_frame_equals_reference_getitem_val_split():
+    """DeviceFrames.frame == PeopleSnapshotDataset.__getitem__ for the val / test split (whole frame, white background)."""
+    from oracle import data_oracle as do
+    imgs, masks, K, c2w, smpl = _scene()
+    frames = DeviceFrames.from_arrays(imgs, masks, K, c2w, smpl, PatchSampler(num_patch=4, patch_size=16, ratio_mask=1), DEV)
+    H, W = masks.shape[1:]
+    ro, rd = do.make_rays(K, c2w, H, W)
+    for idx in (0, 2):
+        ref = do.getitem_eval(imgs[idx], masks[idx], ro, rd, smpl, idx)
+        got = frames.frame(idx)
+        for k in ("rgb", "alpha", "bg_color", "near", "far", "betas", "global_orient", "body_pose", "transl"):
+            a, b = got[k][0].cpu().numpy(), np.asarray(ref[k], np.float32)
+            assert a.shape == b.shape and np.array_equal(a, b), (k, a.shape, b.shape)
+        for k in ("rays_o", "rays_d"):
+            assert np.abs(got[k][0].cpu().numpy() - ref[k]).max() <= 6e-8, k
+        assert int(got["idx"][0]) == idx
+
+
 def test_device_batches_feed_a_training_step():
     """the device data path drives the real training step (plugins + kernels) end to end"""
     from instantavatar_amd import synthetic as syn
