@@ -833,3 +833,21 @@ def test_optimizer_groups_and_lr_schedule_equal_reference_configure_optimizers()
         opt.step()
         sched.step()
     assert np.allclose(lrs, g["F_lr_per_epoch"], rtol=1e-12, atol=0)
+
+
+def test_new_entry_points_validate_arguments_before_any_launch():
+    """ia_precompute_ws / ia_patch_corners / ia_near_far reject bad arguments with a message and never reach a launch
+    (callable without a GPU for exactly that reason)."""
+    from instantavatar_amd import _lib
+    L = _lib.lib()
+    g = _lib.SnarfGrid()
+    g.D, g.H, g.W = 8, 32, 30          # W not a multiple of 4
+    assert L.ia_precompute_workspace_bytes(C.byref(g)) > 0
+    assert L.ia_precompute_ws(None, None, None, None, None, C.byref(g), None, 0, None) != 0 and b"null pointer" in L.ia_last_error()
+    one = C.c_void_p(16)
+    assert L.ia_precompute_ws(one, one, one, None, None, C.byref(g), None, 0, None) != 0 and b"multiple of 4" in L.ia_last_error()
+    assert L.ia_patch_corners(None, None, None, 4, 64, 64, 16, C.c_float(1.0), None, None, None) != 0 and b"ia_patch_corners" in L.ia_last_error()
+    assert L.ia_patch_corners(one, one, one, 4, 16, 64, 16, C.c_float(1.0), one, one, None) != 0          # H <= patch
+    assert L.ia_patch_corners(one, one, one, 0, 64, 64, 16, C.c_float(1.0), one, one, None) == 0          # n == 0: nothing to do
+    assert L.ia_near_far(None, 5, None, None, None) != 0 and b"ia_near_far" in L.ia_last_error()
+    assert L.ia_near_far(None, 0, None, None, None) == 0
