@@ -189,6 +189,18 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
                             float dvg_thresh, float *cand_xc, int32_t cand_cap,
                             int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand,
                             int zero_counter, void *stream);
+/* The same call for the training route with SMPL parameters under optimisation (DNeRF.py:113-128 ->
+ * deformer_torch.py:50-67): additionally cand_Jinv [cap,3,3], the Broyden J_inv of every surviving root
+ * (the matrix before the last rank-1 update, fuse_cuda_kernel_fast.cu:383-391), compacted exactly like
+ * cand_xc -- what the reference gathers with `others['J_inv'][others['valid_ids']]` from a dense
+ * [1,P,13,3,3] tensor.  Input of ia_snarf_implicit_bwd_compact.                                    */
+int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
+                                 const float *voxel_J, const float *tfs,
+                                 const int32_t *bone_ids, int n_init,
+                                 const ia_snarf_grid *grid, float cvg_thresh,
+                                 float dvg_thresh, float *cand_xc, float *cand_Jinv,
+                                 int32_t cand_cap, int32_t *pt_off, uint8_t *pt_cnt,
+                                 int32_t *n_cand, int zero_counter, void *stream);
 
 /* ---- a7: implicit differentiation of the roots ----------------------------------------
  * Backward of ForwardDeformer.forward's training branch (deformer_torch.py:50-67 with
@@ -202,6 +214,12 @@ int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *va
                           const float *grad_xc, long n, const float *voxel_w,
                           const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes,
                           void *stream);
+/* The same backward over a COMPACT candidate list (ia_snarf_search_compact_jinv): no validity mask, the
+ * first min(cap, *n_cand) rows are live (n_cand: device int32, no host read).  Workspace as above for n = cap. */
+int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *cand_Jinv, const float *grad_xc,
+                                  long cap, const int32_t *n_cand, const float *voxel_w,
+                                  const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes,
+                                  void *stream);
 
 /* ---- a9 + a10 + a11: canonical field ---------------------------------------
  * Replaces NeRFNGPNet.forward (ngp.py:73-83) = tcnn NetworkWithInputEncoding

@@ -413,10 +413,12 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     // MODE 0
     float *__restrict__ xc, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ valid_raw,
     float *__restrict__ J_inv,
-    // MODE 1
+    // MODE 1 / 2 (2 = 1 + the Broyden J_inv of every surviving root, compacted like cand_xc: the training route
+    // with SMPL parameters under optimisation needs it for the implicit differentiation, deformer_torch.py:58-60)
     float *__restrict__ cand_xc, int cand_cap, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
-    int32_t *__restrict__ n_cand, unsigned long long *prof) {
+    int32_t *__restrict__ n_cand, unsigned long long *prof, float *__restrict__ cand_Jinv) {
   constexpr int NP = IA_SEARCH_NP;
+  __shared__ float s_Ji[MODE == 2 ? IA_N_INIT_MAX : 1][MODE == 2 ? NP : 1][9];
   __shared__ float s_x[IA_N_INIT_MAX][NP][3];
   __shared__ float s_xd[NP][3];
   __shared__ uint8_t s_valid[IA_N_INIT_MAX][NP];
@@ -558,6 +560,10 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
 #pragma unroll
           for (int k = 0; k < 9; k++) J_inv[o + k] = ok ? Ji[k] : 0.f;
         }
+        if (MODE == 2 && ok) {
+#pragma unroll
+          for (int k = 0; k < 9; k++) s_Ji[init][pt][k] = Ji[k];  // Q4 as above
+        }
         active = false;
       } else {
         // :340-351 update = -J_inv g ; x += update (start of the next iteration)
@@ -637,6 +643,10 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     if (o < cand_cap) {
       cand_xc[(size_t)o * 3] = s_x[init][pt][0]; cand_xc[(size_t)o * 3 + 1] = s_x[init][pt][1];
       cand_xc[(size_t)o * 3 + 2] = s_x[init][pt][2];
+      if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) cand_Jinv[(size_t)o * 9 + k] = s_Ji[init][pt][k];
+      }
     }
   }
 }
@@ -713,8 +723,38 @@ extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, con
                      (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
                      ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
                      valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
-                     (int32_t *)nullptr, (unsigned long long *)nullptr);
+                     (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr);
   IA_LAUNCH_CHECK("k_search<0>");
+  return IA_OK;
+}
+
+static int ia_search_compact_impl(const char *who, const float *xd, int P, const int32_t *n_pts_dev, const float *voxel_J,
+                                  const float *tfs, const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
+                                  float cvg_thresh, float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
+                                  int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, bool with_jinv,
+                                  hipStream_t s) {
+  IA_CHECK_ARG(P >= 0, "%s: P < 0", who);
+  IA_CHECK_ARG(n_cand, "%s: n_cand is null", who);
+  if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(xd && voxel_J && tfs && grid && cand_xc && pt_off && pt_cnt && (cand_Jinv || !with_jinv), "%s: null pointer", who);
+  BoneIds b;
+  IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "%s: bad bone ids / n_init=%d", who, n_init);
+  const dim3 grd(ia_div_up(P, IA_SEARCH_NP)), blk(IA_SEARCH_THREADS);
+  const SnarfGridDev g = ia_make_grid_dev(grid);
+  ia_prof_begin(IA_PROF_SEARCH, s);
+  if (with_jinv)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<2>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
+                       cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
+                       (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
+                       ia_prof_units(IA_PROF_SEARCH), cand_Jinv);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
+                       cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
+                       (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
+                       ia_prof_units(IA_PROF_SEARCH), (float *)nullptr);
+  ia_prof_end(IA_PROF_SEARCH, s);
+  IA_LAUNCH_CHECK("k_search<compact>");
   return IA_OK;
 }
 
@@ -723,22 +763,20 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
                                        int n_init, const ia_snarf_grid *grid, float cvg_thresh,
                                        float dvg_thresh, float *cand_xc, int32_t cand_cap, int32_t *pt_off,
                                        uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, void *stream) {
-  IA_CHECK_ARG(P >= 0, "ia_snarf_search_compact: P < 0");
-  IA_CHECK_ARG(n_cand, "ia_snarf_search_compact: n_cand is null");
-  hipStream_t s = (hipStream_t)stream;
-  if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
-  if (P == 0) return IA_OK;
-  IA_CHECK_ARG(xd && voxel_J && tfs && grid && cand_xc && pt_off && pt_cnt, "ia_snarf_search_compact: null pointer");
-  BoneIds b;
-  IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search_compact: bad bone ids / n_init=%d", n_init);
-  ia_prof_begin(IA_PROF_SEARCH, s);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0, s, xd, P,
-                     n_pts_dev, voxel_J, tfs, b, n_init, ia_make_grid_dev(grid), cvg_thresh * cvg_thresh,
-                     dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr,
-                     (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand, ia_prof_units(IA_PROF_SEARCH));
-  ia_prof_end(IA_PROF_SEARCH, s);
-  IA_LAUNCH_CHECK("k_search<1>");
-  return IA_OK;
+  return ia_search_compact_impl("ia_snarf_search_compact", xd, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, cvg_thresh,
+                                dvg_thresh, cand_xc, nullptr, cand_cap, pt_off, pt_cnt, n_cand, zero_counter, false,
+                                (hipStream_t)stream);
+}
+
+extern "C" int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
+                                            const float *voxel_J, const float *tfs, const int32_t *bone_ids,
+                                            int n_init, const ia_snarf_grid *grid, float cvg_thresh,
+                                            float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
+                                            int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter,
+                                            void *stream) {
+  return ia_search_compact_impl("ia_snarf_search_compact_jinv", xd, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid,
+                                cvg_thresh, dvg_thresh, cand_xc, cand_Jinv, cand_cap, pt_off, pt_cnt, n_cand, zero_counter,
+                                true, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -761,8 +799,9 @@ __device__ __forceinline__ float id_border_index(float g, int size) {
 
 __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
     const float *__restrict__ xc, const float *__restrict__ J_inv, const uint8_t *__restrict__ valid,
-    const float *__restrict__ grad, long n, const float *__restrict__ voxel_w, SnarfGridDev g,
-    float *__restrict__ partial) {
+    const float *__restrict__ grad, long n, const int32_t *__restrict__ n_dev, const float *__restrict__ voxel_w,
+    SnarfGridDev g, float *__restrict__ partial) {
+  if (n_dev) n = min(n, (long)*n_dev);   // compact candidate lists: device-side live count, no validity mask
   __shared__ float s_w[IA_ID_THREADS][25];   // +1: the 24-float rows start in different banks
   __shared__ float s_vh[IA_ID_THREADS][13];
   const int tid = threadIdx.x;
@@ -770,7 +809,7 @@ __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
   float acc0 = 0.f, acc1 = 0.f;              // outputs tid and tid + 256 of the 288 (bone, row, col) sums
   for (long base = (long)blockIdx.x * IA_ID_THREADS; base < n; base += (long)gridDim.x * IA_ID_THREADS) {
     const long i = base + tid;
-    const bool ok = i < n && valid[i];
+    const bool ok = i < n && (!valid || valid[i]);
     float w[24], vh[12];
 #pragma unroll
     for (int k = 0; k < 24; k++) w[k] = 0.f;
@@ -844,18 +883,32 @@ static int ia_implicit_blocks(long n) {
 
 extern "C" size_t ia_snarf_implicit_bwd_workspace_bytes(long n) { return (size_t)ia_implicit_blocks(n) * 288 * sizeof(float); }
 
-extern "C" int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *valid, const float *grad_xc,
-                                     long n, const float *voxel_w, const ia_snarf_grid *grid, float *d_tfs, void *ws,
-                                     size_t ws_bytes, void *stream) {
-  IA_CHECK_ARG(n >= 0, "ia_snarf_implicit_bwd: n < 0");
+static int ia_implicit_bwd_impl(const char *who, const float *xc, const float *J_inv, const uint8_t *valid,
+                                const float *grad_xc, long n, const int32_t *n_dev, const float *voxel_w,
+                                const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes, hipStream_t s) {
+  IA_CHECK_ARG(n >= 0, "%s: n < 0", who);
   if (n == 0) return IA_OK;
-  IA_CHECK_ARG(xc && J_inv && valid && grad_xc && voxel_w && grid && d_tfs && ws, "ia_snarf_implicit_bwd: null pointer");
-  if (ws_bytes < ia_snarf_implicit_bwd_workspace_bytes(n)) return ia_set_error(IA_ERR_WORKSPACE, "ia_snarf_implicit_bwd: workspace too small");
+  IA_CHECK_ARG(xc && J_inv && (valid || n_dev) && grad_xc && voxel_w && grid && d_tfs && ws, "%s: null pointer", who);
+  if (ws_bytes < ia_snarf_implicit_bwd_workspace_bytes(n)) return ia_set_error(IA_ERR_WORKSPACE, "%s: workspace too small", who);
   const int blocks = ia_implicit_blocks(n);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_implicit_bwd, dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, voxel_w,
+  hipLaunchKernelGGL(k_implicit_bwd, dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev, voxel_w,
                      ia_make_grid_dev(grid), static_cast<float *>(ws));
   hipLaunchKernelGGL(k_implicit_bwd_reduce, dim3(1), dim3(288), 0, s, static_cast<const float *>(ws), blocks, d_tfs);
   IA_LAUNCH_CHECK("k_implicit_bwd");
   return IA_OK;
+}
+
+extern "C" int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *valid, const float *grad_xc,
+                                     long n, const float *voxel_w, const ia_snarf_grid *grid, float *d_tfs, void *ws,
+                                     size_t ws_bytes, void *stream) {
+  return ia_implicit_bwd_impl("ia_snarf_implicit_bwd", xc, J_inv, valid, grad_xc, n, nullptr, voxel_w, grid, d_tfs, ws,
+                              ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *cand_Jinv, const float *grad_xc, long cap,
+                                             const int32_t *n_cand, const float *voxel_w, const ia_snarf_grid *grid,
+                                             float *d_tfs, void *ws, size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(n_cand, "ia_snarf_implicit_bwd_compact: n_cand is null");
+  return ia_implicit_bwd_impl("ia_snarf_implicit_bwd_compact", cand_xc, cand_Jinv, nullptr, grad_xc, cap, n_cand, voxel_w,
+                              grid, d_tfs, ws, ws_bytes, (hipStream_t)stream);
 }

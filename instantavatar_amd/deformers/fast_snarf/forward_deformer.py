@@ -205,6 +205,32 @@ class _ImplicitDiffFn(torch.autograd.Function):
         return d_tfs, None, None, None, None
 
 
+class _ImplicitDiffCompactFn(torch.autograd.Function):
+    """`_ImplicitDiffFn` over the compact candidate list of `ia_snarf_search_compact_jinv`: value = the roots,
+    gradient to tfs through `ia_snarf_implicit_bwd_compact` (live count on the device, no mask, no host read)."""
+
+    @staticmethod
+    def forward(ctx, tfs, cand_xc, cand_Jinv, n_cand, deformer):
+        ctx.deformer = deformer
+        ctx.save_for_backward(cand_xc, cand_Jinv, n_cand)
+        ctx.tfs_shape = tfs.shape
+        return cand_xc.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, J_inv, n_cand = ctx.saved_tensors
+        d = ctx.deformer
+        L = _lib.lib()
+        cap = xc.shape[0]
+        gg = g.reshape(-1, 3).float().contiguous()
+        d_tfs = torch.zeros(ctx.tfs_shape, device=xc.device)
+        ws = torch.empty(int(L.ia_snarf_implicit_bwd_workspace_bytes(cap)), dtype=torch.uint8, device=xc.device)
+        _lib.check(L.ia_snarf_implicit_bwd_compact(_lib.ptr(xc), _lib.ptr(J_inv), _lib.ptr(gg), cap, _lib.ptr(n_cand),
+                                                   _lib.ptr(d.lbs_voxel_final), C.byref(d.grid_desc()), _lib.ptr(d_tfs),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_implicit_bwd_compact")
+        return d_tfs, None, None, None, None
+
+
 def skinning_mask(x, w, tfs, inverse=False):
     """x [P,3], w [P,24], tfs [1,24,4,4] -> skinned points [P,3]."""
     T = torch.einsum("pn,nij->pij", w, tfs[0])

@@ -263,22 +263,46 @@ class SNARFDeformer():
                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_deform_query")
         return rgb, sigma
 
-    def search_compact(self, pts, n_pts_dev=None):
+    def search_compact(self, pts, n_pts_dev=None, cap=None, want_J_inv=False):
         """Search + filter + compaction (`ia_snarf_search_compact`): returns a dict with
-        cand_xc [cap,3], pt_off [P], pt_cnt [P] and n_cand (device int32[1])."""
+        cand_xc [cap,3], pt_off [P], pt_cnt [P] and n_cand (device int32[1]); with `want_J_inv`
+        (`ia_snarf_search_compact_jinv`) also cand_Jinv [cap,3,3], the Broyden J_inv of every
+        surviving root -- the input of the implicit differentiation when tfs carries a gradient."""
         pts = pts.detach().reshape(-1, 3).float().contiguous()
         P = pts.shape[0]
         k = len(self.deformer.init_bones)
         dev = pts.device
-        out = dict(cand_xc=torch.empty((P * k, 3), device=dev), pt_off=torch.empty(P, dtype=torch.int32, device=dev),
+        cap = P * k if cap is None else min(int(cap), P * k)
+        out = dict(cand_xc=torch.empty((cap, 3), device=dev), pt_off=torch.empty(P, dtype=torch.int32, device=dev),
                    pt_cnt=torch.empty(P, dtype=torch.uint8, device=dev), n_cand=torch.zeros(1, dtype=torch.int32, device=dev))
         tfs = self.tfs.detach().float().contiguous()
-        _lib.check(_lib.lib().ia_snarf_search_compact(_lib.ptr(pts), P, _lib.ptr(n_pts_dev), _lib.ptr(self.deformer.voxel_J_cl),
-                                                      _lib.ptr(tfs), self.deformer._bones_c, k,
-                                                      C.byref(self.deformer.grid_desc()), 1e-5, 1e-1, _lib.ptr(out["cand_xc"]),
-                                                      P * k, _lib.ptr(out["pt_off"]), _lib.ptr(out["pt_cnt"]),
-                                                      _lib.ptr(out["n_cand"]), 0, _lib.stream()), "ia_snarf_search_compact")
+        L = _lib.lib()
+        head = (_lib.ptr(pts), P, _lib.ptr(n_pts_dev), _lib.ptr(self.deformer.voxel_J_cl), _lib.ptr(tfs),
+                self.deformer._bones_c, k, C.byref(self.deformer.grid_desc()), 1e-5, 1e-1, _lib.ptr(out["cand_xc"]))
+        tail = (cap, _lib.ptr(out["pt_off"]), _lib.ptr(out["pt_cnt"]), _lib.ptr(out["n_cand"]), 0, _lib.stream())
+        if want_J_inv:
+            out["cand_Jinv"] = torch.empty((cap, 3, 3), device=dev)
+            _lib.check(L.ia_snarf_search_compact_jinv(*head, _lib.ptr(out["cand_Jinv"]), *tail), "ia_snarf_search_compact_jinv")
+        else:
+            _lib.check(L.ia_snarf_search_compact(*head, *tail), "ia_snarf_search_compact")
         return out
+
+    def candidates_with_grad(self, sc):
+        """The compact candidate positions of `search_compact`, carrying -- when the bone transforms are under
+        optimisation (`tfs.requires_grad`: SMPL refinement, DNeRF.py:113-128) -- the gradient of the implicit
+        differentiation of deformer_torch.py:50-67 (`ia_snarf_implicit_bwd_compact`); plain tensor otherwise."""
+        if "cand_Jinv" not in sc:
+            return sc["cand_xc"]
+        from .fast_snarf.forward_deformer import _ImplicitDiffCompactFn
+        return _ImplicitDiffCompactFn.apply(self.tfs, sc["cand_xc"], sc["cand_Jinv"], sc["n_cand"], self.deformer)
+
+    def fused_train_route(self):
+        """True when the fused training route covers the current state: always without a gradient to tfs; with one,
+        for the implicit differentiation of version 1 (version 2's closed-form inverse skinning, deformer_torch.py:68-75,
+        stays on the dense torch route)."""
+        if getattr(self, "force_dense_train", False):   # tests: the route that keeps the reference's dense structure
+            return False
+        return not self.tfs.requires_grad or self.deformer.version == 1
 
     #: number of `query_train_fused` calls whose candidates exceeded the capacity (they were dropped); the
     #: capacity doubles after every such call (deferred check, see `_cand_count_check`)
@@ -316,10 +340,12 @@ class SNARFDeformer():
         P = pts.shape[0]
         k = len(self.deformer.init_bones)
         self._cand_count_check()
-        sc = self.search_compact(pts)
         cap = min(P * k, self.train_cand_capacity)
+        want_J_inv = self.tfs.requires_grad and torch.is_grad_enabled()
+        with torch.no_grad():
+            sc = self.search_compact(pts, cap=cap, want_J_inv=want_J_inv)
         from ..training import field_autograd
-        rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cap], n_dev=sc["n_cand"])
+        rgb_c, sig_c = field_autograd(net, self.candidates_with_grad(sc), n_dev=sc["n_cand"])
         self._cand_count_post(sc["n_cand"], cap)
         arg = torch.empty(P, dtype=torch.int32, device=pts.device)
         sig_d = sig_c.detach().float().contiguous()
@@ -329,7 +355,7 @@ class SNARFDeformer():
 
     def deform_train(self, pts, model):
         """snarf_deformer.py:143-159."""
-        if self._is_native_field(model) and pts.is_cuda and not self.tfs.requires_grad:
+        if self._is_native_field(model) and pts.is_cuda and self.fused_train_route():
             return self.query_train_fused(pts.type(self.dtype), model)
         pts_cano_all, valid = self.deform(pts.type(self.dtype), eval_mode=False)
         rgb_cano = torch.zeros_like(pts_cano_all).float()

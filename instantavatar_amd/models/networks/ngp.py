@@ -207,9 +207,19 @@ class NeRFNGPNet(nn.Module):
         enc, col = self._half_params()
         if max_samples:
             self._reserve_encode_workspace(max_samples, enc.device)
+        if self._desc is not None:
+            # centre / scale are host copies inside the descriptor: a checkpoint load or a broadcast that overwrote the
+            # two buffers in place (only `mark_updated()` follows those) must reach it too -- keyed on the tensors'
+            # versions, so the device is read back only when they really changed.  (Kernel arguments of an already
+            # captured HIP graph keep the old values: re-capture after loading a checkpoint with another bbox.)
+            cs = self._center_scale_host()
+            if self._cs_key != getattr(self, "_desc_cs_key", None):
+                self._desc.center[:], self._desc.scale[:] = cs
+                self._desc_cs_key = self._cs_key
         if self._desc is None:
             f = _lib.Field()
             f.center[:], f.scale[:] = self._center_scale_host()
+            self._desc_cs_key = self._cs_key
             f.hash = self.hash_desc
             e, c = enc.data_ptr(), col.data_ptr()
             f.sig_w1 = e

@@ -154,16 +154,17 @@ class DensityGrid(torch.nn.Module):
         return sd.reshape(G, G, G)
 
     # -- training-time grid ---------------------------------------------------------
-    def update(self, deformer, net, step, reduce_hook=None, jitter=None):
+    def update(self, deformer, net, step, reduce_hook=None, jitter=None, differentiable=True):
         """density_grid.py:46-92.  `reduce_hook(density_cached)` (optional) runs between the EMA update
         and the thresholding: data-parallel training MAX-reduces the cache there, so `density_field`,
         the returned `valid` mask and the occupancy bits all come from the reduced cache, once.
-        `jitter` ([G,G,G,3] in [0,1)) may be injected for reproducible tests (reference: torch.rand_like)."""
+        `jitter` ([G,G,G,3] in [0,1)) may be injected for reproducible tests (reference: torch.rand_like).
+        `differentiable=False`: the probe is not recorded for autograd (callers that drop the regulariser)."""
         G = self.grid_size
         if jitter is None:
             jitter = torch.rand_like(self.coords)
         coords = denormalize(self.coords + jitter.reshape(self.coords.shape).to(self.coords) / G, self.aabb)
-        with torch.enable_grad():
+        with (torch.enable_grad() if differentiable else torch.no_grad()):
             _, density = deformer(coords.reshape(-1, 3), net, eval_mode=False)
         density = density.clip(min=0).reshape(coords.shape[:-1])
         old = self.density_field

@@ -286,25 +286,30 @@ class Raymarcher(torch.nn.Module):
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         st = dict(s_pts=torch.empty((cap, 3), device=dev), s_z=torch.empty(cap, device=dev), s_slot=i32(cap),
                   ray_off=i32(n), ray_cnt=i32(n), n_samples=i32(1), near=near, far=far, n=n, S=S)
-        jitter = torch.rand((n, S), device=dev)                                    # :156
+        draws = getattr(self, "train_draws", None) or {}                           # injected by reproducible tests
+        jitter = draws["ray_jitter"].to(dev).float().reshape(n, S).contiguous() if "ray_jitter" in draws else torch.rand((n, S), device=dev)  # :156
+        want_J_inv = deformer.tfs.requires_grad and torch.is_grad_enabled()
         with torch.no_grad():
             _lib.check(L.ia_march_train_compact(_lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), n, _lib.ptr(grid.occ_bits),
                                                 C.byref(occ), S, _lib.ptr(jitter), _lib.ptr(st["s_pts"]), _lib.ptr(st["s_z"]),
                                                 _lib.ptr(st["s_slot"]), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]),
                                                 _lib.ptr(st["n_samples"]), cap, _lib.stream()), "ia_march_train_compact")
-            sc = deformer.search_compact(st["s_pts"], n_pts_dev=st["n_samples"])
+            k = len(deformer.deformer.init_bones)
+            cand_cap = min(cap * k, self.train_cand_capacity)
+            sc = deformer.search_compact(st["s_pts"], n_pts_dev=st["n_samples"], cap=cand_cap,
+                                         want_J_inv=want_J_inv)
         # No host read: the field runs on a capacity-sized candidate buffer with the device-side
         # count (kernels clamp to it).  The counts of step i are copied to pinned memory and looked
         # at during step i+1: a step whose candidates exceeded the capacity (they were dropped) is
         # counted in `train_overflow` and the capacity grows for the following steps.
         self._train_counts_check()
-        k = len(deformer.deformer.init_bones)
-        cand_cap = min(cap * k, self.train_cand_capacity)
         st.update(pt_off=sc["pt_off"], pt_cnt=sc["pt_cnt"], n_init=k,
                   bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
-                  noise=torch.randn((n, S), device=dev) if noise > 0 else None, noise_scale=float(noise))   # :167
+                  noise=(draws["noise"].to(dev).float().reshape(n, S).contiguous() if "noise" in draws else torch.randn((n, S), device=dev))
+                  if noise > 0 else None, noise_scale=float(noise))                # :167
         from ..training import field_autograd
-        rgb_c, sig_c = field_autograd(net, sc["cand_xc"][:cand_cap], n_dev=sc["n_cand"])
+        # (SMPL refinement: the candidates carry the implicit-differentiation gradient to tfs, deformer_torch.py:50-67)
+        rgb_c, sig_c = field_autograd(net, deformer.candidates_with_grad(sc), n_dev=sc["n_cand"])
         self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)
         color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
         return {
@@ -368,7 +373,7 @@ class Raymarcher(torch.nn.Module):
         """raymarcher_acc.py:140-186: fixed MAX_SAMPLES slots per ray from
         `ia_raymarch_train`, jitter, masked field evaluation, cumprod compositing."""
         pair = self._fused or _find_native_pair(model)
-        if pair is not None and rays.o.is_cuda and not pair[0].tfs.requires_grad:
+        if pair is not None and rays.o.is_cuda and pair[0].fused_train_route():
             return self.render_train_fused(rays, pair[0], pair[1], noise, bg_color)
         L = _lib.lib()
         _lib.require_cuda(rays.o)
@@ -388,7 +393,9 @@ class Raymarcher(torch.nn.Module):
                                            _lib.ptr(step_size.detach()), N_step, _lib.ptr(z_vals), _lib.stream()),
                        "ia_raymarch_train")
         mask = z_vals > 0
-        z_vals = z_vals + torch.rand_like(z_vals) * step_size[:, None]
+        draws = getattr(self, "train_draws", None) or {}
+        jit = draws["ray_jitter"].to(z_vals).reshape(z_vals.shape) if "ray_jitter" in draws else torch.rand_like(z_vals)
+        z_vals = z_vals + jit * step_size[:, None]
         pts = z_vals[..., None] * rays_d[:, None] + rays_o[:, None]
         rgb_vals = torch.zeros_like(pts, dtype=torch.float32)
         sigma_vals = -torch.ones_like(rgb_vals[..., 0], dtype=torch.float32) * 1e3
@@ -397,7 +404,8 @@ class Raymarcher(torch.nn.Module):
             rgb_vals = rgb_vals.masked_scatter(mask[..., None].expand_as(rgb_vals), r.float())
             sigma_vals = sigma_vals.masked_scatter(mask, s.float())
         if noise > 0:
-            sigma_vals = sigma_vals + noise * torch.randn_like(sigma_vals)
+            sigma_vals = sigma_vals + noise * (draws["noise"].to(sigma_vals).reshape(sigma_vals.shape) if "noise" in draws
+                                               else torch.randn_like(sigma_vals))
         dists = torch.ones_like(sigma_vals) * step_size[:, None]
         weights, transmittance = composite(sigma_vals.reshape(z_vals.shape), dists, thresh=0)
         no_hit = transmittance[..., -1]

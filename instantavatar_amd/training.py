@@ -57,10 +57,6 @@ class _FieldFn(torch.autograd.Function):
         ctx.need_dx = x.requires_grad
         ctx.n_dev = n_dev
         ctx.save_for_backward(xc, acts, rgb)
-        from . import parallel
-        red = parallel.current_reducer()
-        if red is not None:
-            red.field_forward()   # the last backward of the step starts the bucketed all-reduce
         return rgb, sigma
 
     @staticmethod
@@ -191,6 +187,13 @@ def _mlp_backward_gemm(net, acts, rgb, d_rgb, d_sigma, S, g_enc, g_col):
 
 
 def field_autograd(net, x, n_dev=None):
+    if torch.is_grad_enabled() and (net.encoder.params.requires_grad or net.color_net.params.requires_grad or x.requires_grad):
+        from . import parallel
+        red = parallel.current_reducer()
+        if red is not None:
+            # the LAST field backward of the step starts the bucketed all-reduce; only calls that are recorded into the
+            # autograd graph are counted (a no-grad probe has no backward and would keep the count from reaching zero)
+            red.field_forward()
     return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net, n_dev)
 
 
@@ -384,10 +387,12 @@ def all_reduce_grads(model, world_size, reducer=None):
     (reducer or GradReducer(world_size)).finish([p for p in model.parameters()])
 
 
-def update_density_grid(model, world_size=1, jitter=None):
+def update_density_grid(model, world_size=1, jitter=None, differentiable=True):
     """DNeRFModel.update_density_grid (DNeRF.py:99-110); with several ranks the cached densities are
     MAX-reduced between the EMA update and the thresholding (DensityGrid.update's reduce hook), so every
-    rank thresholds -- and regularises with -- the same field, once."""
+    rank thresholds -- and regularises with -- the same field, once.
+    differentiable=False: the probe runs without recording an autograd graph (the refine configuration drops the
+    regulariser, DNeRF.py:137: the graph over 262 144 probe points would be built and thrown away)."""
     N = 1 if getattr(model.renderer, "smpl_init", False) else 20   # DNeRF.py:100
     if model.global_step % N != 0:
         return None
@@ -396,7 +401,8 @@ def update_density_grid(model, world_size=1, jitter=None):
     if world_size > 1:
         from .parallel import reduce_density_cache
         hook = lambda cached: reduce_density_cache(cached, world_size)
-    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook, jitter=jitter)
+    density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook, jitter=jitter,
+                                 differentiable=differentiable)
     inv = (~valid).to(density.dtype)   # mean over the cells outside the grid, without a boolean-mask gather (host sync)
     reg = N * (density * inv).sum() / inv.sum().clamp(min=1.0)
     if model.global_step < 500:
@@ -404,10 +410,16 @@ def update_density_grid(model, world_size=1, jitter=None):
     return reg
 
 
-def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False, _capturing=False):
-    """DNeRFModel.training_step (DNeRF.py:112-161) for the non-refine configs.
+def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=False, _capturing=False, draws=None):
+    """DNeRFModel.training_step (DNeRF.py:112-161), all four configurations: plain (SNARF_NGP.yaml), the fit stage
+    (SMPLDeformer + SMPLParamEmbedding) and refinement (SNARF_NGP_refine.yaml: SNARFDeformer + SMPLParamEmbedding,
+    `is_refine` -- no sigma noise, no density regulariser; the gradient reaches the SMPL tables through tfs by the
+    implicit differentiation of the roots, on the fused route).
     `_capturing`: the call is being recorded into a HIP graph (GraphedTrainStep): nothing executes, so the
-    host-side step counter is left alone."""
+    host-side step counter is left alone.
+    `draws`: optional dict of injected random tensors for reproducible tests -- `grid_jitter` [64,64,64,3]
+    (density_grid.py:47), `ray_jitter` [n_rays, MAX_SAMPLES] (raymarcher_acc.py:156), `noise` [n_rays, MAX_SAMPLES] (:167)."""
+    draws = draws or {}
     from . import parallel
     if getattr(model, "SMPL_param", None) is not None:            # DNeRF.py:113-128 (optimize_SMPL.enable)
         batch = dict(batch)
@@ -425,10 +437,14 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     reducer = parallel.GradReducer(world_size)
     parallel.set_current_reducer(reducer if world_size > 1 else None)
     try:
-        reg = update_density_grid(model, world_size)
+        reg = update_density_grid(model, world_size, jitter=draws.get("grid_jitter"), differentiable=not is_refine)
         model.net_coarse.initialize(model.deformer.bbox)
         use_noise = model.global_step < 1000 and not is_refine
-        predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
+        model.renderer.train_draws = draws if draws else None
+        try:
+            predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
+        finally:
+            model.renderer.train_draws = None
         losses = loss_fn(predicts, batch)
         if reg is not None and not is_refine:
             losses["reg"] = reg

@@ -29,9 +29,50 @@ def _np(t):
     return t.detach().numpy() if torch.is_tensor(t) else np.asarray(t)
 
 
-def install(oracle, field_holder):
+def torch_encoder(xn, enc, hd, n_levels=16):
+    """fp32 restatement of tcnn's NetworkWithInputEncoding (HashGrid -> 32-64-16 MLP) on unit coordinates, differentiable
+    w.r.t. xn and the flat parameter vector enc = [W1 64x2L | W2 16x64 | table]: what tcnn's backward computes (its
+    input gradient is the derivative of the trilinear weights, floor() has none), without its fp16 rounding."""
+    n1 = 64 * 2 * n_levels
+    W1, W2, table = enc[:n1].view(64, 2 * n_levels), enc[n1:n1 + 1024].view(16, 64), enc[n1 + 1024:].view(-1, 2)
+    feats = []
+    for l in range(n_levels):
+        scale, res = float(hd.scale[l]), int(hd.res[l])
+        off, size = int(hd.offset[l]), int(hd.offset[l + 1] - hd.offset[l])
+        pos = xn * scale + 0.5
+        g = pos.detach().floor()
+        w = pos - g
+        g = g.long()
+        acc = 0
+        for idx in range(8):
+            c = [g[:, d] + ((idx >> d) & 1) for d in range(3)]
+            wt = 1
+            for d in range(3):
+                wt = wt * (w[:, d] if (idx >> d) & 1 else 1 - w[:, d])
+            if res ** 3 <= size:
+                index = (c[0] + c[1] * res + c[2] * res * res) % size
+            else:
+                index = ((c[0] * 1) ^ ((c[1] * 2654435761) & 0xffffffff) ^ ((c[2] * 805459861) & 0xffffffff)) % size
+            acc = acc + wt[:, None] * table[off + index]
+        feats.append(acc)
+    h1 = torch.relu(torch.cat(feats, dim=1) @ W1.t())
+    return h1 @ W2.t()
+
+
+def torch_color(in15, col):
+    """fp32 restatement of tcnn's colour Network (15 -> pad 16 with 1 -> 64 -> 64 -> 16, sigmoid, 3 used)."""
+    Wc1, Wc2, Wc3 = col[:1024].view(64, 16), col[1024:5120].view(64, 64), col[5120:6144].view(16, 64)
+    cin = torch.cat([in15, torch.ones_like(in15[:, :1])], dim=1)
+    c2 = torch.relu(torch.relu(cin @ Wc1.t()) @ Wc2.t())
+    return torch.sigmoid((c2 @ Wc3.t())[:, :3])
+
+
+def install(oracle, field_holder, differentiable=False):
     """Install the stubs and return the imported reference modules.  field_holder: dict with key "field" (oracle Field
-    struct) used by the tinycudann stand-in."""
+    struct) used by the tinycudann stand-in.  differentiable: the two tcnn stand-ins carry REAL flat parameter vectors
+    (field_holder["fp"], the dict of synthetic.make_field) and a backward pass -- forward values still come from the
+    oracle's C restatement (fp16 rounding points of tcnn), gradients from the fp32 formula above, which is what the
+    training-step goldens (make_refine_golden.py) need."""
     sys.dont_write_bytecode = True
     C = oracle.C
     L = oracle.lib()
@@ -66,7 +107,7 @@ def install(oracle, field_holder):
     # ---- the ray-march extension (raymarcher_acc.py:13-16) ----
     def f32(t):
         assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
-        return t.numpy()
+        return t.detach().numpy()   # (rays carry a gradient to w2s when the SMPL parameters are optimised; the kernels have none)
 
     def raymarch_test(rays_o, rays_d, near, far, alive, density_field, scale, offset, step_size, N_step):
         Na = alive.shape[0]
@@ -136,6 +177,73 @@ def install(oracle, field_holder):
 
         def forward(self, x):
             return torch.as_tensor(oracle.tcnn_color(field_holder["field"], _np(x.float())))
+    if differentiable:
+        fp = field_holder["fp"]
+        flat = lambda *ks: torch.cat([torch.as_tensor(np.asarray(fp[k], np.float32).reshape(-1)) for k in ks])
+
+        def current_field(enc, col):
+            """oracle Field struct of the CURRENT parameter values (rebuilt after every optimiser step)"""
+            key = (enc._version, col._version)
+            if field_holder.get("key") != key:
+                n1 = 64 * 2 * fp["n_levels"]
+                e, c = enc.detach().numpy(), col.detach().numpy()
+                d = dict(fp)
+                d.update(sig_w1=e[:n1].astype(np.float16), sig_w2=e[n1:n1 + 1024].astype(np.float16),
+                         table=e[n1 + 1024:].astype(np.float16), col_w1=c[:1024].astype(np.float16),
+                         col_w2=c[1024:5120].astype(np.float16), col_w3=c[5120:6144].astype(np.float16))
+                field_holder["field"], field_holder["keep"] = oracle.make_field(d)
+                field_holder["key"] = key
+            return field_holder["field"]
+
+        class _EncFn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, enc):
+                ctx.save_for_backward(x, enc)
+                return torch.as_tensor(oracle.tcnn_encoder(current_field(enc, field_holder["col"]), _np(x.float())))
+
+            @staticmethod
+            def backward(ctx, g):
+                x, enc = ctx.saved_tensors
+                with torch.enable_grad():
+                    x2, e2 = x.detach().requires_grad_(True), enc.detach().requires_grad_(True)
+                    out = torch_encoder(x2, e2, field_holder["field"].hash, fp["n_levels"])
+                    gx, ge = torch.autograd.grad(out, [x2, e2], g)
+                return gx, ge
+
+        class _ColFn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, col):
+                ctx.save_for_backward(x, col)
+                return torch.as_tensor(oracle.tcnn_color(current_field(field_holder["enc"], col), _np(x.float())))
+
+            @staticmethod
+            def backward(ctx, g):
+                x, col = ctx.saved_tensors
+                with torch.enable_grad():
+                    x2, c2 = x.detach().requires_grad_(True), col.detach().requires_grad_(True)
+                    gx, gc = torch.autograd.grad(torch_color(x2, c2), [x2, c2], g)
+                return gx, gc
+
+        class NetworkWithInputEncoding(torch.nn.Module):   # noqa: F811
+            def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config):
+                super().__init__()
+                assert (n_input_dims, n_output_dims, encoding_config["n_levels"]) == (3, 16, 16)
+                self.params = torch.nn.Parameter(flat("sig_w1", "sig_w2", "table"))
+                field_holder["enc"] = self.params
+
+            def forward(self, x):
+                return _EncFn.apply(x, self.params)
+
+        class Network(torch.nn.Module):                    # noqa: F811
+            def __init__(self, n_input_dims, n_output_dims, network_config):
+                super().__init__()
+                assert (n_input_dims, n_output_dims) == (15, 3)
+                self.params = torch.nn.Parameter(flat("col_w1", "col_w2", "col_w3"))
+                field_holder["col"] = self.params
+
+            def forward(self, x):
+                return _ColFn.apply(x, self.params)
+
     tcnn = types.ModuleType("tinycudann")
     tcnn.NetworkWithInputEncoding, tcnn.Network = NetworkWithInputEncoding, Network
     sys.modules["tinycudann"] = tcnn

@@ -1,4 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_one.sh <pytest args>
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest "$@" > gpurun_out/pytest_one.log 2>&1; tail -40 gpurun_out/pytest_one.log | cut -c1-300
+# one pytest selection on the GPU box: tools/gpu_one.sh <pytest args>
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 900 python -m pytest "$@" -q -s > $O/one.log 2>&1; tail -60 $O/one.log
