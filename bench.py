@@ -94,13 +94,18 @@ def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
 
 
 def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, n_rays=4096, warmup=3, graphed=True,
-                     sampler="patch"):
+                     sampler="patch", refine=False):
     """train.py analogue (configs 2/4): one frame + 4096 rays per step and rank, targets rendered from the synthetic
     field, Adam(lr 1e-2), occupancy update every 20 steps, gradient all-reduce over RCCL.
     sampler="patch": the reference's default data path (confs/SNARF_NGP.yaml -> sampler: patch, 4 patches of 32 x 32
     anchored on mask pixels, random background; peoplesnapshot.py:99-151) through the device-resident frames
     (datasets.DeviceFrames, utils.sampler.PatchSampler).  sampler="uniform": 4096 rays drawn uniformly over the image
-    (the lighter workload rounds 1-2 quoted; kept as a secondary figure)."""
+    (the lighter workload rounds 1-2 quoted; kept as a secondary figure).
+    refine=True: BASELINE config 4 (confs/SNARF_NGP_refine.yaml): an already formed field (the synthetic one, not re-initialised),
+    per-frame SMPL parameters as trainable embedding tables started 0.03 rad / 1 cm off the poses the targets were rendered
+    at, `sampler: edge` (EdgeSampler 4096 / 0.6 / 0.3 / 16), NGPLoss, Adam with the third parameter group at lr 1e-5, no
+    sigma noise and no density regulariser (is_refine); the gradient reaches the SMPL tables through tfs by implicit
+    differentiation of the Broyden roots on the fused route."""
     from instantavatar_amd.pipeline import build_synthetic_model, make_batch
     from instantavatar_amd.training import GraphedTrainStep, NeRFLoss, configure_optimizer
     n_frames = 4
@@ -111,25 +116,36 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             rgb, _, alpha, _ = model.render_image_fast(b, (res, res))
             targets.append((b, rgb.reshape(1, -1, 3), alpha.reshape(1, -1)))
     trainee, _, _ = build_synthetic_model(dev, resolution=128, n_levels=16)
-    trainee.net_coarse.reset_parameters()
+    smpl = dict(betas=np.zeros((1, 10), np.float32), body_pose=poses[:n_frames, 3:].copy(),
+                global_orient=poses[:n_frames, :3].copy(), transl=tr[:n_frames].copy())
+    if refine:
+        from instantavatar_amd.models.structures.body_model_param import SMPLParamEmbedding
+        from instantavatar_amd.training import NGPLoss
+        rs = np.random.RandomState(99)
+        smpl = dict(smpl, body_pose=(smpl["body_pose"] + 0.03 * rs.randn(n_frames, 69)).astype(np.float32),
+                    global_orient=(smpl["global_orient"] + 0.03 * rs.randn(n_frames, 3)).astype(np.float32),
+                    transl=(smpl["transl"] + 0.01 * rs.randn(n_frames, 3)).astype(np.float32))
+        trainee.SMPL_param = SMPLParamEmbedding(**{k: torch.as_tensor(v.copy()) for k, v in smpl.items()}).to(dev)
+    else:
+        trainee.net_coarse.reset_parameters()
     trainee.train()
     from instantavatar_amd.parallel import broadcast_module_state
     broadcast_module_state(trainee, world_size)   # replicas identical to rank 0 (parameters and buffers), not by seed
-    opt = configure_optimizer(trainee)
-    loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+    opt = configure_optimizer(trainee, smpl_lr=1e-5) if refine else configure_optimizer(trainee)
+    loss_fn = (NGPLoss if refine else NeRFLoss)(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     # one rank: the step is replayed from a captured HIP graph (every 20th step, the occupancy update, runs eagerly);
     # several ranks: eager steps with the bucketed RCCL all-reduce started from inside the backward
-    stepper = GraphedTrainStep(trainee, opt, loss_fn, world_size=world_size, enabled=graphed)
-    if sampler == "patch":
+    stepper = GraphedTrainStep(trainee, opt, loss_fn, world_size=world_size, enabled=graphed, is_refine=refine)
+    if sampler in ("patch", "edge"):
         from instantavatar_amd.datasets.device_frames import DeviceFrames
-        from instantavatar_amd.utils.sampler import PatchSampler
+        from instantavatar_amd.utils.sampler import EdgeSampler, PatchSampler
         imgs = torch.stack([(t[1].reshape(res, res, 3).clamp(0, 1) * 255).round().to(torch.uint8) for t in targets])
         masks = torch.stack([(t[2].reshape(res, res) > 0.5).float() for t in targets])
         K = np.array([[2000.0 * res / 1080, 0, res / 2], [0, 2000.0 * res / 1080, res / 2], [0, 0, 1]])
-        smpl = dict(betas=np.zeros((1, 10), np.float32), body_pose=poses[:n_frames, 3:].copy(),
-                    global_orient=poses[:n_frames, :3].copy(), transl=tr[:n_frames].copy())
-        frames = DeviceFrames(imgs, masks, K, np.eye(4), smpl, PatchSampler(num_patch=4, patch_size=32, ratio_mask=1, dilate=0))
+        smp = (PatchSampler(num_patch=4, patch_size=32, ratio_mask=1, dilate=0) if sampler == "patch" else
+               EdgeSampler(num_sample=n_rays, ratio_mask=0.6, ratio_edge=0.3, kernel_size=16))     # confs/sampler/{patch,edge}.yaml
+        frames = DeviceFrames(imgs, masks, K, np.eye(4), smpl, smp)
         assert 4 * 32 * 32 == n_rays
 
         def step(i):   # (after the capture the sampler writes straight into the graph's static input tensors)
@@ -178,7 +194,12 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
         dt = float(t.item())
     r = trainee.renderer
     r._train_counts_check()
-    return {"it_per_sec": n_steps / dt, "rays_per_sec": n_steps * n_rays * world_size / dt, "steps": n_steps,
+    extra = {}
+    if refine:
+        moved = {k: float((getattr(trainee.SMPL_param, k).weight.detach().cpu() - torch.as_tensor(smpl[k])).abs().max()) for k in ("body_pose", "global_orient", "transl")}
+        extra = {"config": "SNARF_NGP_refine (SMPLParamEmbedding + SNARFDeformer, tfs.requires_grad, fused route, is_refine)",
+                 "smpl_tables_max_abs_change": moved, "train_overflow": int(r.train_overflow)}
+    return {**extra, "it_per_sec": n_steps / dt, "rays_per_sec": n_steps * n_rays * world_size / dt, "steps": n_steps,
             "rays_per_step_per_gpu": n_rays, "sampler": sampler, "mse_first": float(first), "mse_last": float(last),
             "samples_candidates_last_step": list(getattr(r, "last_train_counts", ()) or ()),
             "launch_mode": ("hip_graph (%d replays, %d eager steps)" % (stepper.replays, stepper.eager_steps)) if stepper.replays
@@ -681,6 +702,16 @@ def main():
             u = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph,
                                  sampler="uniform")
             result["train"]["uniform_rays"] = {k: u[k] for k in ("it_per_sec", "rays_per_sec", "mse_last", "samples_candidates_last_step", "launch_mode")}
+            # BASELINE config 4: SMPL refinement (its own try: the config-2 figures above survive a failure here)
+            try:
+                result["train"]["refine"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res,
+                                                             graphed=not args.no_graph, sampler="edge", refine=True)
+                if not args.no_graph and world_size == 1:
+                    e = train_throughput(model, dev, poses, tr, rank, world_size, max(args.train_steps // 2, 10), res=res, graphed=False,
+                                         sampler="edge", refine=True)
+                    result["train"]["refine"]["eager"] = {k: e[k] for k in ("it_per_sec", "launch_mode")}
+            except Exception as e:
+                result["train"]["refine"] = {"error": repr(e)[:300]}
             hj, hsrc = _profile_json("r02_pmc_hgbwd.json")
             if hj is not None:   # the training step's dominant kernel against the measured atomic-request ceiling (committed PMC pass)
                 result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc)

@@ -49,6 +49,7 @@ class DeviceFrames:
         self.smpl_params = {k: torch.as_tensor(np.asarray(v, np.float32), device=dev) for k, v in smpl_params.items()}
         self.sampler = sampler
         self.near, self.far = near, far
+        self._idx_all = torch.arange(N, device=dev)   # `idx_dev` of a batch is a one-element view: no host -> device copy per step
 
     @classmethod
     def from_arrays(cls, images_u8, masks, K, c2w, smpl_params, sampler, device, **kw):
@@ -143,12 +144,13 @@ class DeviceFrames:
             "betas": p["betas"][0][None], "global_orient": p["global_orient"][idx][None], "body_pose": p["body_pose"][idx][None],
             "transl": transl[None], "alpha": alpha.reshape(1, *shape), "bg_color": bg.reshape(1, *shape, 3),
             "idx": torch.tensor([idx]),   # host tensor: the trainer reads it as a Python int (renderer.idx) without a device sync
+            "idx_dev": self._idx_all[idx:idx + 1],   # the same index on the device: row of the SMPLParamEmbedding tables (DNeRF.py:114)
             "near": near.reshape(1, *shape), "far": far.reshape(1, *shape),
         }
         if out is not None:
             # SMPL parameters of the frame into the caller's tensors too; what was written in place is returned as the
             # caller's own tensor objects, so that `batch is out`-style identity checks downstream see no copy to make
-            for k in ("betas", "global_orient", "body_pose", "transl"):
+            for k in ("betas", "global_orient", "body_pose", "transl", "idx_dev"):
                 t = out.get(k)
                 if torch.is_tensor(t) and t.is_cuda and t.shape == res[k].shape:
                     t.copy_(res[k], non_blocking=True)

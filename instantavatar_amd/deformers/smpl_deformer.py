@@ -71,6 +71,13 @@ class SMPLDeformer():
         self.vertices = ((out.vertices @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]).float().contiguous()
         self.w2s = w2s
 
+    def release_graph(self):
+        """drop the autograd graph held by the per-frame attributes (see SNARFDeformer.release_graph)"""
+        for name in ("T_inv", "vertices", "w2s"):
+            v = getattr(self, name, None)
+            if torch.is_tensor(v) and v.requires_grad:
+                setattr(self, name, v.detach())
+
     def transform_rays_w2s(self, rays):
         """smpl_deformer.py:79-86 (same as SNARFDeformer.transform_rays_w2s): fused kernel."""
         from .snarf_deformer import SNARFDeformer

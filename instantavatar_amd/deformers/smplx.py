@@ -43,7 +43,7 @@ def batch_rodrigues(rot_vecs):
     return ident + sin * K + (1 - cos) * torch.bmm(K, K)
 
 
-def batch_rigid_transform(rot_mats, joints, parents):
+def batch_rigid_transform(rot_mats, joints, parents, parents_list=None):
     """lbs.py:345-401"""
     joints = joints.unsqueeze(-1)
     rel = joints.clone()
@@ -53,9 +53,11 @@ def batch_rigid_transform(rot_mats, joints, parents):
     tm[..., :3, :3] = rot_mats
     tm[..., :3, 3:] = rel
     tm[..., 3, 3] = 1
+    # (parents as Python ints: reading them from a device tensor would be one host synchronisation per joint)
+    par = parents_list if parents_list is not None else [int(p) for p in parents.tolist()]
     chain = [tm[:, 0]]
     for i in range(1, N):
-        chain.append(torch.matmul(chain[int(parents[i])], tm[:, i]))
+        chain.append(torch.matmul(chain[par[i]], tm[:, i]))
     transforms = torch.stack(chain, dim=1)
     posed = transforms[:, :, :3, 3]
     jh = torch.nn.functional.pad(joints, [0, 0, 0, 1])
@@ -82,6 +84,7 @@ class SMPL(nn.Module):
         parents = np.asarray(data["parents"] if "parents" in data else data["kintree_table"][0]).astype(np.int64)
         parents[0] = -1
         self.register_buffer("parents", torch.as_tensor(parents))
+        self.parents_list = [int(p) for p in parents]
         self.register_buffer("lbs_weights", f32(data["lbs_weights"] if "lbs_weights" in data else data["weights"]))
         faces = np.asarray(data["f"]).astype(np.int64) if "f" in data else np.zeros((0, 3), np.int64)
         self.register_buffer("faces_tensor", torch.as_tensor(faces))
@@ -130,7 +133,7 @@ class SMPL(nn.Module):
         v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)
         J = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
         rot = batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
-        Jt, A = batch_rigid_transform(rot, J, self.parents)
+        Jt, A = batch_rigid_transform(rot, J, self.parents, self.parents_list)
         verts = None
         T = None
         shape_offsets = pose_offsets = None

@@ -47,6 +47,20 @@ def get_bbox_from_smpl(vs, factor=1.2):
     return torch.cat([c - s[:, None], c + s[:, None]], dim=0)
 
 
+def affine_inverse(A):
+    """Inverse of affine 4x4 matrices [..., 4, 4] with last row (0, 0, 0, 1): M^-1 = adj(M) / det(M) by cross products of
+    the rows of M, translation -M^-1 t.  Differentiable, no solver library, no host synchronisation."""
+    M, t = A[..., :3, :3], A[..., :3, 3]
+    r0, r1, r2 = M[..., 0, :], M[..., 1, :], M[..., 2, :]
+    c0, c1, c2 = torch.linalg.cross(r1, r2), torch.linalg.cross(r2, r0), torch.linalg.cross(r0, r1)
+    det = (r0 * c0).sum(-1, keepdim=True)
+    Minv = torch.stack([c0, c1, c2], dim=-1) / det[..., None]
+    top = torch.cat([Minv, -(Minv @ t[..., None])], dim=-1)
+    bottom = torch.zeros_like(top[..., :1, :])
+    bottom[..., 0, 3] = 1.0
+    return torch.cat([top, bottom], dim=-2)
+
+
 def _abs_path(p):
     try:
         import hydra
@@ -155,7 +169,10 @@ class SNARFDeformer():
             out = self.body_model(betas=smpl_params["betas"], body_pose=bp, global_orient=go, transl=tr,
                                   return_verts=False)
             s2w = out.A[:, 0].float()
-            w2s = torch.inverse(s2w)
+            # snarf_deformer.py:84 `torch.inverse(s2w)`: the LU route of the library reads its status back to the host (one
+            # synchronisation per step) and does not survive HIP-graph capture; s2w = [M t; 0 0 0 1], so the inverse is
+            # [M^-1, -M^-1 t] with M^-1 from the cofactors -- plain differentiable tensor ops, equal to the LU inverse to rounding
+            w2s = affine_inverse(s2w)
             tfs = (w2s[:, None] @ out.A.float() @ self.tfs_inv_t).type(self.dtype)
             A = out.A
         else:
@@ -171,6 +188,20 @@ class SNARFDeformer():
         self.tfs = tfs
         self.A = A
         self.smpl_params = smpl_params
+        self._vertices = None
+
+    def release_graph(self):
+        """Drop the autograd graph the per-frame attributes hold on to (tfs / w2s / A are non-leaf tensors when the SMPL
+        parameters are optimised): called at the end of a training step.  A graph kept alive across steps keeps the
+        AccumulateGrad nodes of the SMPL tables alive on the stream they were created on, which breaks a later HIP-graph
+        capture of the step on another stream (and holds the step's activations)."""
+        for name in ("tfs", "w2s", "A"):
+            v = getattr(self, name, None)
+            if torch.is_tensor(v) and v.requires_grad:
+                setattr(self, name, v.detach())
+        p = getattr(self, "smpl_params", None)
+        if isinstance(p, dict):
+            self.smpl_params = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in p.items()}
         self._vertices = None
 
     @property

@@ -423,7 +423,10 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     from . import parallel
     if getattr(model, "SMPL_param", None) is not None:            # DNeRF.py:113-128 (optimize_SMPL.enable)
         batch = dict(batch)
-        body_params = model.SMPL_param(batch["idx"].reshape(-1).long().to(model.SMPL_param.betas.weight.device))
+        idx_dev = batch.get("idx_dev")     # device copy of the frame index when the data side provides one (no H2D copy per step)
+        if idx_dev is None:
+            idx_dev = batch["idx"].reshape(-1).long().to(model.SMPL_param.betas.weight.device)
+        body_params = model.SMPL_param(idx_dev.reshape(-1).long())
         for k in ("global_orient", "body_pose", "transl"):
             batch[k] = body_params[k]
         from .deformers.smpl_deformer import SMPLDeformer
@@ -460,7 +463,10 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
     if not _capturing:
         model.global_step += 1
-    return losses
+    # nothing the caller gets keeps the autograd graph of this step alive (see SNARFDeformer.release_graph)
+    if hasattr(model.deformer, "release_graph"):
+        model.deformer.release_graph()
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
 
 
 class GraphedTrainStep:
@@ -475,8 +481,9 @@ class GraphedTrainStep:
     next call: clone what must be kept).
 
     Run eagerly, through `training_step`, are: steps that update the occupancy grid (every 20th, DNeRF.py:100;
-    their regulariser changes the autograd graph), several ranks (the bucketed all-reduce), models with a
-    `SMPL_param` embedding, and any batch whose tensor shapes differ from the captured ones.  One graph is
+    their regulariser changes the autograd graph), several ranks (the bucketed all-reduce) and any batch whose tensor
+    shapes differ from the captured ones.  Models with a `SMPL_param` embedding (fit stage, refinement) are captured
+    too: the frame index reaches the embedding tables as the device tensor `idx_dev` of the batch.  One graph is
     held per (noise on/off, capacity) state; a candidate-capacity overflow (renderer.train_overflow) drops
     the graphs so that they are captured again with the grown capacity.  Learning rates are turned into
     device tensors, so that an `lr_scheduler` keeps working across replays."""
@@ -484,12 +491,18 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_fn, world_size=1, is_refine=False, enabled=True):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.world_size, self.is_refine = world_size, is_refine
-        self.enabled = bool(enabled) and world_size == 1 and getattr(model, "SMPL_param", None) is None
+        self.enabled = bool(enabled) and world_size == 1
+        if getattr(model, "SMPL_param", None) is not None:
+            # SMPL parameters under optimisation: capturable on the fused SNARF route only (the SMPLDeformer's training
+            # query -- fit stage -- reads validity counts on the host and inverts 6 890 vertex transforms with the LU library)
+            fused = getattr(model.deformer, "fused_train_route", None)
+            self.enabled = self.enabled and fused is not None and getattr(model.deformer.deformer, "version", 1) == 1
         self.graphs = {}
         self.inputs = None
         self.replays = 0
         self.eager_steps = 0
         self.capture_error = None
+        self._warmed = False   # an eager step has run through this object (lazy initialisation done)
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _update_period(self):
@@ -537,10 +550,14 @@ class GraphedTrainStep:
         eager = (not self.enabled) or m.global_step % self._update_period() == 0
         if not eager and torch.is_tensor(batch.get("idx")) and batch["idx"].is_cuda:
             eager = True   # the frame index is read on the host (DNeRF.py:113); keep it a host tensor for graph replay
+        if not eager and getattr(m, "SMPL_param", None) is not None and not torch.is_tensor(batch.get("idx_dev")):
+            batch = dict(batch)   # the embedding row is looked up on the device: give the static inputs an `idx_dev` slot
+            batch["idx_dev"] = torch.full((1,), int(batch["idx"][0]), dtype=torch.long, device=m.SMPL_param.betas.weight.device)
         if not eager and self.inputs is not None and batch is not self.inputs:
             eager = self._signature(batch) != self._sig
         if eager:
             self.eager_steps += 1
+            self._warmed = True
             return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         if self.inputs is None:
             self.inputs = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in batch.items()}
@@ -561,6 +578,15 @@ class GraphedTrainStep:
         use_noise = m.global_step < 1000 and not self.is_refine
         key = (bool(use_noise), r.train_cand_capacity)
         entry = self.graphs.get(key)
+        if entry is None and not self._warmed:
+            # one eager step on these inputs before the first capture of this state: lazy initialisation (pinned counter
+            # buffers, workspace growth, library handles, the optimiser's state tensors) must not land inside a capture --
+            # it would either fail it or bake one-off allocations into the graph's pool
+            # (a resume at a global_step that is not a multiple of the update period gets here; normally step 0 -- an
+            # occupancy-update step, eager by rule -- has already done it)
+            self._warmed = True
+            self.eager_steps += 1
+            return training_step(m, self.inputs, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         if entry is None:
             self.graphs = {k: e for k, e in self.graphs.items() if k[1] == r.train_cand_capacity}
             try:
@@ -568,6 +594,8 @@ class GraphedTrainStep:
             except Exception as e:  # capture not possible on this stack: stay eager (same kernels, host-launched)
                 self.capture_error = repr(e)[:300]
                 self.enabled = False
+                import warnings
+                warnings.warn("GraphedTrainStep: HIP-graph capture failed, training continues with eager launches (slower): " + self.capture_error)
                 torch.cuda.synchronize()
                 self.eager_steps += 1
                 return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)

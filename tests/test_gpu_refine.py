@@ -37,11 +37,12 @@ def _setup():
     model.train()
     prep = model.deformer.prepare_deformer
 
-    def prepare_and_retain(params):   # tfs is not a leaf: keep its gradient for the comparison
+    def prepare_and_hook(params):   # tfs is not a leaf (and training_step drops the graph at its end): record its gradient
         prep(params)
+        model.last_tfs = model.deformer.tfs.detach().clone()
         if model.deformer.tfs.requires_grad:
-            model.deformer.tfs.retain_grad()
-    model.deformer.prepare_deformer = prepare_and_retain
+            model.deformer.tfs.register_hook(lambda g: setattr(model, "d_tfs", g.detach().clone()))
+    model.deformer.prepare_deformer = prepare_and_hook
     return model, opt, loss_fn
 
 
@@ -72,7 +73,7 @@ def _draws(k, model):
 def _grads(model):
     n1 = model.net_coarse.sig_w1_size + 1024
     ge = model.net_coarse.encoder.params.grad.detach().cpu().numpy()
-    return dict(d_tfs=model.deformer.tfs.grad[0].cpu().numpy(), mlp_sigma=ge[:n1], table=ge[n1:],
+    return dict(d_tfs=model.d_tfs[0].cpu().numpy(), mlp_sigma=ge[:n1], table=ge[n1:],
                 mlp_color=model.net_coarse.color_net.params.grad.detach().cpu().numpy(),
                 **{n: getattr(model.SMPL_param, n).weight.grad.detach().cpu().numpy() for n in ("global_orient", "transl", "body_pose")})
 
@@ -95,7 +96,7 @@ def test_refine_training_steps_match_reference_training_step_golden():
         print("step", k, "losses", got, "reference", ref)
         assert np.all(np.abs(got - ref) <= tol * np.abs(ref) + 1e-6), (k, got, ref)
         g = _grads(model)
-        assert np.abs(model.deformer.tfs[0].detach().cpu().numpy() - G["tfs_%d" % k]).max() < (2e-5 if k == 0 else 2e-4)
+        assert np.abs(model.last_tfs[0].cpu().numpy() - G["tfs_%d" % k]).max() < (2e-5 if k == 0 else 2e-4)
         c_min, r_max = (0.9999, 1e-2) if k == 0 else (0.999, 5e-2)     # measured: step 0 cos 1.00000, rel 4e-4 .. 2e-3; step 2 cos 0.9999, rel 1.3e-2
         report = {}
         for name, ref_g in (("d_tfs", G["d_tfs_%d" % k]), ("body_pose", G["g_body_pose_%d" % k]), ("mlp_sigma", G["g_mlp_sigma_%d" % k]),
@@ -167,3 +168,32 @@ def test_refine_step_rendered_image_matches_golden():
     e_rgb, e_a = np.abs(rgb - G["rgb_0"]).max(-1), np.abs(alpha - G["alpha_0"])
     assert (e_rgb > 1e-3).mean() < 5e-3 and (e_a > 1e-3).mean() < 5e-3, ((e_rgb > 1e-3).mean(), (e_a > 1e-3).mean(), e_rgb.max())
     assert (G["alpha_0"] > 0.5).mean() > 0.02
+
+
+def test_refine_step_replays_from_a_hip_graph():
+    """The refine step (embedding look-up on the device, SMPL forward under autograd, implicit differentiation, three
+    parameter groups) captured and replayed by GraphedTrainStep: same losses as eager steps from the same state, the SMPL
+    tables keep moving, and a resume in the middle of an update period warms up eagerly before it captures."""
+    from instantavatar_amd.training import GraphedTrainStep
+    curves, tables = [], []
+    for graphed in (False, True):
+        model, opt, loss_fn = _setup()
+        torch.manual_seed(5)
+        training_step(model, _batch(0), opt, loss_fn, is_refine=True)   # step 0 (builds the occupancy grid), outside the stepper:
+        stepper = GraphedTrainStep(model, opt, loss_fn, is_refine=True, enabled=graphed)   # its first call is then NOT an update step
+        ls = []
+        for it in range(8):
+            b = _batch(it % 3)
+            b["idx_dev"] = torch.tensor([it % 3], device=DEV)
+            out = stepper(b)
+            ls.append(float(out["loss"].detach()))
+        if graphed:
+            assert stepper.capture_error is None, stepper.capture_error
+            assert stepper.eager_steps == 1 and stepper.replays == 7, (stepper.eager_steps, stepper.replays)
+        curves.append(ls)
+        tables.append(model.SMPL_param.body_pose.weight.detach().cpu().numpy().copy())
+    e, g = np.array(curves[0]), np.array(curves[1])
+    print("eager", e, "graph", g)
+    assert np.allclose(e, g, rtol=2e-2, atol=1e-6), (e, g)
+    assert np.abs(tables[1] - G["table_body_pose"]).max() > 1e-5          # the replayed steps really optimise the SMPL tables
+    assert np.abs(tables[0] - tables[1]).max() < 4e-5
