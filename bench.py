@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed on the CPU oracle after one warm-up frame (0 = skip; minimum 3)")
     ap.add_argument("--spinup-max-ms", type=float, default=4000.0,
                     help="upper bound of the adaptive, untimed and REPORTED spin-up: 10-frame windows are run until three "
                          "consecutive windows agree within 3 %% (reported as spinup_ms / value_first_window / value_steady)")
@@ -66,8 +66,8 @@ def parse():
 
 
 def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
-    """The CPU restatement (oracle/) timed on this box's host cores on a bounded
-    sample: `n_frames` full frames of the same workload (kind = "port")."""
+    """The CPU restatement (oracle/) timed on this box's host cores on a bounded sample of the same workload: one untimed
+    warm-up frame, then `n_frames` (>= 3) full frames timed one by one; value = 1 / median frame time (SURVEY 8d protocol)."""
     from oracle import oracle as orc
     from instantavatar_amd import synthetic as syn
     fd = model.deformer.deformer
@@ -79,18 +79,24 @@ def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
     ro, rd = syn.make_camera_rays(res)
     rng = np.random.RandomState(0)
     orc.lib()
-    t0 = time.time()
-    for i in range(n_frames):
-        world = orc.make_world(body, init, fp, np.zeros(10, np.float32), poses[i, 3:], poses[i, :3], tr[i], syn.INIT_BONES)
+    n_frames = max(int(n_frames), 3)
+    times = []
+    t_all = time.time()
+    for i in range(n_frames + 1):          # frame 0 = warm-up (page faults of the 25 MB grid, OpenMP pool start-up)
+        f = (i * 37) % len(poses)
+        world = orc.make_world(body, init, fp, np.zeros(10, np.float32), poses[f, 3:], poses[f, :3], tr[f], syn.INIT_BONES)
         jit = rng.rand(5, 64 ** 3, 3).astype(np.float32)
+        t0 = time.time()
         orc.render_image_fast(world, ro, rd, jit)
-    dt = time.time() - t0
+        if i > 0:
+            times.append(time.time() - t0)
+    med = float(np.median(times))
     cores = os.cpu_count() or 1
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": ("%d full %dx%d frames (occupancy build + render) through oracle/ -- a C + OpenMP restatement of the reference's "
-                       "algorithm (fp32); the reference itself has no CPU path (its kernels are CUDA-only), so this port stands in "
-                       "for the 'PyTorch-CPU path' of BASELINE.json" % (n_frames, res, res)),
-            "seconds": dt}
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": ("1 warm-up + %d full %dx%d frames of the bench's pose track (occupancy build + render) through oracle/ -- a C + OpenMP "
+                       "restatement of the reference's algorithm (fp32), all host cores; median frame time.  The reference itself has no CPU "
+                       "path (its kernels are CUDA-only), so this port stands in for the 'PyTorch-CPU path' of BASELINE.json" % (n_frames, res, res)),
+            "frame_seconds": [round(t, 3) for t in times], "seconds": time.time() - t_all}
 
 
 def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, n_rays=4096, warmup=3, graphed=True,
@@ -296,7 +302,8 @@ def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512)
                                 "what": "the same 2^20 random points sorted by Morton code first (the sort is not part of avg_launch_us)"}
     except Exception as e:
         out["morton_binned"] = {"error": repr(e)[:200]}
-    cj, src = _profile_json("r02_pmc_encode.json", "r01_pmc_encode.json")
+    cj, src = _profile_json("r03_pmc_encode.json")
+    out["counters_source"] = src
     if cj is not None:
         try:
             c = cj["k_encode_xcd<16>"]
@@ -382,16 +389,36 @@ def dry_run(args, rank, world_size):
         dist.destroy_process_group()
 
 
+def _so_sha256():
+    import hashlib
+    from instantavatar_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+
+_SO_HASH = [None]
+
+
 def _profile_json(*names):
-    """newest committed PMC summary under profiles/ among `names` (rocprofv3 --pmc passes, tools/pmc_*.py)"""
+    """A committed PMC summary under profiles/ (rocprofv3 --pmc passes, tools/pmc_all.sh) -- accepted ONLY when it was
+    collected on the library this process runs: the summaries carry the library's sha256 (tools/pmc_r3.py).
+    Returns (summary or None, source string saying which file was used or why none was)."""
+    if _SO_HASH[0] is None:
+        _SO_HASH[0] = _so_sha256()
+    why = "no PMC summary under profiles/ (tools/pmc_all.sh)"
     for n in names:
         p = os.path.join(ROOT, "profiles", n)
-        if os.path.exists(p):
-            try:
-                return json.load(open(p)), "profiles/" + n
-            except Exception:
-                pass
-    return None, None
+        if not os.path.exists(p):
+            continue
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        h = j.get("so_sha256")
+        if h == _SO_HASH[0]:
+            return j, "profiles/" + n
+        why = ("profiles/%s was collected on another build of the library (%s, this one is %s): not quoted" %
+               (n, (h or "no hash")[:12], _SO_HASH[0][:12]))
+    return None, why
 
 
 def main():
@@ -425,7 +452,9 @@ def main():
     model, body, fp = build_synthetic_model(dev, resolution=128, n_levels=16)
     res = args.res
     n_total = args.steps + args.warmup
-    poses, tr = syn.procedural_pose_track(max(200, n_total * world_size))
+    track = os.path.join(ROOT, "tests", "golden", "aist_demo_200.npz")
+    poses, tr = syn.load_animation_track(track)          # BASELINE config 3 / SURVEY 8(d): first 200 frames of aist_demo.npz
+    poses_proc, tr_proc = syn.procedural_pose_track(200)   # rounds 1-2 workload, secondary figure
 
     def max_over_ranks(x):
         if world_size > 1:
@@ -529,11 +558,14 @@ def main():
         cnt_sum[k:k + 1].add_(counter.mean())
         cov_sum[k:k + 1].add_((alpha > 0.5).float().mean())
 
+    frames_done = [0]
+
     def run_frames(i0, n):
         """the loop body of the timed region (frame + the two statistics reductions, executed on the frame's stream), used
         unchanged by the spin-up windows and the warm-up, so that nothing is executed for the first time inside the timed region"""
         for i in range(i0, i0 + n):
             frame(i, stats)
+            frames_done[0] += 1
 
     # Adaptive spin-up, untimed but REPORTED.  A GPU that idled through model construction, the first
     # replays of a freshly instantiated graph and the first launches of the statistics kernels are all
@@ -561,6 +593,7 @@ def main():
     if world_size > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    frames_done[0] = 0
     t0 = time.perf_counter()
     run_frames(args.warmup, args.steps)
     torch.cuda.synchronize()
@@ -568,6 +601,8 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    main_samples_per_ray = float(cnt_sum.sum().item()) / args.steps
+    main_alpha_coverage = float(cov_sum.sum().item()) / args.steps
     # frames whose wave-front loop needed more iterations than the graph holds (deferred check) are
     # rendered again eagerly; that time belongs to the job
     incomplete = graphed.finish() if graphed is not None else 0
@@ -593,6 +628,28 @@ def main():
         torch.cuda.synchronize()
         one_fps = args.steps / (time.perf_counter() - t1)
         g0.finish()
+    # secondary figure: the procedural pose track rounds 1-2 quoted, through the same graphs (untimed for `value`)
+    proc_track = None
+    try:
+        keep = (poses, tr, pose_t, tr_t)
+        poses, tr = poses_proc, tr_proc
+        pose_t, tr_t = torch.as_tensor(poses, device=dev), torch.as_tensor(tr, device=dev)
+        n_sec = min(max(args.steps, 20), 100)
+        run_frames(0, 10)
+        torch.cuda.synchronize()
+        cnt_sum.zero_(); cov_sum.zero_()
+        t2 = time.perf_counter()
+        run_frames(10, n_sec)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        inc2 = graphed.finish() if graphed is not None else 0
+        proc_track = {"frames_per_s": max_over_ranks(n_sec / dt2) if world_size == 1 else n_sec * world_size / max_over_ranks(dt2),
+                      "frames": n_sec, "samples_per_ray": float(cnt_sum.sum().item()) / n_sec,
+                      "alpha_coverage": float(cov_sum.sum().item()) / n_sec, "frames_incomplete_in_graph": int(inc2) - int(incomplete),
+                      "what": "synthetic.procedural_pose_track(200), the workload of the round-1/2 bench lines"}
+        poses, tr, pose_t, tr_t = keep
+    except Exception as e:
+        proc_track = {"error": repr(e)[:200]}
     # per-kernel timing for the roofline block: HIP events around every launch of the two dominant
     # stages on the stream they run on.  Recording ~50 events per frame costs ~10 % of the frame,
     # so `value` comes from the un-instrumented pass above and the SAME K frames are then launched
@@ -616,14 +673,17 @@ def main():
         for kid, name in ((0, "k_search"), (1, "k_field")):
             ms, n, units = C.c_double(), C.c_int64(), (C.c_uint64 * 2)()
             _lib.check(L.ia_profile_get(kid, C.byref(ms), C.byref(n), units))
-            kernels[name] = dict(ms=ms.value, launches=n.value, units=[int(units[0]), int(units[1])])
+            u3 = (C.c_uint64 * 3)()
+            _lib.check(L.ia_profile_get_units(kid, u3, 3))
+            kernels[name] = dict(ms=ms.value, launches=n.value, units=[int(u3[0]), int(u3[1]), int(u3[2])])
         _lib.check(L.ia_profile_enable(0))
         ks, kf = kernels["k_search"], kernels["k_field"]
         # algorithmic bytes: field = 512 B gathered (16 lv x 8 corners x 2 x fp16)
-        # + 12 B in + 16 B out per sample; search = 384 B per trilinear fetch (8 corners x 12 ch
-        # x 4 B) + 12 B in per point + 12 B out per surviving root (bounded by solves).
+        # + 12 B in + 16 B out per sample; search = 384 B per trilinear fetch THAT LOADS (8 corners x 12 ch x 4 B; a
+        # fetch whose 8 corners all lie outside the grid is zero by construction and moves nothing: counted in
+        # units[1], excluded here) + 12 B in per point + 12 B out per surviving root (bounded by solves).
         kf["bytes"] = kf["units"][0] * (512 + 12 + 16)
-        ks["bytes"] = ks["units"][1] * 384 + ks["units"][0] // 13 * 12
+        ks["bytes"] = ks["units"][2] * 384 + ks["units"][0] // 13 * 12
         dom = "k_field" if kf["ms"] >= ks["ms"] else "k_search"
         k = kernels[dom]
         nl = max(k["launches"], 1)
@@ -632,8 +692,8 @@ def main():
         # The 25 MB transform grid (k_search) and the 26 MB fp16 hash table (k_field) are L2 / Infinity-Cache
         # resident: the algorithmic bytes are served by the cache hierarchy, so the roof they are priced against
         # is the aggregate L2 bandwidth; the bytes that actually reached the fabric (PMC: FETCH_SIZE x2 + WRITE_SIZE,
-        # profiles/) divided by the same launch time give the HBM fraction.
-        tj, tsrc = _profile_json("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+        # profiles/, accepted only when collected on THIS build) divided by the same launch time give the HBM fraction.
+        tj, tsrc = _profile_json("r03_pmc_traffic.json")
         traffic = None
         if tj is not None:
             try:
@@ -641,33 +701,48 @@ def main():
             except Exception:
                 traffic = None
         roof = {"kernel": dom, "bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": min(achieved / L2_PEAK_GBS, 1.0), "traffic": traffic, "traffic_source": tsrc if traffic is not None else None,
+                "frac": min(achieved / L2_PEAK_GBS, 1.0), "traffic": traffic, "traffic_source": tsrc,
                 "hbm": ({"achieved": traffic / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": traffic / per_launch_s / 1e9 / HBM_PEAK_GBS} if traffic else None),
-                "note": ("achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream): "
-                         "k_search = 384 B per trilinear fetch of the 25 MB transform grid + 12 B per point + 12 B per root; "
+                "note": ("achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream, this run): "
+                         "k_search = 384 B per trilinear fetch that loads (fetches with all 8 corners outside the grid are zero without "
+                         "a load: `fetches_algorithm` counts them, `fetches_loaded` does not) + 12 B per point + 12 B per root; "
                          "k_field (encode + MLP kernels) = 540 B per sample (512 B hash-table gathers).  Both tables are served "
                          "from L1 / L2 / Infinity Cache, hence the L2 roof (34.5 TB/s aggregate); `hbm` prices the PMC fabric "
                          "traffic of the same kernel against the 8 TB/s HBM peak"),
                 "avg_launch_us": per_launch_s * 1e6, "launches": k["launches"],
                 "algorithmic_bytes_per_launch": k["bytes"] / nl,
-                "fetches_per_s": ks["units"][1] / (ks["ms"] * 1e-3) if ks["ms"] > 0 else 0.0,
+                "solves": ks["units"][0], "fetches_algorithm": ks["units"][1], "fetches_loaded": ks["units"][2],
+                "fetches_loaded_per_s": ks["units"][2] / (ks["ms"] * 1e-3) if ks["ms"] > 0 else 0.0,
                 "ms_per_frame": {n: v["ms"] / args.steps for n, v in kernels.items()},
                 "other": {n: {"avg_launch_us": v["ms"] * 1e3 / max(v["launches"], 1), "launches": v["launches"],
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0),
                               "units": v["units"]} for n, v in kernels.items()}}
-        cj, csrc = _profile_json("r02_pmc_search.json")
+        # resource usage of the search kernel as compiled into this library (hipFuncGetAttributes / occupancy query)
+        vg, lds, thr, wgs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if L.ia_search_kernel_info(C.byref(vg), C.byref(lds), C.byref(thr), C.byref(wgs)) == 0:
+            roof["kernel_resources"] = {"vgprs": vg.value, "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": thr.value,
+                                        "workgroups_per_cu": wgs.value, "waves_per_simd": wgs.value * thr.value / 64 / 4.0}
+        cj, csrc = _profile_json("r03_pmc_search.json")
         if cj is not None:
-            # committed PMC passes of this kernel (tools/pmc_r2.sh): what actually bounds k_search is the rate at which a
+            # committed PMC passes of this kernel (tools/pmc_all.sh): what actually bounds k_search is the rate at which a
             # CU's vector L1 (TCP) looks up cache lines for divergent 16-byte gathers -- ~1 access per clock and CU
-            keep = ("l1_hit_rate", "l2_hit_rate", "tcp_accesses_per_clk_per_cu_at_2.4GHz", "wave_cycle_split", "avg_launch_us_in_pass", "launches")
+            keep = ("l1_hit_rate", "l2_hit_rate", "tcp_accesses_per_launch", "tcp_accesses_per_clk_per_cu_at_2.4GHz", "wave_cycle_split",
+                    "avg_launch_us_in_pass", "launches")
             roof["counters"] = {v: {k: cj[v][k] for k in keep if k in cj[v]} for v in ("k_search/probe", "k_search/render") if v in cj}
-            roof["counters"]["source"] = csrc
-            roof["counters"]["vgprs"], roof["counters"]["waves_per_simd"] = 91, 5
+        roof["counters_source"] = csrc
 
     frames = args.steps * world_size
     fps = frames / dt
-    frames_per_rank = [args.steps] * world_size
+    frames_per_rank = [args.steps]
+    if world_size > 1:   # what every rank really rendered inside the timed region (gathered, not assumed)
+        got = [None] * world_size
+        torch.distributed.all_gather_object(got, int(frames_done[0]))
+        frames_per_rank = [int(g) for g in got]
+        frames = sum(frames_per_rank)
+        fps = frames / dt
+    else:
+        frames_per_rank = [int(frames_done[0])]
     result = {
         "metric": "novel_pose_render_frames_per_sec_512x512", "value": fps, "unit": "frames/s",
         "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -675,12 +750,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": "render_image_fast %dx%d, SNARF_NGP defaults (13 init bones, 128^2x32 skinning voxels, "
                                "16-level hash grid T=2^19, 64^3 occupancy rebuilt per frame with 5 probes, "
-                               "MAX_SAMPLES 256, MAX_BATCH 291600), synthetic SMPL-like body + procedural poses" % (res, res),
+                               "MAX_SAMPLES 256, MAX_BATCH 291600), synthetic SMPL-like body animated by the first 200 frames of "
+                               "data/animation/aist_demo.npz (animate.py:48-50 translation; tests/golden/aist_demo_200.npz)" % (res, res),
+                   "pose_track": "aist_demo.npz[:200]",
                    "frames_sharded_over": world_size},
         "rays_per_sec": fps * res * res,
         "frames_per_rank": frames_per_rank,
-        "samples_per_ray": float(cnt_sum.sum().item()) / args.steps,
-        "alpha_coverage": float(cov_sum.sum().item()) / args.steps,
+        "samples_per_ray": main_samples_per_ray,
+        "alpha_coverage": main_alpha_coverage,
+        "procedural_track": proc_track,
         "frames_in_flight": (args.in_flight if graphed is not None else 1),
         "one_frame_in_flight": ({"frames_per_s": one_fps * world_size, "frame_latency_ms": 1e3 / one_fps} if one_fps else None),
         "render_loop_iters": model.renderer.last_iters, "launch_mode": mode,
@@ -693,9 +771,8 @@ def main():
         result["roofline"] = roof
     if rank == 0 and prof:
         result["hashgrid_lookup"] = hashgrid_roofline(model, dev, frame_batch=batches[0])
-        mj, msrc = _profile_json("r02_pmc_mfma.json")
-        if mj is not None:
-            result["mfma"] = dict(mj, source=msrc)
+        mj, msrc = _profile_json("r03_pmc_mfma.json")
+        result["mfma"] = dict(mj, source=msrc) if mj is not None else {"source": msrc}
     if args.train_steps > 0:
         try:
             result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph)
@@ -712,9 +789,9 @@ def main():
                     result["train"]["refine"]["eager"] = {k: e[k] for k in ("it_per_sec", "launch_mode")}
             except Exception as e:
                 result["train"]["refine"] = {"error": repr(e)[:300]}
-            hj, hsrc = _profile_json("r02_pmc_hgbwd.json")
-            if hj is not None:   # the training step's dominant kernel against the measured atomic-request ceiling (committed PMC pass)
-                result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc)
+            hj, hsrc = _profile_json("r03_pmc_hgbwd.json")
+            # the training step's dominant kernel against the measured atomic-request ceiling (PMC pass on this build)
+            result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc) if hj is not None else {"source": hsrc}
         except Exception as e:  # the headline line must survive a failure of the secondary workload
             result["train"] = {"error": repr(e)[:300]}
     if rank == 0 and world_size == 1 and args.cpu_frames > 0:

@@ -512,6 +512,13 @@ int ia_profile_enable(int on);
 int ia_profile_reset(void);
 int ia_profile_get(int kernel_id, double *total_ms, int64_t *launches,
                    uint64_t *units);
+/* all n (<= 8) counters of a kernel: id 0 -> {solves, trilinear fetches of the algorithm (fuse_cuda_kernel_fast.cu:
+ * one per Broyden evaluation), fetches that loaded memory (a fetch whose 8 corners all lie outside the grid is zero
+ * without a load)}; id 1 -> {samples evaluated}.  Synchronises.                                                  */
+int ia_profile_get_units(int kernel_id, uint64_t *units, int n);
+/* registers per lane, static LDS bytes and threads per workgroup, resident workgroups per CU of the Broyden-search
+ * kernel as compiled into this library (measurement only).                                                        */
+int ia_search_kernel_info(int *vgprs, int *lds_bytes, int *threads, int *workgroups_per_cu);
 
 #ifdef __cplusplus
 }

@@ -1043,7 +1043,10 @@ __global__ __launch_bounds__(256) void k_grad_scale(const float *__restrict__ rg
     if (t == gridDim.x - 1) {
       const float amax = __uint_as_float(atomicExch(&state[0], 0u));
       atomicExch(&state[1], 0u);
-      *scale = 1024.0f / fmaxf(amax, 1e-30f);  // NaN in -> NaN out
+      // a non-finite gradient makes the scale NaN: every half gradient, every weight-gradient sum and every table
+      // contribution of this call become NaN and the step is skipped by the non-finite check downstream
+      // (fmaxf(NaN, 1e-30f) would return 1e-30 -- S = 1e33, finite -- and an infinite amax would give S = 0)
+      *scale = (isnan(amax) || isinf(amax)) ? __uint_as_float(0x7fc00000u) : 1024.0f / fmaxf(amax, 1e-30f);
     }
   }
 }

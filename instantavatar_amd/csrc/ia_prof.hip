@@ -78,3 +78,17 @@ extern "C" int ia_profile_get(int id, double *total_ms, int64_t *launches, uint6
   }
   return IA_OK;
 }
+
+// All counters of a kernel (n <= 8 words per shard, summed over the shards).  Synchronises (bench only).
+// id 0: {solves, trilinear fetches of the algorithm, fetches that loaded memory}; id 1: {samples}.
+extern "C" int ia_profile_get_units(int id, uint64_t *units, int n) {
+  IA_CHECK_ARG(id >= 0 && id < IA_PROF_N && units && n >= 1 && n <= 8, "ia_profile_get_units: bad argument");
+  for (int i = 0; i < n; i++) units[i] = 0;
+  if (!g_prof_units) return IA_OK;
+  (void)hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)IA_PROF_SHARDS * 8);
+  (void)hipMemcpy(h.data(), g_prof_units + (size_t)id * IA_PROF_SHARDS * 8, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  for (int sh = 0; sh < IA_PROF_SHARDS; sh++)
+    for (int i = 0; i < n; i++) units[i] += h[(size_t)sh * 8 + i];
+  return IA_OK;
+}

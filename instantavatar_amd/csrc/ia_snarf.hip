@@ -268,7 +268,7 @@ __global__ __launch_bounds__(384) void k_bbox_reduce(const float *__restrict__ p
 // padding) read a clamped in-range address and get weight 0 -- fma(v, 0, acc) == acc for the
 // finite table values, so the result equals the reference's "skip the corner" bit for bit --
 // which removes the per-corner control flow that would serialise eight memory round trips.
-__device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const SnarfGridDev &g, float gx,
+__device__ __forceinline__ bool fetch_J(const float *__restrict__ vJ, const SnarfGridDev &g, float gx,
                                         float gy, float gz, float *__restrict__ out) {
   const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
   const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
@@ -301,7 +301,7 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   if (!((bx0 || bx1) && (by0 || by1) && (bz0 || bz1))) {
 #pragma unroll
     for (int c = 0; c < 12; c++) out[c] = 0.f;
-    return;
+    return false;
   }
 #endif
 #pragma unroll
@@ -332,6 +332,129 @@ __device__ __forceinline__ void fetch_J(const float *__restrict__ vJ, const Snar
   }
 #pragma unroll
   for (int c = 0; c < 6; c++) { out[2 * c] = acc[c].x; out[2 * c + 1] = acc[c].y; }
+  return true;
+}
+
+// ---- quad-cooperative trilinear fetch ------------------------------------------------------------------------------
+// A lane fetching its own 8 corners issues 24 divergent 16-byte loads, and the CU's vector L1 serves a divergent load one
+// (lane, 64-byte segment) look-up at a time: 24 look-ups per fetch, the limit k_search ran at in round 2 (0.9 look-ups per
+// clock and CU, profiles/r02_pmc_search.json).  Here the four lanes of a quad serve their four fetches one after the other:
+// in round T every lane learns the target lane's corner offsets and weights (DPP quad broadcasts), lane k < 3 loads piece k
+// (row k of the 3x4 transform) of each of the 8 corner records -- the three loads of a quad fall into ONE 48-byte record,
+// i.e. 1-2 segments instead of 3 separate look-ups, and the L1 sees 8 load instructions per fetch instead of 24 -- and
+// accumulates ITS ROW over the corners in the reference order (fuse_cuda_kernel_fast.cu:188-226: every output element is
+// the same fma chain as before, on another lane), then the three rows return to the target lane by DPP.
+// tools/ubench/records64.hip (B4 against A): 33.5 against 21.9 G fetches/s L2-resident, 53.5 against 35.8 L1-resident.
+// All DPP traffic happens in wave-uniform control flow (a DPP read from a lane that EXEC has switched off returns
+// nothing); only the loads are predicated.
+// MEASURED IN THE KERNEL (round 3, MI355X, bit-identical results -- the parity tests pass with it): the L1 look-ups drop
+// as predicted, 98.5 M -> 57.7 M per launch, but the broadcasts, the per-round address arithmetic and the row delivery
+// raise the VALU instructions from 47.9 M to 110 M per launch and the registers from 91 to 143 (3 waves per SIMD instead of
+// 5): the kernel turns VALU-bound (110 M x 4 clk / 1 024 SIMDs = 179 us of issue per launch) and the compact search of a
+// frame's 213 k sample points takes 297 us instead of 246 us (IA_QUAD_GROUP 4 / 2: 300 / 301 us; 4 waves forced: 295-333 us).
+// OFF by default; kept as the measured alternative (tools/ab_search.sh "-DIA_SEARCH_QUAD=1").
+#ifndef IA_SEARCH_QUAD
+#define IA_SEARCH_QUAD 0
+#endif
+template <int S> __device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), S * 0x55, 0xF, 0xF, false));
+}
+template <int S> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xF, 0xF, false);
+}
+
+// what a lane contributes to its round: record offsets (clamped into the grid) and weights (0 for corners outside) of the
+// 8 corners in the reference order, and whether anything has to be loaded at all
+struct FetchPlan {
+  uint32_t off[8];
+  float w[8];
+  uint32_t load;   // 1: the lane is active and at least one corner lies inside the grid
+};
+__device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, float gy, float gz, bool active, FetchPlan &p) {
+  const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
+  const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+  const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  const float fx1 = x1 - ix, fx0 = ix - x0, fy1 = y1 - iy, fy0 = iy - y0, fz1 = z1 - iz, fz0 = iz - z0;
+  const float wgt[8] = {fx1 * fy1 * fz1, fx0 * fy1 * fz1, fx1 * fy0 * fz1, fx0 * fy0 * fz1,
+                        fx1 * fy1 * fz0, fx0 * fy1 * fz0, fx1 * fy0 * fz0, fx0 * fy0 * fz0};
+  const bool bx0 = x0 >= 0 && x0 < g.W, bx1 = x1 >= 0 && x1 < g.W;
+  const bool by0 = y0 >= 0 && y0 < g.H, by1 = y1 >= 0 && y1 < g.H;
+  const bool bz0 = z0 >= 0 && z0 < g.D, bz1 = z1 >= 0 && z1 < g.D;
+  const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
+  const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
+  const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int xx = (k & 1) ? cx1 : cx0, yy = (k & 2) ? cy1 : cy0, zz = (k & 4) ? cz1 : cz0;
+    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
+    p.off[k] = (uint32_t)((zz * g.H + yy) * g.W + xx) * 12u;
+    p.w[k] = in ? wgt[k] : 0.f;
+  }
+  p.load = (active && (bx0 || bx1) && (by0 || by1) && (bz0 || bz1)) ? 1u : 0u;
+}
+
+#ifndef IA_QUAD_GROUP
+#define IA_QUAD_GROUP 8   // corner records whose loads are in flight together within a round (8 = one round trip per round)
+#endif
+// round T of the quad: serve the fetch of lane T.  Wave-uniform control flow outside the load predicate.
+template <int T>
+__device__ __forceinline__ void fetch_round(const float *__restrict__ vJ, const FetchPlan &p, int k, float *__restrict__ out) {
+  const uint32_t load = quad_bcast<T>(p.load);
+  if (__ballot(load != 0) == 0) {   // nobody in this wave has an active lane T with a corner inside: rows are zero
+    if (k == T) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) out[c] = 0.f;
+    }
+    return;
+  }
+  uint32_t off[8];
+  float w[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) { off[c] = quad_bcast<T>(p.off[c]); w[c] = quad_bcast<T>(p.w[c]); }
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
+  const bool mine = load != 0 && k < 3;
+#pragma unroll
+  for (int c0 = 0; c0 < 8; c0 += IA_QUAD_GROUP) {
+    float4 v[IA_QUAD_GROUP];
+#pragma unroll
+    for (int j = 0; j < IA_QUAD_GROUP; j++) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < IA_QUAD_GROUP; j++) v[j] = *reinterpret_cast<const float4 *>(vJ + off[c0 + j] + (uint32_t)k * 4u);
+    }
+#pragma unroll
+    for (int j = 0; j < IA_QUAD_GROUP; j++) {
+      const f2 w2 = (f2){w[c0 + j], w[c0 + j]};
+      a0 = __builtin_elementwise_fma((f2){v[j].x, v[j].y}, w2, a0);
+      a1 = __builtin_elementwise_fma((f2){v[j].z, v[j].w}, w2, a1);
+    }
+    if (IA_QUAD_GROUP < 8) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // rows 0..2 (lanes 0..2 of the quad) back to the target lane
+  const float r[12] = {quad_bcast<0>(a0.x), quad_bcast<0>(a0.y), quad_bcast<0>(a1.x), quad_bcast<0>(a1.y),
+                       quad_bcast<1>(a0.x), quad_bcast<1>(a0.y), quad_bcast<1>(a1.x), quad_bcast<1>(a1.y),
+                       quad_bcast<2>(a0.x), quad_bcast<2>(a0.y), quad_bcast<2>(a1.x), quad_bcast<2>(a1.y)};
+  if (k == T) {
+#pragma unroll
+    for (int c = 0; c < 12; c++) out[c] = r[c];
+  }
+}
+
+// the fetch of every lane of the wave (call in wave-uniform control flow); `loaded`: this lane's fetch touched memory
+__device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const SnarfGridDev &g, float gx, float gy, float gz,
+                                             bool active, float *__restrict__ out, bool &loaded) {
+  FetchPlan p;
+  fetch_plan(g, gx, gy, gz, active, p);
+  loaded = p.load != 0;
+  const int k = threadIdx.x & 3;
+  fetch_round<0>(vJ, p, k, out);
+  fetch_round<1>(vJ, p, k, out);
+  fetch_round<2>(vJ, p, k, out);
+  fetch_round<3>(vJ, p, k, out);
 }
 
 // fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55)
@@ -428,7 +551,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   __shared__ int s_next;
   __shared__ int s_blockbase;
   __shared__ int s_nlive;
-  __shared__ int s_prof[2];
+  __shared__ int s_prof[3];
   __shared__ uint16_t s_list[IA_N_INIT_MAX * NP];
   __shared__ float s_T[IA_N_INIT_MAX][12];  // rows 0..2 of the init bones' transforms (same indexing as the 4x4)
   if (n_pts_dev) P = min(P, *n_pts_dev);
@@ -439,7 +562,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   if (p0 >= P) return;  // uniform per workgroup
   const int np = min(NP, P - p0);
   const int n_items = np * n_init;
-  if (tid == 0) { s_next = 0; s_nlive = 0; s_prof[0] = 0; s_prof[1] = 0; }
+  if (tid == 0) { s_next = 0; s_nlive = 0; s_prof[0] = 0; s_prof[1] = 0; s_prof[2] = 0; }
   for (int e = tid; e < np * 3; e += IA_SEARCH_THREADS) (&s_xd[0][0])[e] = xd[(size_t)p0 * 3 + e];
   for (int e = tid; e < n_init * 12; e += IA_SEARCH_THREADS) s_T[e / 12][e % 12] = tfs[bones.id[e / 12] * 16 + e % 12];
   __syncthreads();
@@ -480,7 +603,9 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
 
   // ---- lane state machine ----
   bool active = false, first = false;
-  int item = 0, iter = 0, fetches = 0, solves = 0;  // `solves` counts the queued (non-trivial) ones
+  // `solves` counts the queued (non-trivial) ones; `fetches` every trilinear fetch of the reference's algorithm, `loaded` those
+  // that touched memory (a fetch with all 8 corners outside the grid is zero by construction and loads nothing)
+  int item = 0, iter = 0, fetches = 0, solves = 0, loaded = 0;
   float t0 = 0, t1 = 0, t2 = 0, xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
   float Ji[9];
 #pragma unroll
@@ -518,13 +643,19 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
       }
     }
     if (!__any(active)) break;
+    const float ix = g.scl[0] * (xl0 + g.off[0]);
+    const float iy = g.scl[1] * (xl1 + g.off[1]);
+    const float iz = g.scl[2] * (xl2 + g.off[2]);
+    float Jl[12];
+    bool ld = false;
+#if IA_SEARCH_QUAD
+    fetch_J_quad(vJ, g, ix, iy, iz, active, Jl, ld);   // all lanes: the quad serves its four fetches in four rounds
+#else
+    if (active) ld = fetch_J(vJ, g, ix, iy, iz, Jl);
+#endif
     if (active) {
-      const float ix = g.scl[0] * (xl0 + g.off[0]);
-      const float iy = g.scl[1] * (xl1 + g.off[1]);
-      const float iz = g.scl[2] * (xl2 + g.off[2]);
-      float Jl[12];
-      fetch_J(vJ, g, ix, iy, iz, Jl);
       fetches++;
+      loaded += ld ? 1 : 0;
       bool done = false, ok = false;
       // residual g(x) = J x + d - x_d at the current point (:325-332 initial, :356-367 updated)
       const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
@@ -575,16 +706,17 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     }
   }
   if (prof) {  // bench-only accounting: solves and trilinear fetches
-    int f = fetches, n = solves;
+    int f = fetches, n = solves, l = loaded;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); }
-    if (lane == 0) { atomicAdd(&s_prof[0], n); atomicAdd(&s_prof[1], f); }
+    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); l += __shfl_xor(l, o, 64); }
+    if (lane == 0) { atomicAdd(&s_prof[0], n); atomicAdd(&s_prof[1], f); atomicAdd(&s_prof[2], l); }
   }
   __syncthreads();
   if (prof && tid == 0) {  // one pair of global atomics per workgroup, on a per-shard line
     unsigned long long *ps = prof + (size_t)(blockIdx.x & (IA_PROF_SHARDS - 1)) * 8;
     atomicAdd(ps, (unsigned long long)s_prof[0]);
     atomicAdd(ps + 1, (unsigned long long)s_prof[1]);
+    atomicAdd(ps + 2, (unsigned long long)s_prof[2]);
   }
   // ---- a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4 ----
   for (int init0 = 0; init0 < n_init; init0 += IA_SEARCH_THREADS / NP) {
@@ -911,4 +1043,20 @@ extern "C" int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *
   IA_CHECK_ARG(n_cand, "ia_snarf_implicit_bwd_compact: n_cand is null");
   return ia_implicit_bwd_impl("ia_snarf_implicit_bwd_compact", cand_xc, cand_Jinv, nullptr, grad_xc, cap, n_cand, voxel_w,
                               grid, d_tfs, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Resource usage of the search kernel as compiled into THIS library (bench.py reports it next to the counters instead
+// of quoting numbers from a build log): VGPRs per lane, static LDS per workgroup, threads per workgroup and the
+// resident workgroups per CU the runtime computes from them.
+extern "C" int ia_search_kernel_info(int *vgprs, int *lds_bytes, int *threads, int *workgroups_per_cu) {
+  hipFuncAttributes a;
+  const void *fn = reinterpret_cast<const void *>(&k_search<1>);
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return ia_set_error(IA_ERR_LAUNCH, "ia_search_kernel_info: hipFuncGetAttributes failed");
+  int nb = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, IA_SEARCH_THREADS, 0);
+  if (vgprs) *vgprs = a.numRegs;
+  if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
+  if (threads) *threads = IA_SEARCH_THREADS;
+  if (workgroups_per_cu) *workgroups_per_cu = nb;
+  return IA_OK;
 }

@@ -98,8 +98,12 @@ class _CandidateGatherFn(torch.autograd.Function):
 
 
 class SNARFDeformer():
-    #: capacity (candidates) of one training-mode field call (`query_train_fused`)
-    train_cand_capacity = 1 << 20
+    #: capacity (candidates) of one training-mode field call (`query_train_fused`, the probe of DensityGrid.update).
+    #: None = points x init bones: every candidate fits by construction, nothing can be dropped (262 144 probe points x 13
+    #: = 3.4 M rows, 1.6 GB of fp16 activations for the duration of the call every 20th step -- of 288 GB).  A number
+    #: bounds the buffers instead; a call that needs more is then detected one call later (`train_overflow`) and the
+    #: capacity doubles.
+    train_cand_capacity = None
 
     def __init__(self, model_path, gender, opt, body_model=None) -> None:
         # body_model: optional pre-built SMPL (e.g. SMPL.from_dict(synthetic.make_body()))
@@ -360,7 +364,8 @@ class SNARFDeformer():
         self.last_cand_count = int(self._cc_host[0])
         if self.last_cand_count > self._cc_cap:
             self.train_overflow += 1
-            self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_cand_count)
+            if self.train_cand_capacity is not None:
+                self.train_cand_capacity = max(self.train_cand_capacity, 2 * self.last_cand_count)
 
     def query_train_fused(self, pts, net):
         """deform_train (snarf_deformer.py:143-159) without the dense [P,13,*] temporaries:
@@ -371,7 +376,7 @@ class SNARFDeformer():
         P = pts.shape[0]
         k = len(self.deformer.init_bones)
         self._cand_count_check()
-        cap = min(P * k, self.train_cand_capacity)
+        cap = P * k if self.train_cand_capacity is None else min(P * k, self.train_cand_capacity)
         want_J_inv = self.tfs.requires_grad and torch.is_grad_enabled()
         with torch.no_grad():
             sc = self.search_compact(pts, cap=cap, want_J_inv=want_J_inv)

@@ -22,6 +22,12 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
     from Lightning's `optimizer_states[0]` / `lr_schedulers[0]` when the checkpoint holds them (resume)."""
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    net = getattr(model, "net_coarse", None)
+    enc = sd.get("net_coarse.encoder.params")
+    if enc is not None and hasattr(net, "adopt_tcnn_layout") and enc.numel() != net.encoder.params.numel():
+        # a checkpoint written with the OTHER of tcnn's two possible level tables: follow it (decided by the vector's size)
+        r3 = net.adopt_tcnn_layout(enc.numel())
+        print("load_checkpoint: encoder.params has %d elements -> tcnn layout with level-3 resolution %d adopted" % (enc.numel(), r3))
     own = model.state_dict()
     take = {}
     unexpected = []
@@ -45,10 +51,11 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
     if strict_path_keys and on_path:
         raise KeyError("checkpoint lacks the field parameters: %s" % on_path)
     model.load_state_dict(take, strict=False)
-    net = getattr(model, "net_coarse", None)
     if net is not None:
         if hasattr(net, "mark_updated"):
             net.mark_updated()
+        if hasattr(net, "self_check") and net.encoder.params.is_cuda and "net_coarse.encoder.params" in take:
+            model.tcnn_self_check = net.self_check()   # finite, no constant level: a shifted layout would show here
     for g in ("density_grid_train", "density_grid_test"):
         grid = getattr(getattr(model, "renderer", None), g, None)
         if grid is not None and hasattr(grid, "pack_bits") and grid.density_field.is_cuda:

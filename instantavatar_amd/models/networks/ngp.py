@@ -113,6 +113,47 @@ class NeRFNGPNet(nn.Module):
             out[r3] = 64 * 2 * n_levels + SIG_W2 + 2 * int(hd.offset[n_levels])
         return out
 
+    def adopt_tcnn_layout(self, encoder_numel):
+        """Decide the one open layout question of tcnn v1.6 -- level-3 resolution 54 or 55 (it depends on the last bit of the
+        build's exp2f, _lib.apply_level3_override) -- from the SIZE of a real `encoder.params` vector, and switch this module to
+        it (level table, parameter vector, kernel descriptor).  Returns the resolution adopted; raises when the size fits
+        neither layout.  With the first real checkpoint this pins SURVEY row a10 in one run (see `self_check`)."""
+        sizes = self.tcnn_encoder_sizes(self.n_levels, self.log2_T)
+        fit = [r for r, n in sizes.items() if n == int(encoder_numel)]
+        if not fit:
+            raise ValueError("encoder.params with %d elements fits neither tcnn layout (level-3 resolution 54: %d, 55: %d elements)"
+                             % (encoder_numel, sizes[54], sizes[55]))
+        r3 = fit[0] if self.n_levels > 3 else int(self.hash_desc.res[min(3, self.n_levels - 1)])
+        if self.n_levels > 3 and int(self.hash_desc.res[3]) != r3:
+            dev = self.encoder.params.device
+            self.hash_desc = _lib.make_hash_desc(self.n_levels, self.log2_T, BASE_RES, PER_LEVEL_SCALE, level3_res=r3)
+            self.n_entries = int(self.hash_desc.offset[self.n_levels])
+            self.encoder = _TcnnParams(self.sig_w1_size + SIG_W2 + 2 * self.n_entries).to(dev)
+            self._half = self._half_key = self._desc = None
+            self.reset_parameters()
+        self.tcnn_level3_res = r3
+        return r3
+
+    @torch.no_grad()
+    def self_check(self, n=8192, seed=0):
+        """Sanity of a freshly loaded parameter set on the device: the hash-grid features of `n` random points of the unit
+        cube must be finite and no level may be constant (a layout that reads a checkpoint shifted by even one level offset
+        shows up as levels of pure initialisation noise or zeros), sigma / rgb must be finite.  Returns a report dict;
+        raises ValueError on a failed check."""
+        dev = self.encoder.params.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        x = (torch.rand((n, 3), device=dev, generator=g) - 0.5) * self.scale.to(dev) + self.center.to(dev)
+        feat = self.encode(x).float().reshape(n, self.n_levels, 2)
+        rgb, sigma = self.forward(x)
+        std = feat.std(dim=0).amax(dim=1)
+        rep = {"level3_res": int(self.hash_desc.res[min(3, self.n_levels - 1)]), "finite": bool(torch.isfinite(feat).all() and torch.isfinite(sigma).all()
+                                                                                               and torch.isfinite(rgb).all()),
+               "feature_std_per_level": [float(v) for v in std], "constant_levels": [int(i) for i in (std == 0).nonzero().reshape(-1)],
+               "encoder_numel": int(self.encoder.params.numel())}
+        if not rep["finite"] or rep["constant_levels"]:
+            raise ValueError("NeRFNGPNet.self_check failed: %s" % rep)
+        return rep
+
     def load_tcnn_params(self, encoder_params, color_params):
         """Load the reference's two flat tcnn parameter vectors (state-dict entries `net_coarse.encoder.params`,
         `net_coarse.color_net.params`, ngp.py:27-58).  Sizes are checked against this module's level table; a

@@ -311,6 +311,10 @@ class Raymarcher(torch.nn.Module):
         # (SMPL refinement: the candidates carry the implicit-differentiation gradient to tfs, deformer_torch.py:50-67)
         rgb_c, sig_c = field_autograd(net, deformer.candidates_with_grad(sc), n_dev=sc["n_cand"])
         self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)
+        # device-side overflow flag of THIS step: candidates past the capacity were dropped (in atomic-arrival order), so the
+        # step's gradients are wrong -- `training_step` feeds the flag to the optimiser's found_inf, the update is skipped on
+        # the device without a host read; the deferred count check then grows the capacity and the next steps are whole
+        self.train_overflow_flag = (sc["n_cand"] > cand_cap).to(torch.float32).reshape(())
         color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
         return {
             "rgb_coarse": color.reshape(rays.o.shape),

@@ -231,3 +231,12 @@ def procedural_pose_track(n_frames, seed=42):
     poses[:, 0] += np.pi  # face the camera the way aist_demo does (y down in camera)
     tr = np.stack([0.2 * np.sin(t), np.full_like(t, 0.15), np.full_like(t, 5.0)], 1)
     return poses.astype(np.float32), tr.astype(np.float32)
+
+
+def load_animation_track(path):
+    """animate.py:46-50: `poses[..., :72]` and `trans - trans[0] + (0, 0.15, 5)` of an AIST-style pose file
+    (tests/golden/aist_demo_200.npz = the first 200 frames of the reference's data/animation/aist_demo.npz)."""
+    z = np.load(path)
+    poses = z["poses"][..., :72].astype(np.float32)
+    tr = (z["trans"] - z["trans"][0:1] + np.array([0, 0.15, 5.0])).astype(np.float32)
+    return poses, tr

@@ -1,16 +1,19 @@
 """Training-side glue of the hot path (rows a7/a8/a15/a17 of SURVEY.md section 8).
 
-* `field_autograd`: NeRFNGPNet under autograd (what tcnn's torch binding does at
-  ngp.py:78,81).  Forward = the fused HIP kernel in training mode
-  (`ia_field_fwd_train`, identical outputs + fp16 activation record); backward =
-  MLP weight/input gradients as plain GEMMs over the saved activations (rocBLAS
-  via torch.matmul, fp32) and the hash-table scatter-add as the HIP kernel
-  `ia_hashgrid_bwd` (fp32 atomics; tcnn accumulates in fp16 under a 1024x loss
-  scale, DNeRF.py:58 -- fp32 needs no scaling, the GradScaler stays functional).
-* `NeRFLoss`: instant_avatar/utils/loss.py:53-77.
-* `training_step`: DNeRFModel.training_step (models/DNeRF.py:112-161) without
-  Lightning; `all_reduce_grads` is the data-parallel extension (RCCL over xGMI,
-  one flat bucket per parameter tensor: 52 MB hash-table gradient + 2 small ones).
+* `field_autograd`: NeRFNGPNet under autograd (what tcnn's torch binding does at ngp.py:78,81).  Forward = the fused HIP
+  kernel in training mode (`ia_field_fwd_train`: identical outputs + the fp16 activation record); backward = ONE MFMA
+  kernel for both tiny MLPs (`ia_field_bwd`: weight and input gradients, fp32 accumulation; the ten-GEMM formulation
+  `_mlp_backward_gemm` is kept as its checker) and the hash-table scatter-add `ia_hashgrid_bwd` (fp32 atomics,
+  quad-cooperative; optionally the input gradient dx).  Gradients are rounded to half under a per-call scale
+  (`ia_field_grad_scale`; tcnn relies on a fixed 1024x loss scale, DNeRF.py:58) and accumulated in fp32 straight into
+  `param.grad`.
+* `NeRFLoss` / `NGPLoss`: instant_avatar/utils/loss.py, value + gradient from one kernel (`ia_nerf_loss`).
+* `training_step`: DNeRFModel.training_step (models/DNeRF.py:112-161) without Lightning, all configurations (plain, fit,
+  refine); non-finite gradients and candidate overflows skip the optimiser step on the device (fused Adam's found_inf).
+* data parallel: ONE bucketed gradient average per step, started from inside the backward pass (`parallel.GradReducer`:
+  finished level groups of the 52 MB table gradient go to RCCL while the next group is scattered), MAX-reduce of the cached
+  occupancy densities every 20 steps.
+* `GraphedTrainStep`: the whole step captured into a HIP graph and replayed.
 """
 import ctypes as C
 
@@ -353,13 +356,17 @@ def _non_finite_flag(params):
 _ONES = {}
 
 
-def optimizer_step_skip_non_finite(optimizer, params):
+def optimizer_step_skip_non_finite(optimizer, params, extra_flag=None):
     """GradScaler.step's inf/NaN skip (DNeRF.py:151-154: `self.scaler.step(optimizer)`) without its host
     synchronisation: torch's fused Adam takes a device-side `found_inf` flag and leaves parameters, moments
     and step counters untouched when it is set.  One non-finite gradient would otherwise poison the whole
     52 MB table (the per-call gradient scale S = 1024 / amax turns a single NaN into NaN everywhere).
-    Non-fused optimisers (CPU tests) fall back to a host check.  Returns the flag (device scalar)."""
+    Non-fused optimisers (CPU tests) fall back to a host check.  Returns the flag (device scalar), which also covers
+    `extra_flag` (device scalar, optional): a step whose training render dropped candidates is skipped the same way."""
     flag = _non_finite_flag(params)
+    if extra_flag is not None and flag is not None:
+        # a second device-side reason to skip the update (a training render whose candidates overflowed their capacity)
+        flag = torch.maximum(flag, extra_flag.to(flag))
     fused = all(g.get("fused") for g in optimizer.param_groups)
     if flag is None:
         optimizer.step()
@@ -458,7 +465,11 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     finally:
         parallel.set_current_reducer(None)
     params = [p for g in optimizer.param_groups for p in g["params"]]
-    losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params)
+    overflow = getattr(model.renderer, "train_overflow_flag", None)
+    model.renderer.train_overflow_flag = None
+    losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params, extra_flag=overflow)
+    if overflow is not None:
+        losses["skipped_overflow"] = overflow
     if hasattr(model.net_coarse, "mark_updated"):
         model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
     if not _capturing:

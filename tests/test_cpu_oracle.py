@@ -420,6 +420,13 @@ def test_tcnn_param_vector_sizes_and_loader_messages(oracle, monkeypatch):
     assert float(net.encoder.params.min()) == 0.25 and float(net.color_net.params.max()) == -0.5
     net55 = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), level3_res=55)
     net55.load_tcnn_params(enc55, torch.zeros(6144))
+    # a loader that is handed a vector of the other layout can FOLLOW it instead: decided by the size alone
+    net_a = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), level3_res=54)
+    assert net_a.adopt_tcnn_layout(sizes[55]) == 55 and net_a.encoder.params.numel() == sizes[55] and int(net_a.hash_desc.res[3]) == 55
+    net_a.load_tcnn_params(enc55, torch.zeros(6144))
+    assert net_a.adopt_tcnn_layout(sizes[54]) == 54 and net_a.encoder.params.numel() == sizes[54]
+    with pytest.raises(ValueError):
+        net_a.adopt_tcnn_layout(sizes[54] + 2)
     monkeypatch.setenv("IA_TCNN_LEVEL3_RES", "55")             # the suite-wide switch
     assert NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1])).encoder.params.numel() == sizes[55]
     assert int(oracle.hash_desc().res[3]) == 55

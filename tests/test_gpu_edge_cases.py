@@ -168,3 +168,59 @@ def test_train_driver_checkpoint_feeds_animate_driver(tmp_path):
     assert animate.main(["--synthetic", "--ckpt", ckpt, "--max-frames", "2", "--downscale", "8", "--out", out, "--no-gif"]) == 0
     im = np.asarray(Image.open(os.path.join(out, "0.png")))
     assert im.shape == (135, 135, 4) and (im[..., 3] > 128).mean() > 0.01
+
+
+def test_checkpoint_of_the_other_tcnn_layout_is_adopted_and_self_checked(tmp_path):
+    """a checkpoint whose `encoder.params` has the OTHER of tcnn's two possible sizes (level-3
+    resolution 54 / 55) is followed by the loader (decided from numel), and the loaded field passes `self_check` (finite,
+    no constant level); a vector with a level of zeros fails it."""
+    from instantavatar_amd.drivers.checkpoint import load_checkpoint, save_checkpoint
+    from instantavatar_amd.pipeline import build_synthetic_model
+    import os as _os
+    own = int(_os.environ.get("IA_TCNN_LEVEL3_RES", "54"))
+    other = 55 if own == 54 else 54
+    model, _, _ = build_synthetic_model(DEV, resolution=32)
+    src, _, _ = build_synthetic_model(DEV, resolution=32)
+    assert src.net_coarse.adopt_tcnn_layout(src.net_coarse.tcnn_encoder_sizes()[other]) == other
+    with torch.no_grad():
+        src.net_coarse.encoder.params.uniform_(-0.5, 0.5)
+    path = str(tmp_path / "other_layout.ckpt")
+    save_checkpoint(src, path)
+    assert int(model.net_coarse.hash_desc.res[3]) == own
+    load_checkpoint(model, path)
+    assert int(model.net_coarse.hash_desc.res[3]) == other and model.tcnn_self_check["level3_res"] == other
+    assert torch.equal(model.net_coarse.encoder.params, src.net_coarse.encoder.params)
+    assert min(model.tcnn_self_check["feature_std_per_level"]) > 0 and model.tcnn_self_check["finite"]
+    # a degenerate table (one level all zero) is caught
+    net = model.net_coarse
+    off = [int(o) for o in net.hash_desc.offset[:net.n_levels + 1]]
+    w_end = net.sig_w1_size + 1024
+    with torch.no_grad():
+        net.encoder.params[w_end + 2 * off[5]:w_end + 2 * off[6]] = 0
+    net.mark_updated()
+    with pytest.raises(ValueError):
+        net.self_check()
+
+
+def test_field_follows_centre_and_scale_changed_in_place():
+    """a model that has already rendered keeps host copies of centre / scale inside its kernel
+    descriptor; loading other values IN PLACE (checkpoint, broadcast) must reach the kernels."""
+    from instantavatar_amd.pipeline import build_synthetic_model
+    model, _, _ = build_synthetic_model(DEV, resolution=32)
+    net = model.net_coarse
+    bb = model.deformer.bbox
+    x = torch.rand((4096, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * (bb[1] - bb[0]) * 0.5 + bb[0] + (bb[1] - bb[0]) * 0.25
+    with torch.no_grad():
+        r0, s0 = net(x)
+        new_c, new_s = net.center + 0.05, net.scale * 1.1
+        net.center.copy_(new_c)          # what load_state_dict / broadcast_module_state do
+        net.scale.copy_(new_s)
+        net.mark_updated()
+        r1, s1 = net(x)
+    fresh, _, _ = build_synthetic_model(DEV, resolution=32)
+    with torch.no_grad():
+        fresh.net_coarse.center, fresh.net_coarse.scale = new_c.clone(), new_s.clone()
+        fresh.net_coarse._desc = None
+        r2, s2 = fresh.net_coarse(x)
+    assert not torch.equal(s0, s1)
+    assert torch.equal(s1, s2) and torch.equal(r1, r2)

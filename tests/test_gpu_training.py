@@ -557,3 +557,46 @@ def test_hashgrid_backward_is_independent_of_call_granularity(gw):
         for l0, l1 in ((net.n_levels // 2, net.n_levels), (0, net.n_levels // 2)):
             _lib.check(L.ia_hashgrid_bwd_levels(_lib.ptr(x), V, None, C.byref(fd), _lib.ptr(dfeat), parts.data_ptr(), l0, l1, _lib.stream()))
         assert (parts - ref).abs().max() / ref.abs().max() < 1e-5
+
+
+def test_render_candidate_overflow_skips_the_optimizer_step_on_the_device(gw):
+    """a training render whose candidates exceed the capacity drops some of them -- its gradients are
+    wrong.  The step is then skipped ON THE DEVICE (found_inf of the fused Adam, no host read), the deferred count check
+    grows the capacity, and the following steps are whole."""
+    tmodel, batches = _train_setup(seed_model=6, n_rays=1024)
+    opt = configure_optimizer(tmodel)
+    loss_fn = NeRFLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
+    r = tmodel.renderer
+    training_step(tmodel, batches[0], opt, loss_fn)              # step 0: builds the occupancy grid, plenty of capacity
+    r.train_cand_capacity, r.train_overflow = 512, 0
+    p = tmodel.net_coarse.encoder.params
+    skipped = []
+    for it in range(4):
+        before = p.detach().clone()
+        out = training_step(tmodel, batches[(it + 1) % 3], opt, loss_fn)
+        torch.cuda.synchronize()
+        s = float(out["skipped_overflow"])
+        skipped.append(s)
+        assert float(out["skipped_non_finite"]) == s
+        assert torch.equal(before, p.detach()) == (s == 1.0), (it, s)
+    assert skipped[0] == 1.0 and skipped[-1] == 0.0, skipped     # the capacity grew: the last step went through
+    assert r.train_overflow >= 1 and r.train_cand_capacity > 512
+
+
+def test_non_finite_upstream_gradient_skips_the_step(gw):
+    """one NaN in d_sigma must end in `skipped_non_finite` through the gradient scale (S = NaN), not through luck."""
+    model = gw[0]
+    net = model.net_coarse
+    bb = model.deformer.bbox
+    x = torch.rand((4096, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)) * (bb[1] - bb[0]) + bb[0]
+    for p in net.parameters():
+        p.grad = None
+    rgb, sigma = field_autograd(net, x)
+    w = torch.ones_like(sigma)
+    w[17] = float("nan")
+    ((rgb.sum()) + (sigma * w).sum()).backward()
+    from instantavatar_amd.training import _non_finite_flag
+    assert float(_non_finite_flag(list(net.parameters()))) == 1.0
+    assert not torch.isfinite(net.encoder.params.grad).all()
+    for p in net.parameters():
+        p.grad = None

@@ -58,7 +58,8 @@ def load(root):
     return out
 
 
-def main(root, out_dir):
+def main(root, out_dir, prefix="r02", meta=None):
+    """meta: dict merged into every JSON written (round 3: the sha256 of the library the counters were collected on)"""
     S = load(root)
     g = lambda fam, c, k="per_launch": S.get(fam, {}).get(c, {}).get(k)
     # ---- traffic
@@ -109,8 +110,8 @@ def main(root, out_dir):
             acc_, l2req = g(k, "TCP_TOTAL_CACHE_ACCESSES_sum"), g(k, "TCP_TCC_READ_REQ_sum")
             h, m = g(k, "TCC_HIT_sum"), g(k, "TCC_MISS_sum")
             search[k] = {"l1_hit_rate": (1.0 - l2req / acc_) if acc_ else None, "l2_hit_rate": (h / (h + m)) if h is not None and m is not None and h + m > 0 else None}
-    search["_note"] = ("registers / occupancy of k_search<1>: 91 VGPRs, 9.5 KB LDS per 128-thread workgroup -> 5 waves per SIMD "
-                       "(hipcc -Rpass-analysis=kernel-resource-usage); counters are sums over the chip per launch, averaged over the launches")
+    search["_note"] = ("counters are sums over the chip per launch, averaged over the launches; registers / occupancy of the kernel: "
+                       "ia_kernel_info(\"k_search\") of the same library, reported live by bench.py")
     # ---- MFMA
     mfma = {}
     for fam in ("k_field", "k_field_bwd"):
@@ -126,7 +127,8 @@ def main(root, out_dir):
     mfma["_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES (32 per v_mfma_f32_32x32x16_f16, summed over the chip) / (launch duration x 2.4 GHz x 1024 SIMDs); the MLPs are 18 432 FLOP per "
                      "sample (22 v_mfma_f32_32x32x16_f16 per 32 samples forward): the matrix cores are used for the dense tiny-MLP GEMMs "
                      "only and are nowhere near a bound -- reported, not optimised (SURVEY 8d)")
-    for name, obj in (("r02_pmc_traffic.json", traffic), ("r02_pmc_search.json", search), ("r02_pmc_mfma.json", mfma)):
+    for name, obj in ((prefix + "_pmc_traffic.json", traffic), (prefix + "_pmc_search.json", search), (prefix + "_pmc_mfma.json", mfma)):
+        obj.update(meta or {})
         json.dump(obj, open(os.path.join(out_dir, name), "w"), indent=1)
         print("==", name)
         print(json.dumps(obj, indent=1)[:3000])
