@@ -54,6 +54,9 @@ def parse():
                     help="independent frames in flight per GPU (one captured graph and one HIP stream each; 1 = strictly one frame "
                          "after the other).  The frames of a sequence are independent units (animate.py)")
     ap.add_argument("--train-only", action="store_true", help="headline = training throughput (rays/s over all ranks)")
+    ap.add_argument("--force-collectives", action="store_true", help="with --gpus 1: start a 1-rank RCCL group and take the multi-rank "
+                    "training path (bucketed all-reduce from inside the backward, density MAX-reduce) -- the eager-vs-graph gap of the "
+                    "N-rank step measured on one GPU")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises launch, frame sharding and the "
                     "collectives on the gloo backend (CPU test of the N > 1 plumbing)")
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
@@ -444,6 +447,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
+    elif args.force_collectives:
+        import torch.distributed as dist
+        from instantavatar_amd import parallel
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        parallel.FORCE_COLLECTIVES = True
 
     from instantavatar_amd import _lib, synthetic as syn
     from instantavatar_amd.pipeline import build_synthetic_model, make_batch
@@ -466,6 +476,11 @@ def main():
     if args.train_only:
         tr_res = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3),
                                   graphed=not args.no_graph)
+        if not args.no_graph and (world_size > 1 or args.force_collectives):
+            # the same N-rank step launched eagerly (~60 launches + the collectives from Python): the gap a captured step closes
+            e = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3), graphed=False)
+            tr_res["eager"] = {k: e[k] for k in ("it_per_sec", "rays_per_sec", "launch_mode")}
+            tr_res["collectives"] = "RCCL, %d rank(s)%s" % (world_size, " (forced on one rank)" if args.force_collectives else "")
         if rank == 0:
             print(json.dumps({"metric": "train_rays_per_sec", "value": tr_res["rays_per_sec"], "unit": "rays/s", "n_gpus": world_size,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / tr_res["it_per_sec"],

@@ -17,6 +17,16 @@ collective), frames + ray batches at training:
 import torch
 
 
+#: test / measurement switch: take the multi-rank code paths (bucketed all-reduce from inside the backward, MAX-reduce of
+#: the density cache, broadcast) with a process group of ANY size, including one rank -- so that a single-GPU box
+#: executes the RCCL collectives, their stream / event ordering against the scatter kernels and their graph capture
+FORCE_COLLECTIVES = False
+
+
+def collectives_on(world_size):
+    return world_size > 1 or (FORCE_COLLECTIVES and _dist().is_available() and _dist().is_initialized())
+
+
 def shard_frames(n_frames, rank, world_size):
     """Round-robin frame ownership: rank r renders frames r, r+W, r+2W, ..."""
     return list(range(rank, n_frames, world_size))
@@ -29,7 +39,7 @@ def _dist():
 
 def reduce_density_cache(density_cached, world_size):
     """In-place MAX all-reduce of DensityGrid.density_cached (1 MB)."""
-    if world_size <= 1:
+    if not collectives_on(world_size):
         return density_cached
     dist = _dist()
     dist.all_reduce(density_cached, op=dist.ReduceOp.MAX)
@@ -40,7 +50,7 @@ def broadcast_module_state(module, world_size, src=0):
     """Start-up / resume broadcast: parameters and buffers of `module` from rank `src`.
     Replicas must not rely on equal seeds: a resumed checkpoint, a different library version or a
     rank-dependent RNG draw would silently fork them."""
-    if world_size <= 1:
+    if not collectives_on(world_size):
         return
     dist = _dist()
     # the training occupancy grids are kept in a plain list like the reference's (not in state_dict): name them explicitly
@@ -82,7 +92,7 @@ class GradReducer:
 
     @property
     def active(self):
-        return self.world_size > 1
+        return collectives_on(self.world_size)
 
     def field_forward(self):
         self._fields += 1
@@ -138,6 +148,15 @@ class GradReducer:
                 flat = g.view(-1)
             for a, b in self._covered(flat):
                 self.reduce_async(flat[a:b])
+        # every byte of every gradient travelled exactly once: the slices handed in from inside the backward
+        # (training.gradient_buckets) and the remainders above must not overlap -- an overlap would average a slice twice
+        segs = sorted(self._ranges)
+        for (a0, b0), (a1, b1) in zip(segs, segs[1:]):
+            assert a1 >= b0, "GradReducer: gradient slices overlap (%d..%d and %d..%d)" % (a0, b0, a1, b1)
+        for p in params:
+            if p.grad is not None:
+                assert not self._covered(p.grad.view(-1)), "GradReducer: part of a gradient was not reduced"
+        self.last_collectives = len(self._works)
         for w, t, scale in self._works:
             w.wait()
             if scale:

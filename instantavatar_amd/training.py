@@ -388,9 +388,9 @@ def all_reduce_grads(model, world_size, reducer=None):
     left, waits, and turns sums into means.  Without one: a fresh reducer, i.e. one all-reduce per
     parameter tensor (the 52 MB hash-table gradient as ONE flat bucket; xGMI is point-to-point, so few
     large collectives beat many small ones)."""
-    if world_size <= 1:
+    from .parallel import GradReducer, collectives_on
+    if not collectives_on(world_size):
         return
-    from .parallel import GradReducer
     (reducer or GradReducer(world_size)).finish([p for p in model.parameters()])
 
 
@@ -405,7 +405,8 @@ def update_density_grid(model, world_size=1, jitter=None, differentiable=True):
         return None
     grid = model.renderer.density_grid_train
     hook = None
-    if world_size > 1:
+    from .parallel import collectives_on
+    if collectives_on(world_size):
         from .parallel import reduce_density_cache
         hook = lambda cached: reduce_density_cache(cached, world_size)
     density, valid = grid.update(model.deformer, model.net_coarse, model.global_step, reduce_hook=hook, jitter=jitter,
@@ -445,7 +446,7 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
     model.deformer.prepare_deformer(batch)
     reducer = parallel.GradReducer(world_size)
-    parallel.set_current_reducer(reducer if world_size > 1 else None)
+    parallel.set_current_reducer(reducer if reducer.active else None)
     try:
         reg = update_density_grid(model, world_size, jitter=draws.get("grid_jitter"), differentiable=not is_refine)
         model.net_coarse.initialize(model.deformer.bbox)
@@ -460,12 +461,18 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
             losses["reg"] = reg
             losses["loss"] = losses["loss"] + reg
         optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
+        total = losses["loss"]
+        overflow = getattr(model.renderer, "train_overflow_flag", None)
+        if overflow is not None:
+            # a render that dropped candidates (capacity overflow) must not update anything, on ANY rank: its loss is turned
+            # into NaN before the backward pass, so every gradient of this rank is NaN, the gradient average carries that to
+            # all ranks, and the ordinary non-finite check skips the step everywhere -- no extra collective, no host read
+            total = total * torch.where(overflow > 0, torch.full_like(overflow, float("nan")), torch.ones_like(overflow))
+        total.backward()
         all_reduce_grads(model, world_size, reducer)
     finally:
         parallel.set_current_reducer(None)
     params = [p for g in optimizer.param_groups for p in g["params"]]
-    overflow = getattr(model.renderer, "train_overflow_flag", None)
     model.renderer.train_overflow_flag = None
     losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params, extra_flag=overflow)
     if overflow is not None:
@@ -492,17 +499,27 @@ class GraphedTrainStep:
     next call: clone what must be kept).
 
     Run eagerly, through `training_step`, are: steps that update the occupancy grid (every 20th, DNeRF.py:100;
-    their regulariser changes the autograd graph), several ranks (the bucketed all-reduce) and any batch whose tensor
-    shapes differ from the captured ones.  Models with a `SMPL_param` embedding (fit stage, refinement) are captured
+    their regulariser changes the autograd graph, and with several ranks the cached densities are MAX-reduced) and any batch
+    whose tensor shapes differ from the captured ones.  With several ranks the bucketed all-reduce is part of the captured
+    graph (`graph_collectives`); every rank replays / runs eagerly at the same steps, so the collectives stay matched.  Models with a `SMPL_param` embedding (fit stage, refinement) are captured
     too: the frame index reaches the embedding tables as the device tensor `idx_dev` of the batch.  One graph is
     held per (noise on/off, capacity) state; a candidate-capacity overflow (renderer.train_overflow) drops
     the graphs so that they are captured again with the grown capacity.  Learning rates are turned into
     device tensors, so that an `lr_scheduler` keeps working across replays."""
 
-    def __init__(self, model, optimizer, loss_fn, world_size=1, is_refine=False, enabled=True):
+    def __init__(self, model, optimizer, loss_fn, world_size=1, is_refine=False, enabled=True, graph_collectives=None):
+        """graph_collectives: capture the step of a multi-rank job too -- the bucketed RCCL all-reduce is recorded into the
+        graph together with the kernels (collectives are capturable), so that an N-rank step is launched the same way as a
+        1-rank step instead of ~60 eager launches behind a millisecond of Python.  Default: the environment variable
+        IA_GRAPH_COLLECTIVES (1 = on), else on."""
+        import os
+        from . import parallel
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.world_size, self.is_refine = world_size, is_refine
-        self.enabled = bool(enabled) and world_size == 1
+        if graph_collectives is None:
+            graph_collectives = os.environ.get("IA_GRAPH_COLLECTIVES", "1") != "0"
+        self.graph_collectives = bool(graph_collectives)
+        self.enabled = bool(enabled) and (not parallel.collectives_on(world_size) or self.graph_collectives)
         if getattr(model, "SMPL_param", None) is not None:
             # SMPL parameters under optimisation: capturable on the fused SNARF route only (the SMPLDeformer's training
             # query -- fit stage -- reads validity counts on the host and inverts 6 890 vertex transforms with the LU library)
@@ -543,7 +560,7 @@ class GraphedTrainStep:
         r._graph_capture = True
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = training_step(m, self.inputs, self.optimizer, self.loss_fn, 1, self.is_refine, _capturing=True)
+                out = training_step(m, self.inputs, self.optimizer, self.loss_fn, self.world_size, self.is_refine, _capturing=True)
         finally:
             r._graph_capture = False
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
