@@ -565,13 +565,13 @@ def main():
             frame = eager_frame
 
     n_acc = max(args.in_flight, 1)
-    cnt_sum = torch.zeros(n_acc, device=dev)   # one accumulator per replica / stream: no cross-stream read-modify-write
-    cov_sum = torch.zeros(n_acc, device=dev)
+    stat_acc = torch.zeros((n_acc, 2), device=dev)   # [samples per ray, coverage] per replica / stream: no cross-stream read-modify-write
+    cnt_sum, cov_sum = stat_acc[:, 0], stat_acc[:, 1]
 
     def stats(out, k):
+        """the two per-frame statistics, one launch on the frame's stream (`ia_frame_stats`)"""
         rgb, depth, alpha, counter = out
-        cnt_sum[k:k + 1].add_(counter.mean())
-        cov_sum[k:k + 1].add_((alpha > 0.5).float().mean())
+        _lib.check(L.ia_frame_stats(_lib.ptr(counter), _lib.ptr(alpha), counter.numel(), stat_acc[k].data_ptr(), _lib.stream()), "ia_frame_stats")
 
     frames_done = [0]
 
@@ -603,8 +603,7 @@ def main():
     spinup_ms = (time.perf_counter() - t_spin) * 1e3
     run_frames(0, args.warmup)
     torch.cuda.synchronize()
-    cnt_sum.zero_()
-    cov_sum.zero_()
+    stat_acc.zero_()
     if world_size > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -652,7 +651,7 @@ def main():
         n_sec = min(max(args.steps, 20), 100)
         run_frames(0, 10)
         torch.cuda.synchronize()
-        cnt_sum.zero_(); cov_sum.zero_()
+        stat_acc.zero_()
         t2 = time.perf_counter()
         run_frames(10, n_sec)
         torch.cuda.synchronize()

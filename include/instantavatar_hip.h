@@ -512,6 +512,9 @@ int ia_profile_enable(int on);
 int ia_profile_reset(void);
 int ia_profile_get(int kernel_id, double *total_ms, int64_t *launches,
                    uint64_t *units);
+/* measurement helper: acc2[0] += mean(counter), acc2[1] += mean(alpha > 0.5) over the R rays of a rendered frame
+ * (what a caller logging samples per ray / coverage of a sequence accumulates), one launch.                     */
+int ia_frame_stats(const float *counter, const float *alpha, int R, float *acc2, void *stream);
 /* all n (<= 8) counters of a kernel: id 0 -> {solves, trilinear fetches of the algorithm (fuse_cuda_kernel_fast.cu:
  * one per Broyden evaluation), fetches that loaded memory (a fetch whose 8 corners all lie outside the grid is zero
  * without a load)}; id 1 -> {samples evaluated}.  Synchronises.                                                  */

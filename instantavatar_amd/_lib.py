@@ -124,6 +124,7 @@ _SIGS = {
     "ia_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
     "ia_profile_get_units": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
+    "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
 }
 EXPORTED = sorted(_SIGS)
 

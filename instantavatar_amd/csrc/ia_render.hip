@@ -1033,6 +1033,29 @@ extern "C" int ia_render_test(const float *rays_o, const float *rays_d, const fl
   return IA_OK;
 }
 
+// per-frame statistics a caller accumulates over a sequence (bench.py: samples per ray, alpha coverage): ONE launch
+// instead of a chain of framework reductions behind every frame.  acc[0] += mean(counter), acc[1] += mean(alpha > 0.5).
+__global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ counter, const float *__restrict__ alpha, int R,
+                                                     float *__restrict__ acc) {
+  float c = 0.f, a = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+    c += counter[i];
+    a += alpha[i] > 0.5f ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); a += __shfl_xor(a, o, 64); }
+  if (ia_lane() == 0) { atomicAdd(acc, c / (float)R); atomicAdd(acc + 1, a / (float)R); }
+}
+
+extern "C" int ia_frame_stats(const float *counter, const float *alpha, int R, float *acc2, void *stream) {
+  IA_CHECK_ARG(counter && alpha && acc2 && R > 0, "ia_frame_stats: bad arguments");
+  int blocks = ia_div_up(R, 256 * 8);
+  if (blocks > 128) blocks = 128;
+  hipLaunchKernelGGL(k_frame_stats, dim3(blocks), dim3(256), 0, (hipStream_t)stream, counter, alpha, R, acc2);
+  IA_LAUNCH_CHECK("k_frame_stats");
+  return IA_OK;
+}
+
 extern "C" int ia_transform_rays_w2s(const float *rays_o, const float *rays_d, const float *w2s, int R, float *o_out,
                                      float *d_out, float *near, float *far, void *stream) {
   IA_CHECK_ARG(R >= 0, "ia_transform_rays_w2s: R < 0");

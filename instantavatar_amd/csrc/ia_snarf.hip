@@ -347,24 +347,32 @@ __device__ __forceinline__ bool fetch_J(const float *__restrict__ vJ, const Snar
 // tools/ubench/records64.hip (B4 against A): 33.5 against 21.9 G fetches/s L2-resident, 53.5 against 35.8 L1-resident.
 // All DPP traffic happens in wave-uniform control flow (a DPP read from a lane that EXEC has switched off returns
 // nothing); only the loads are predicated.
-// MEASURED IN THE KERNEL (round 3, MI355X, bit-identical results -- the parity tests pass with it): the L1 look-ups drop
-// as predicted, 98.5 M -> 57.7 M per launch, but the broadcasts, the per-round address arithmetic and the row delivery
-// raise the VALU instructions from 47.9 M to 110 M per launch and the registers from 91 to 143 (3 waves per SIMD instead of
-// 5): the kernel turns VALU-bound (110 M x 4 clk / 1 024 SIMDs = 179 us of issue per launch) and the compact search of a
-// frame's 213 k sample points takes 297 us instead of 246 us (IA_QUAD_GROUP 4 / 2: 300 / 301 us; 4 waves forced: 295-333 us).
-// OFF by default; kept as the measured alternative (tools/ab_search.sh "-DIA_SEARCH_QUAD=1").
+// MEASURED IN THE KERNEL (round 3, MI355X; results bit-identical to the lane-per-fetch path, the parity tests pass with
+// either).  First version (predicated loads with zero-filled registers, DPP broadcasts with an initialised `old`, 128 x 32
+// workgroups): L1 look-ups 98.5 M -> 57.7 M per launch as predicted, but VALU instructions 47.9 M -> 110 M and 143 VGPRs
+// (3 waves per SIMD): VALU-bound, 297 us against 246 us for the compact search of a frame's 213 k sample points.
+// This version (mov_dpp folded into the consuming v_add / v_cndmask, unconditional clamped loads, 256 x 64 workgroups):
+// 66.9 M VALU instructions, 69.6 M look-ups, 124 VGPRs (4 waves per SIMD): 218 us against 245 us in isolation (-11 %),
+// 485 -> 501 frames/s for the whole frame.  IA_QUAD_GROUP-style splitting of a round, a forced fifth wave (96 VGPRs,
+// spills: 380 us) and 128 x 32 / 128 x 64 / 256 x 128 / 512 x 128 / 64 x 16 workgroups (234 / 224 / 224 / 226 / 259 us)
+// measured and rejected.  tools/ab_search.sh "-DIA_SEARCH_QUAD=0" gives the lane-per-fetch path.
 #ifndef IA_SEARCH_QUAD
-#define IA_SEARCH_QUAD 0
+#define IA_SEARCH_QUAD 1
+#endif
+#ifndef IA_QUAD_PREDICATE
+#define IA_QUAD_PREDICATE 1   // 0: every quad loads in every round (no EXEC juggling, wasted look-ups for idle lanes)
 #endif
 template <int S> __device__ __forceinline__ float quad_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), S * 0x55, 0xF, 0xF, false));
+  // (mov_dpp = update_dpp with an undefined `old` and bound_ctrl: one v_mov_b32_dpp, which the DPP combiner can fold into
+  // the VOP2 instruction that consumes it; all four lanes of a quad are always enabled where this is used)
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), S * 0x55, 0xF, 0xF, true));
 }
 template <int S> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S * 0x55, 0xF, 0xF, true);
 }
 
-// what a lane contributes to its round: record offsets (clamped into the grid) and weights (0 for corners outside) of the
-// 8 corners in the reference order, and whether anything has to be loaded at all
+// what a lane contributes to its round: BYTE offsets of the 8 corner records (clamped into the grid) and their weights
+// (0 for corners outside, and for a lane that is not active) in the reference order, and whether anything is needed at all
 struct FetchPlan {
   uint32_t off[8];
   float w[8];
@@ -387,60 +395,48 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
   for (int k = 0; k < 8; k++) {
     const int xx = (k & 1) ? cx1 : cx0, yy = (k & 2) ? cy1 : cy0, zz = (k & 4) ? cz1 : cz0;
     const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
-    p.off[k] = (uint32_t)((zz * g.H + yy) * g.W + xx) * 12u;
+    p.off[k] = (uint32_t)((zz * g.H + yy) * g.W + xx) * 48u;
     p.w[k] = in ? wgt[k] : 0.f;
   }
   p.load = (active && (bx0 || bx1) && (by0 || by1) && (bz0 || bz1)) ? 1u : 0u;
 }
 
-#ifndef IA_QUAD_GROUP
-#define IA_QUAD_GROUP 8   // corner records whose loads are in flight together within a round (8 = one round trip per round)
-#endif
-// round T of the quad: serve the fetch of lane T.  Wave-uniform control flow outside the load predicate.
+// round T of the quad: serve the fetch of lane T.  Wave-uniform control flow throughout: every lane loads (addresses are
+// clamped into the grid, so a load is always legal; the fourth lane of a quad repeats the third piece -- the same 16 bytes,
+// no extra look-up), and a fetch with all corners outside has all weights 0: fma(v, 0, +0) = +0 for the finite table values,
+// exactly the zeros the reference's skipped corners leave.
 template <int T>
-__device__ __forceinline__ void fetch_round(const float *__restrict__ vJ, const FetchPlan &p, int k, float *__restrict__ out) {
+__device__ __forceinline__ void fetch_round(const char *__restrict__ vJb, const FetchPlan &p, uint32_t koff, bool not_mine,
+                                            float *__restrict__ out) {
   const uint32_t load = quad_bcast<T>(p.load);
-  if (__ballot(load != 0) == 0) {   // nobody in this wave has an active lane T with a corner inside: rows are zero
-    if (k == T) {
-#pragma unroll
-      for (int c = 0; c < 12; c++) out[c] = 0.f;
-    }
-    return;
-  }
-  uint32_t off[8];
-  float w[8];
-#pragma unroll
-  for (int c = 0; c < 8; c++) { off[c] = quad_bcast<T>(p.off[c]); w[c] = quad_bcast<T>(p.w[c]); }
+  if (__ballot(load != 0) == 0) return;   // no lane T of this wave needs anything: `out` stays zero (cleared by the caller)
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
-  const bool mine = load != 0 && k < 3;
+#if IA_QUAD_PREDICATE
+  // quads whose lane T is idle (or has all 8 corners outside) sit the round out: `load` is uniform within a quad, so the
+  // DPP broadcasts inside the branch read enabled lanes only
+  if (load != 0)
+#endif
+  {
+    float4 v[8];
 #pragma unroll
-  for (int c0 = 0; c0 < 8; c0 += IA_QUAD_GROUP) {
-    float4 v[IA_QUAD_GROUP];
+    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_bcast<T>(p.off[c]) + koff));
 #pragma unroll
-    for (int j = 0; j < IA_QUAD_GROUP; j++) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mine) {
-#pragma unroll
-      for (int j = 0; j < IA_QUAD_GROUP; j++) v[j] = *reinterpret_cast<const float4 *>(vJ + off[c0 + j] + (uint32_t)k * 4u);
-    }
-#pragma unroll
-    for (int j = 0; j < IA_QUAD_GROUP; j++) {
-      const f2 w2 = (f2){w[c0 + j], w[c0 + j]};
-      a0 = __builtin_elementwise_fma((f2){v[j].x, v[j].y}, w2, a0);
-      a1 = __builtin_elementwise_fma((f2){v[j].z, v[j].w}, w2, a1);
-    }
-    if (IA_QUAD_GROUP < 8) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < 8; c++) {
+      const float w = quad_bcast<T>(p.w[c]);
+      const f2 w2 = (f2){w, w};
+      a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
+      a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
     }
   }
-  // rows 0..2 (lanes 0..2 of the quad) back to the target lane
-  const float r[12] = {quad_bcast<0>(a0.x), quad_bcast<0>(a0.y), quad_bcast<0>(a1.x), quad_bcast<0>(a1.y),
-                       quad_bcast<1>(a0.x), quad_bcast<1>(a0.y), quad_bcast<1>(a1.x), quad_bcast<1>(a1.y),
-                       quad_bcast<2>(a0.x), quad_bcast<2>(a0.y), quad_bcast<2>(a1.x), quad_bcast<2>(a1.y)};
-  if (k == T) {
+  // rows 0..2 (lanes 0..2 of the quad) back to the target lane: out = not_mine ? out : row (v_cndmask with a DPP source)
+  const float a[4] = {a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
-    for (int c = 0; c < 12; c++) out[c] = r[c];
+  for (int c = 0; c < 4; c++) {
+    const float r0 = quad_bcast<0>(a[c]), r1 = quad_bcast<1>(a[c]), r2 = quad_bcast<2>(a[c]);
+    out[c] = not_mine ? out[c] : r0;
+    out[4 + c] = not_mine ? out[4 + c] : r1;
+    out[8 + c] = not_mine ? out[8 + c] : r2;
   }
 }
 
@@ -451,10 +447,18 @@ __device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const
   fetch_plan(g, gx, gy, gz, active, p);
   loaded = p.load != 0;
   const int k = threadIdx.x & 3;
-  fetch_round<0>(vJ, p, k, out);
-  fetch_round<1>(vJ, p, k, out);
-  fetch_round<2>(vJ, p, k, out);
-  fetch_round<3>(vJ, p, k, out);
+  const uint32_t koff = (uint32_t)min(k, 2) * 16u;
+  const char *vJb = reinterpret_cast<const char *>(vJ);
+#pragma unroll
+  for (int c = 0; c < 12; c++) out[c] = 0.f;
+#ifndef IA_QUAD_FENCE
+#define IA_QUAD_FENCE 0   // 1: keep the compiler from hoisting the next round's loads above this round's arithmetic (fewer registers)
+#endif
+#define IA_QUAD_ROUND_END() do { if (IA_QUAD_FENCE) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+  fetch_round<0>(vJb, p, koff, k != 0, out); IA_QUAD_ROUND_END();
+  fetch_round<1>(vJb, p, koff, k != 1, out); IA_QUAD_ROUND_END();
+  fetch_round<2>(vJb, p, koff, k != 2, out); IA_QUAD_ROUND_END();
+  fetch_round<3>(vJb, p, koff, k != 3, out);
 }
 
 // fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55)
@@ -498,10 +502,18 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 // group 2 = 2.55 ms against 2.66 ms; group 2 alone 2.71, 32 points alone (group 4) 3.08, group 1 (82 VGPRs, still 5
 // waves) 2.67, forcing 6 waves per SIMD (spills) 2.86, 64 x 32 2.67, 64 x 16 2.58, 256 x 32 2.68, 256 x 64 2.62.
 #ifndef IA_SEARCH_NP
+#if IA_SEARCH_QUAD
+#define IA_SEARCH_NP 64        // quad-cooperative fetch, round 3: 256 x 64 218 us, 128 x 32 234, 128 x 64 224, 256 x 128 224, 512 x 128 226, 64 x 16 259
+#else
 #define IA_SEARCH_NP 32        // points per workgroup (power of two, <= 128): 9.6 KB of LDS, 16 workgroups per CU
 #endif
+#endif
 #ifndef IA_SEARCH_THREADS
+#if IA_SEARCH_QUAD
+#define IA_SEARCH_THREADS 256
+#else
 #define IA_SEARCH_THREADS 128  // multiple of IA_SEARCH_NP
+#endif
 #endif
 #ifdef IA_SEARCH_WAVES_PER_EU
 #define IA_SEARCH_ATTR __attribute__((amdgpu_waves_per_eu(IA_SEARCH_WAVES_PER_EU, IA_SEARCH_WAVES_PER_EU)))

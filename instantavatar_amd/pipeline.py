@@ -107,8 +107,12 @@ class GraphedRenderer:
     def __call__(self, batch):
         self._poll()
         slot = self.calls % self.DEPTH
-        for k in ("global_orient", "body_pose", "transl", "near", "far"):
-            self.static[k].copy_(batch[k], non_blocking=True)
+        # (near / far of the batch are dead inputs on this path: transform_rays_w2s recomputes them from the ray origins in
+        # the SMPL-root frame, snarf_deformer.py:101-103 -- two 1 MB copies per frame that nobody read)
+        dst = [self.static[k] for k in ("global_orient", "body_pose", "transl")]
+        src = [batch[k] for k in ("global_orient", "body_pose", "transl")]
+        if any(d.data_ptr() != s_.data_ptr() for d, s_ in zip(dst, src)):
+            torch._foreach_copy_(dst, src, non_blocking=True)   # one launch for the 75 pose floats
         self.graph.replay()
         self._host[slot:slot + 1].copy_(self.model.renderer._n_alive_dev[:1], non_blocking=True)
         ev = torch.cuda.Event()
@@ -165,7 +169,7 @@ class PipelinedRenderer:
         self.streams[k].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.streams[k]):
             out = self.graphs[k](batch)
-            for key in ("global_orient", "body_pose", "transl", "near", "far"):   # read on this stream: tell the allocator, or a
+            for key in ("global_orient", "body_pose", "transl"):   # read on this stream: tell the allocator, or a
                 if torch.is_tensor(batch.get(key)):                                # freed input could be reused before the copy ran
                     batch[key].record_stream(self.streams[k])
             if consume is not None:
