@@ -106,6 +106,14 @@ int ia_smpl_tfs(const float *joints_rest, const int32_t *parents,
                 const float *pose, const float *transl, const float *tfs_inv_t,
                 float *tfs, float *w2s, float *A, void *stream);
 
+/* Backward of ia_smpl_tfs for SMPL-parameter optimisation (DNeRF.py:113-128 -> lbs.py under autograd in the
+ * reference): d_tfs [24,4,4] (rows 0..2 are read) -> d_pose [72] and, optionally, d_transl [3] (analytically zero:
+ * the bone transforms are expressed in the SMPL-root frame; what comes out is rounding noise, as in the reference).
+ * The forward quantities are recomputed from the same inputs as ia_smpl_tfs.                                      */
+int ia_smpl_tfs_bwd(const float *joints_rest, const int32_t *parents, const float *pose,
+                    const float *transl, const float *tfs_inv_t, const float *d_tfs,
+                    float *d_pose, float *d_transl, void *stream);
+
 /* ---- SMPLDeformer (nearest-vertex deformer plugin) ------------------
  * Replaces SMPLDeformer.deform (deformers/smpl_deformer.py:86-110) incl. the pytorch3d
  * knn_points call (K = 1): for every point the nearest of the n_verts posed SMPL vertices
@@ -218,6 +226,7 @@ int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const uint8_t *va
  * first min(cap, *n_cand) rows are live (n_cand: device int32, no host read).  Workspace as above for n = cap. */
 int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *cand_Jinv, const float *grad_xc,
                                   long cap, const int32_t *n_cand, const float *voxel_w,
+                                  int channel_last /* voxel_w is [D,H,W,24] instead of [24,D,H,W] */,
                                   const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes,
                                   void *stream);
 

@@ -44,6 +44,7 @@ _SIGS = {
     "ia_last_error": (C.c_char_p, []),
     "ia_hash_desc_init": (C.c_int, [C.POINTER(HashDesc), C.c_int, C.c_int, C.c_int, C.c_float]),
     "ia_smpl_tfs": (C.c_int, [_VP] * 8 + [_VP]),
+    "ia_smpl_tfs_bwd": (C.c_int, [_VP] * 9),
     "ia_voxelise_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ia_voxelise_weights": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP]),
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
@@ -85,7 +86,7 @@ _SIGS = {
                                        C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_snarf_implicit_bwd_workspace_bytes": (C.c_size_t, [C.c_long]),
     "ia_snarf_implicit_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, _VP, C.POINTER(SnarfGrid), _VP, _VP, C.c_size_t, _VP]),
-    "ia_snarf_implicit_bwd_compact": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, C.POINTER(SnarfGrid), _VP, _VP, C.c_size_t, _VP]),
+    "ia_snarf_implicit_bwd_compact": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, C.c_int, C.POINTER(SnarfGrid), _VP, _VP, C.c_size_t, _VP]),
     "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 5),
     "ia_field_grad_scale": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "ia_field_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -121,6 +121,186 @@ __global__ void k_smpl_tfs(const float *__restrict__ joints, const int32_t *__re
 }
 
 // ---------------------------------------------------------------------------
+// a1/a2 backward: dL/dtfs [24,4,4] (rows 0..2) -> dL/dpose [72], dL/dtransl [3].
+// What autograd does for the reference when the SMPL parameters are optimised (DNeRF.py:113-128: prepare_deformer runs
+// lbs.py under autograd -- ~120 tiny launches forward, ~250 backward): here the forward quantities are recomputed and
+// the chain rule is written out, one launch of one wave:
+//   tfs_j = W A_j B_j,  W = A_0^-1,  A_j = [RG_j | g_j - RG_j J_j + tau],  G_j = G_p(j) L_j,  L_j = [R(theta_j) | rel_j]
+//   E_j = D_j B_j^T;  dA_j = R_W^T E_j;  dW = sum_j E_j A_j^T;  dA_0 -= W^T dW W^T   (rows 0..2 throughout)
+//   dRG_j = dA_j[:, :3] - dA_j[:, 3] J_j^T;  dg_j = dA_j[:, 3];  dtau = sum_j dg_j
+//   children before parents:  dRG_p += dRG_j R_j^T + dg_j rel_j^T;  dg_p += dg_j;  dR_j = RG_p^T dRG_j
+//   Rodrigues (lbs.py:295-329; angle = |theta + 1e-8|, dir = theta / angle):  dR_j -> dtheta_j
+// ---------------------------------------------------------------------------
+__global__ void k_smpl_tfs_bwd(const float *__restrict__ joints, const int32_t *__restrict__ parents,
+                               const float *__restrict__ pose, const float *__restrict__ transl,
+                               const float *__restrict__ tfs_inv_t, const float *__restrict__ d_tfs,
+                               float *__restrict__ d_pose, float *__restrict__ d_transl) {
+  __shared__ float tm[24][16];      // L_j
+  __shared__ float chain[24][16];   // G_j
+  __shared__ float A[24][12];       // rows 0..2 of A_j
+  __shared__ float W[16];
+  __shared__ float E[24][12];       // rows 0..2 of D_j B_j^T
+  __shared__ float dA[24][12];
+  __shared__ float dRG[24][9], dg[24][3], dRl[24][9];
+  __shared__ float dW[12];
+  __shared__ int s_par[24];
+  const int j = threadIdx.x;
+  float ang = 1.f, sn = 0.f, cs = 1.f, dir[3] = {0, 0, 0}, K[9], KK[9];
+  if (j < 24) {
+    s_par[j] = parents[j];
+    const float rx = pose[j * 3], ry = pose[j * 3 + 1], rz = pose[j * 3 + 2];
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    ang = sqrtf(ax * ax + ay * ay + az * az);
+    dir[0] = rx / ang; dir[1] = ry / ang; dir[2] = rz / ang;
+    cs = cosf(ang); sn = sinf(ang);
+    const float k[9] = {0, -dir[2], dir[1], dir[2], 0, -dir[0], -dir[1], dir[0], 0};
+    for (int a = 0; a < 9; a++) K[a] = k[a];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        float v = 0.f;
+        for (int q = 0; q < 3; q++) v += K[a * 3 + q] * K[q * 3 + b];
+        KK[a * 3 + b] = v;
+      }
+    const int p = parents[j];
+    float rel[3] = {joints[j * 3], joints[j * 3 + 1], joints[j * 3 + 2]};
+    if (j > 0) { rel[0] -= joints[p * 3]; rel[1] -= joints[p * 3 + 1]; rel[2] -= joints[p * 3 + 2]; }
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) tm[j][a * 4 + b] = (a == b ? 1.f : 0.f) + sn * K[a * 3 + b] + (1.f - cs) * KK[a * 3 + b];
+      tm[j][a * 4 + 3] = rel[a];
+    }
+    tm[j][12] = 0; tm[j][13] = 0; tm[j][14] = 0; tm[j][15] = 1;
+  }
+  __syncthreads();
+  if (j < 16) chain[0][j] = tm[0][j];
+  __syncthreads();
+  for (int i = 1; i < 24; i++) {
+    if (j < 16) {
+      const int a = j >> 2, b = j & 3;
+      const float *pa = chain[s_par[i]];
+      float acc = 0.f;
+      for (int q = 0; q < 4; q++) acc += pa[a * 4 + q] * tm[i][q * 4 + b];
+      chain[i][j] = acc;
+    }
+    __syncthreads();
+  }
+  if (j < 24) {
+    const float jx = joints[j * 3], jy = joints[j * 3 + 1], jz = joints[j * 3 + 2];
+    for (int a = 0; a < 3; a++) {
+      const float t = chain[j][a * 4 + 0] * jx + chain[j][a * 4 + 1] * jy + chain[j][a * 4 + 2] * jz;
+      for (int b = 0; b < 3; b++) A[j][a * 4 + b] = chain[j][a * 4 + b];
+      A[j][a * 4 + 3] = chain[j][a * 4 + 3] - t + (transl ? transl[a] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (j == 0) {  // W = inverse(A_0): Gauss-Jordan with partial pivoting, as the forward kernel
+    float m[4][8];
+    for (int a = 0; a < 4; a++)
+      for (int b = 0; b < 4; b++) { m[a][b] = a < 3 ? A[0][a * 4 + b] : (b == 3 ? 1.f : 0.f); m[a][4 + b] = (a == b) ? 1.f : 0.f; }
+    for (int col = 0; col < 4; col++) {
+      int piv = col;
+      for (int r = col + 1; r < 4; r++) if (fabsf(m[r][col]) > fabsf(m[piv][col])) piv = r;
+      if (piv != col) for (int b = 0; b < 8; b++) { float t = m[col][b]; m[col][b] = m[piv][b]; m[piv][b] = t; }
+      const float inv = 1.f / m[col][col];
+      for (int b = 0; b < 8; b++) m[col][b] *= inv;
+      for (int r = 0; r < 4; r++) if (r != col) {
+        const float f = m[r][col];
+        for (int b = 0; b < 8; b++) m[r][b] -= f * m[col][b];
+      }
+    }
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) W[a * 4 + b] = m[a][4 + b];
+  }
+  __syncthreads();
+  if (j < 24) {
+    // E_j = D_j B_j^T (rows 0..2);  dA_j = R_W^T E_j
+    const float *B = tfs_inv_t + j * 16, *D = d_tfs + j * 16;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 4; b++) {
+        float v = 0.f;
+        for (int q = 0; q < 4; q++) v += D[a * 4 + q] * B[b * 4 + q];
+        E[j][a * 4 + b] = v;
+      }
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 4; b++) {
+        float v = 0.f;
+        for (int q = 0; q < 3; q++) v += W[q * 4 + a] * E[j][q * 4 + b];
+        dA[j][a * 4 + b] = v;
+      }
+  }
+  __syncthreads();
+  if (j < 12) {  // dW = sum_j E_j A_j^T (rows 0..2; A_j's fourth row is (0,0,0,1)), joints in a fixed order
+    const int a = j >> 2, b = j & 3;
+    float v = 0.f;
+    for (int i = 0; i < 24; i++) {
+      float t = 0.f;
+      for (int q = 0; q < 4; q++) t += E[i][a * 4 + q] * (b < 3 ? A[i][b * 4 + q] : (q == 3 ? 1.f : 0.f));
+      v += t;
+    }
+    dW[j] = v;
+  }
+  __syncthreads();
+  if (j < 12) {  // dA_0 -= (W^T dW W^T) rows 0..2, dW's fourth row = 0
+    const int a = j >> 2, b = j & 3;
+    float v = 0.f;
+    for (int q = 0; q < 3; q++)       // (W^T dW)[a][r] = sum_q W[q][a] dW[q][r]
+      for (int r = 0; r < 4; r++) v += W[q * 4 + a] * dW[q * 4 + r] * W[b * 4 + r];   // ... * (W^T)[r][b] = W[b][r]
+    dA[0][a * 4 + b] -= v;
+  }
+  __syncthreads();
+  float d_tau[3] = {0, 0, 0};
+  if (j < 24) {
+    const float jx[3] = {joints[j * 3], joints[j * 3 + 1], joints[j * 3 + 2]};
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) dRG[j][a * 3 + b] = dA[j][a * 4 + b] - dA[j][a * 4 + 3] * jx[b];
+      dg[j][a] = dA[j][a * 4 + 3];
+    }
+  }
+  __syncthreads();
+  if (j == 0) {
+    for (int a = 0; a < 3; a++) { float v = 0.f; for (int i = 0; i < 24; i++) v += dg[i][a]; d_tau[a] = v; }
+    if (d_transl) { d_transl[0] = d_tau[0]; d_transl[1] = d_tau[1]; d_transl[2] = d_tau[2]; }
+    // children before parents (parents[i] < i in the SMPL tree)
+    for (int i = 23; i >= 1; i--) {
+      const int p = s_par[i];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          float v = 0.f;
+          for (int q = 0; q < 3; q++) v += chain[p][q * 4 + a] * dRG[i][q * 3 + b];   // dR_i = RG_p^T dRG_i
+          dRl[i][a * 3 + b] = v;
+        }
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) {
+          float v = dg[i][a] * tm[i][b * 4 + 3];                                       // dg_i rel_i^T
+          for (int q = 0; q < 3; q++) v += dRG[i][a * 3 + q] * tm[i][b * 4 + q];        // dRG_i R_i^T
+          dRG[p][a * 3 + b] += v;
+        }
+        dg[p][a] += dg[i][a];
+      }
+    }
+    for (int a = 0; a < 9; a++) dRl[0][a] = dRG[0][a];
+  }
+  __syncthreads();
+  if (j < 24) {
+    // Rodrigues backward: R = I + sin(a) K + (1 - cos a) K^2
+    const float *dR = dRl[j];
+    float dK[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        float v = sn * dR[a * 3 + b];
+        for (int q = 0; q < 3; q++) v += (1.f - cs) * (dR[a * 3 + q] * K[b * 3 + q] + K[q * 3 + a] * dR[q * 3 + b]);   // dR K^T + K^T dR
+        dK[a * 3 + b] = v;
+      }
+    float dRK = 0.f, dRKK = 0.f;
+    for (int a = 0; a < 9; a++) { dRK += dR[a] * K[a]; dRKK += dR[a] * KK[a]; }
+    const float d_ang = cs * dRK + sn * dRKK;
+    const float d_dir[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    const float th[3] = {pose[j * 3], pose[j * 3 + 1], pose[j * 3 + 2]};
+    const float dot = d_dir[0] * th[0] + d_dir[1] * th[1] + d_dir[2] * th[2];
+    const float coef = d_ang - dot / (ang * ang);
+    for (int a = 0; a < 3; a++) d_pose[j * 3 + a] = d_dir[a] / ang + coef * (th[a] + 1e-8f) / ang;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // a3: precompute.  One thread per voxel.  voxel_w is read channel-major
 // (coalesced per joint plane); tfs is wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------
@@ -813,6 +993,15 @@ extern "C" int ia_smpl_tfs(const float *joints_rest, const int32_t *parents, con
   return IA_OK;
 }
 
+extern "C" int ia_smpl_tfs_bwd(const float *joints_rest, const int32_t *parents, const float *pose, const float *transl,
+                               const float *tfs_inv_t, const float *d_tfs, float *d_pose, float *d_transl, void *stream) {
+  IA_CHECK_ARG(joints_rest && parents && pose && tfs_inv_t && d_tfs && d_pose, "ia_smpl_tfs_bwd: null pointer");
+  hipLaunchKernelGGL(k_smpl_tfs_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, joints_rest, parents, pose, transl, tfs_inv_t,
+                     d_tfs, d_pose, d_transl);
+  IA_LAUNCH_CHECK("k_smpl_tfs_bwd");
+  return IA_OK;
+}
+
 static int ia_precompute_blocks(const ia_snarf_grid *grid) {
   const long nt = (long)grid->D * grid->H * grid->W / IA_PRE_VPT;
   return (int)((nt + 255) / 256 < 8192 ? (nt + 255) / 256 : 8192);
@@ -941,6 +1130,9 @@ __device__ __forceinline__ float id_border_index(float g, int size) {
   return c;
 }
 
+// CL: voxel_w is channel-LAST [D,H,W,24] (96 contiguous bytes per voxel: six 16-byte loads per corner instead of 24 four-byte
+// loads 2 MB apart; the refine step's launch went from 176 us to the figure in DESIGN.md with it)
+template <bool CL>
 __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
     const float *__restrict__ xc, const float *__restrict__ J_inv, const uint8_t *__restrict__ valid,
     const float *__restrict__ grad, long n, const int32_t *__restrict__ n_dev, const float *__restrict__ voxel_w,
@@ -984,9 +1176,19 @@ __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
             const int xx = xa + cx, yy = ya + cy, zz = za + cz;
             if (xx >= g.W || yy >= g.H || zz >= g.D) continue;  // only at the clamped border, weight 0
             const float wt = (cx ? fx : 1.f - fx) * (cy ? fy : 1.f - fy) * (cz ? fz : 1.f - fz);
-            const float *p = voxel_w + ((long)zz * g.H + yy) * g.W + xx;
+            if (CL) {
+              const float4 *p4 = reinterpret_cast<const float4 *>(voxel_w + (((long)zz * g.H + yy) * g.W + xx) * 24);
 #pragma unroll
-            for (int k = 0; k < 24; k++) w[k] = __builtin_fmaf(wt, p[(long)k * vol], w[k]);
+              for (int q = 0; q < 6; q++) {
+                const float4 v = p4[q];
+                w[4 * q] = __builtin_fmaf(wt, v.x, w[4 * q]); w[4 * q + 1] = __builtin_fmaf(wt, v.y, w[4 * q + 1]);
+                w[4 * q + 2] = __builtin_fmaf(wt, v.z, w[4 * q + 2]); w[4 * q + 3] = __builtin_fmaf(wt, v.w, w[4 * q + 3]);
+              }
+            } else {
+              const float *p = voxel_w + ((long)zz * g.H + yy) * g.W + xx;
+#pragma unroll
+              for (int k = 0; k < 24; k++) w[k] = __builtin_fmaf(wt, p[(long)k * vol], w[k]);
+            }
           }
     }
     __syncthreads();  // previous tile consumed
@@ -1010,13 +1212,20 @@ __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
   if (tid + IA_ID_THREADS < 288) partial[(size_t)blockIdx.x * 288 + tid + IA_ID_THREADS] = acc1;
 }
 
-__global__ __launch_bounds__(288) void k_implicit_bwd_reduce(const float *__restrict__ partial, int n_blocks,
-                                                             float *__restrict__ d_tfs) {
-  const int o = threadIdx.x;  // bone * 12 + row * 4 + col
+// one wave per output o = bone * 12 + row * 4 + col: lanes sum the per-workgroup partials b = lane, lane + 64, ... and the
+// wave folds them in a fixed order (a single 288-thread workgroup walking up to 1 024 partials one dependent load after the
+// other took 225 us in the refine step)
+__global__ __launch_bounds__(64) void k_implicit_bwd_reduce(const float *__restrict__ partial, int n_blocks,
+                                                            float *__restrict__ d_tfs) {
+  const int o = blockIdx.x;
   float acc = 0.f;
-  for (int b = 0; b < n_blocks; b++) acc += partial[(size_t)b * 288 + o];
-  const int bone = o / 12, q = o - bone * 12;
-  d_tfs[bone * 16 + q] += acc;  // rows 0..2 of the 4x4; row 3 has no gradient
+  for (int b = threadIdx.x; b < n_blocks; b += 64) acc += partial[(size_t)b * 288 + o];
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k, 64);
+  if (threadIdx.x == 0) {
+    const int bone = o / 12, q = o - bone * 12;
+    d_tfs[bone * 16 + q] += acc;  // rows 0..2 of the 4x4; row 3 has no gradient
+  }
 }
 
 static int ia_implicit_blocks(long n) {
@@ -1029,15 +1238,20 @@ extern "C" size_t ia_snarf_implicit_bwd_workspace_bytes(long n) { return (size_t
 
 static int ia_implicit_bwd_impl(const char *who, const float *xc, const float *J_inv, const uint8_t *valid,
                                 const float *grad_xc, long n, const int32_t *n_dev, const float *voxel_w,
-                                const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes, hipStream_t s) {
+                                const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes, hipStream_t s,
+                                bool channel_last = false) {
   IA_CHECK_ARG(n >= 0, "%s: n < 0", who);
   if (n == 0) return IA_OK;
   IA_CHECK_ARG(xc && J_inv && (valid || n_dev) && grad_xc && voxel_w && grid && d_tfs && ws, "%s: null pointer", who);
   if (ws_bytes < ia_snarf_implicit_bwd_workspace_bytes(n)) return ia_set_error(IA_ERR_WORKSPACE, "%s: workspace too small", who);
   const int blocks = ia_implicit_blocks(n);
-  hipLaunchKernelGGL(k_implicit_bwd, dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev, voxel_w,
-                     ia_make_grid_dev(grid), static_cast<float *>(ws));
-  hipLaunchKernelGGL(k_implicit_bwd_reduce, dim3(1), dim3(288), 0, s, static_cast<const float *>(ws), blocks, d_tfs);
+  if (channel_last)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_implicit_bwd<true>), dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev,
+                       voxel_w, ia_make_grid_dev(grid), static_cast<float *>(ws));
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_implicit_bwd<false>), dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev,
+                       voxel_w, ia_make_grid_dev(grid), static_cast<float *>(ws));
+  hipLaunchKernelGGL(k_implicit_bwd_reduce, dim3(288), dim3(64), 0, s, static_cast<const float *>(ws), blocks, d_tfs);
   IA_LAUNCH_CHECK("k_implicit_bwd");
   return IA_OK;
 }
@@ -1050,11 +1264,11 @@ extern "C" int ia_snarf_implicit_bwd(const float *xc, const float *J_inv, const 
 }
 
 extern "C" int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *cand_Jinv, const float *grad_xc, long cap,
-                                             const int32_t *n_cand, const float *voxel_w, const ia_snarf_grid *grid,
-                                             float *d_tfs, void *ws, size_t ws_bytes, void *stream) {
+                                             const int32_t *n_cand, const float *voxel_w, int channel_last,
+                                             const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes, void *stream) {
   IA_CHECK_ARG(n_cand, "ia_snarf_implicit_bwd_compact: n_cand is null");
   return ia_implicit_bwd_impl("ia_snarf_implicit_bwd_compact", cand_xc, cand_Jinv, nullptr, grad_xc, cap, n_cand, voxel_w,
-                              grid, d_tfs, ws, ws_bytes, (hipStream_t)stream);
+                              grid, d_tfs, ws, ws_bytes, (hipStream_t)stream, channel_last != 0);
 }
 
 // Resource usage of the search kernel as compiled into THIS library (bench.py reports it next to the counters instead

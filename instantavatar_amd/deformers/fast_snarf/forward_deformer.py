@@ -75,6 +75,15 @@ class ForwardDeformer(torch.nn.Module):
         self.register_buffer("grid_denorm", grid_denorm)
         self._grid_c = None
 
+    def lbs_voxel_channel_last(self):
+        """the skinning-weight volume as [D,H,W,24] (made once, on first use: only the SMPL-refinement backward gathers the 24
+        weights of single voxels; `precompute` streams the channel-major planes)"""
+        cl = getattr(self, "_lbs_cl", None)
+        if cl is None or cl.data_ptr() == 0 or getattr(self, "_lbs_cl_src", None) != self.lbs_voxel_final.data_ptr():
+            cl = self._lbs_cl = self.lbs_voxel_final[0].permute(1, 2, 3, 0).contiguous()
+            self._lbs_cl_src = self.lbs_voxel_final.data_ptr()
+        return cl
+
     def normalize(self, x):
         y = (x - self.offset) / self.scale
         return torch.cat([y[..., :2], y[..., 2:] * self.ratio], dim=-1)
@@ -226,7 +235,7 @@ class _ImplicitDiffCompactFn(torch.autograd.Function):
         d_tfs = torch.zeros(ctx.tfs_shape, device=xc.device)
         ws = torch.empty(int(L.ia_snarf_implicit_bwd_workspace_bytes(cap)), dtype=torch.uint8, device=xc.device)
         _lib.check(L.ia_snarf_implicit_bwd_compact(_lib.ptr(xc), _lib.ptr(J_inv), _lib.ptr(gg), cap, _lib.ptr(n_cand),
-                                                   _lib.ptr(d.lbs_voxel_final), C.byref(d.grid_desc()), _lib.ptr(d_tfs),
+                                                   _lib.ptr(d.lbs_voxel_channel_last()), 1, C.byref(d.grid_desc()), _lib.ptr(d_tfs),
                                                    _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_implicit_bwd_compact")
         return d_tfs, None, None, None, None
 

@@ -47,6 +47,10 @@ def get_bbox_from_smpl(vs, factor=1.2):
     return torch.cat([c - s[:, None], c + s[:, None]], dim=0)
 
 
+#: prepare_deformer's backward through `ia_smpl_tfs_bwd` (False: lbs.py-style torch ops under autograd, the kernels' checker)
+FUSED_SMPL_BACKWARD = True
+
+
 def affine_inverse(A):
     """Inverse of affine 4x4 matrices [..., 4, 4] with last row (0, 0, 0, 1): M^-1 = adj(M) / det(M) by cross products of
     the rows of M, translation -M^-1 t.  Differentiable, no solver library, no host synchronisation."""
@@ -95,6 +99,40 @@ class _CandidateGatherFn(torch.autograd.Function):
                                                       _lib.ptr(d_cand_rgb), _lib.ptr(d_cand_sigma), _lib.stream()),
                    "ia_candidate_gather_bwd")
         return d_cand_rgb, d_cand_sigma, None, None
+
+
+class _SmplTfsFn(torch.autograd.Function):
+    """prepare_deformer's tfs / w2s / A (snarf_deformer.py:79-86) from the per-frame kernel `ia_smpl_tfs`, differentiable
+    w.r.t. the pose and the translation through `ia_smpl_tfs_bwd` -- what the reference obtains by running lbs.py under
+    autograd when the SMPL parameters are optimised (~370 tiny launches per step replaced by two)."""
+
+    @staticmethod
+    def forward(ctx, global_orient, body_pose, transl, deformer):
+        fo = deformer._frame_out
+        pose = torch.cat([global_orient.detach().reshape(1, 3), body_pose.detach().reshape(1, 69)], dim=1).float().contiguous()
+        trc = transl.detach().reshape(3).float().contiguous()
+        tfs, w2s, A = torch.empty_like(fo["tfs"]), torch.empty_like(fo["w2s"]), torch.empty_like(fo["A"])
+        _lib.check(_lib.lib().ia_smpl_tfs(_lib.ptr(deformer._joints_rest), _lib.ptr(deformer._parents32), _lib.ptr(pose),
+                                          _lib.ptr(trc), _lib.ptr(deformer.tfs_inv_t), _lib.ptr(tfs), _lib.ptr(w2s), _lib.ptr(A),
+                                          _lib.stream()), "ia_smpl_tfs")
+        ctx.deformer = deformer
+        ctx.shapes = (global_orient.shape, body_pose.shape, transl.shape)
+        ctx.save_for_backward(pose, trc)
+        ctx.mark_non_differentiable(w2s, A)
+        return tfs, w2s, A
+
+    @staticmethod
+    def backward(ctx, d_tfs, _d_w2s, _d_A):
+        pose, trc = ctx.saved_tensors
+        d = ctx.deformer
+        d_pose = torch.empty(72, device=pose.device)
+        d_tr = torch.empty(3, device=pose.device)
+        g = d_tfs.reshape(24, 4, 4).float().contiguous()
+        _lib.check(_lib.lib().ia_smpl_tfs_bwd(_lib.ptr(d._joints_rest), _lib.ptr(d._parents32), _lib.ptr(pose), _lib.ptr(trc),
+                                              _lib.ptr(d.tfs_inv_t), _lib.ptr(g), _lib.ptr(d_pose), _lib.ptr(d_tr), _lib.stream()),
+                   "ia_smpl_tfs_bwd")
+        s_go, s_bp, s_tr = ctx.shapes
+        return d_pose[:3].reshape(s_go), d_pose[3:].reshape(s_bp), d_tr.reshape(s_tr), None
 
 
 class SNARFDeformer():
@@ -167,8 +205,13 @@ class SNARFDeformer():
         go, bp, tr = smpl_params["global_orient"], smpl_params["body_pose"], smpl_params["transl"]
         needs_grad = any(t.requires_grad for t in (go, bp, tr))
         _lib.require_cuda(go)  # no CPU route: the per-frame path is HIP kernels
-        if needs_grad:
-            # differentiable route (SMPL-parameter refinement, config 4): torch ops under autograd; the voxel
+        if needs_grad and FUSED_SMPL_BACKWARD and self.deformer.version == 1 and torch.is_grad_enabled():
+            # SMPL-parameter refinement (config 4), version 1: the joint chain and its backward as two kernels.  (w2s / A carry no
+            # gradient: with the implicit differentiation of version 1 nothing downstream of the rays is differentiated,
+            # deformer_torch.py:50-67 -- the reference's gradient through transform_rays_w2s is identically zero there.)
+            tfs, w2s, A = _SmplTfsFn.apply(go, bp, tr, self)
+        elif needs_grad:
+            # differentiable route (version 2, or the checker of the kernels above): torch ops under autograd; the voxel
             # precompute / search below still run as kernels, the gradient reaches tfs by implicit differentiation
             out = self.body_model(betas=smpl_params["betas"], body_pose=bp, global_orient=go, transl=tr,
                                   return_verts=False)

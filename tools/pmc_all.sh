@@ -20,6 +20,9 @@ done
 for c in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   run pmc_enc_$(echo $c | tr ' ' '_') "$c" -- python $R/tools/pmc_encode.py
 done
+for c in "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
+  run pmc_encc_$(echo $c | tr ' ' '_') "$c" -- python $R/tools/pmc_encode.py coherent
+done
 for c in "TCC_ATOMIC_sum TCC_REQ_sum" "TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum"; do
   run pmc3_$(echo $c | tr ' ' '+') "$c" -- python $R/bench.py --train-only --steps 30 --warmup 5 --no-graph
 done

@@ -47,6 +47,23 @@ def per_kernel(pattern, match):
     return {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}, {k: statistics.median(v) for k, v in durs.items()}, {k: len(v) for k, v in durs.items()}
 
 
+def per_kernel_tail(pattern, match, last_n):
+    """counters averaged over the LAST `last_n` dispatches of the kernels matching `match` (the measured launches of a
+    script whose earlier launches of the same kernel belong to its set-up), and their median duration in us"""
+    out, us = {}, []
+    for f in sorted(glob.glob(pattern, recursive=True)):
+        rows = [r for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-last_n:]
+        acc = collections.defaultdict(list)
+        for r in rows:
+            if int(r["Dispatch_Id"]) in ids:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                us.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+        for c, v in acc.items():
+            out[c] = sum(v) / max(len(ids), 1)     # a counter may be reported in several rows per dispatch (per XCD): sum them
+    return out, (statistics.median(us) if us else None), None
+
+
 def main(root, out_dir):
     os.makedirs(out_dir, exist_ok=True)
     meta = {"so_sha256": so_hash(), "collected_by": "tools/pmc_all.sh (rocprofv3 --pmc <one set per pass> --kernel-trace)"}
@@ -68,6 +85,27 @@ def main(root, out_dir):
         if "FETCH_SIZE" in c:
             d["fabric_fetch_bytes_per_launch_x2_corrected"] = c["FETCH_SIZE"] * 1024.0 * 2.0
         enc[k] = d
+    # the same kernel on the canonical samples of a real frame (ray-major): the LAST four k_encode_xcd launches of the pass
+    Cc, usc, _ = per_kernel_tail(os.path.join(root, "pmc_encc_*", "**", "*counter_collection.csv"), "k_encode_xcd", 4)
+    if Cc:
+        d = dict(Cc)
+        d["launch_us_under_pmc_median"] = usc
+        nsamp = None
+        try:
+            for f in glob.glob(os.path.join(root, "pmc_encc_*.log")):
+                for line in open(f):
+                    if line.startswith("frame-coherent samples:"):
+                        nsamp = int(line.split(":")[1])
+        except Exception:
+            pass
+        d["samples_per_launch"] = nsamp
+        if nsamp and "TCP_TCC_READ_REQ_sum" in d:
+            d["l2_read_requests_per_sample"] = d["TCP_TCC_READ_REQ_sum"] / nsamp
+        if nsamp and "TCP_TOTAL_CACHE_ACCESSES_sum" in d:
+            d["l1_accesses_per_sample"] = d["TCP_TOTAL_CACHE_ACCESSES_sum"] / nsamp
+        if "TCC_HIT_sum" in d and d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0) > 0:
+            d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+        enc["k_encode_xcd<16>/frame_coherent"] = d
     enc["_note"] = ("one pass per counter set over tools/pmc_encode.py (2^20 uniformly random points in the field bbox, 16-level table). "
                     "Algorithmic bytes: 512 B/sample.  L2 request-rate ceiling: 8 XCD x 16 channels x 2.1 GHz = 269 G requests/s "
                     "(profiles/r02_ubench_l2gather.txt).  FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)")
