@@ -858,3 +858,35 @@ def test_new_entry_points_validate_arguments_before_any_launch():
     assert L.ia_patch_corners(one, one, one, 0, 64, 64, 16, C.c_float(1.0), one, one, None) == 0          # n == 0: nothing to do
     assert L.ia_near_far(None, 5, None, None, None) != 0 and b"ia_near_far" in L.ia_last_error()
     assert L.ia_near_far(None, 0, None, None, None) == 0
+
+
+def test_round3_entry_points_validate_arguments_before_any_launch():
+    """ia_snarf_search_compact_jinv / ia_snarf_implicit_bwd_compact / ia_smpl_tfs_bwd / ia_frame_stats / ia_profile_get_units
+    reject bad arguments with a message and never reach a launch (so this runs without a GPU)."""
+    from instantavatar_amd import _lib
+    L = _lib.lib()
+    g = _lib.SnarfGrid()
+    g.D, g.H, g.W = 8, 32, 32
+    one = C.c_void_p(16)
+    bones = _lib.bone_array([0, 1, 2])
+    tail = (C.c_float(1e-5), C.c_float(1e-1))
+    # n_cand is required; P < 0 is rejected; P == 0 returns before touching anything; the J_inv output is required
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, None, 0, None) != 0
+    assert b"n_cand" in L.ia_last_error()
+    assert L.ia_snarf_search_compact_jinv(one, -1, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, None) != 0
+    assert L.ia_snarf_search_compact_jinv(None, 0, None, None, None, bones, 3, C.byref(g), *tail, None, None, 0, None, None, one, 0, None) == 0
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, None, 16, one, one, one, 0, None) != 0
+    assert b"null pointer" in L.ia_last_error()
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 99, C.byref(g), *tail, one, one, 16, one, one, one, 0, None) != 0
+    assert b"n_init" in L.ia_last_error()
+    # compact implicit backward: the device-side count is mandatory, the workspace is checked
+    assert L.ia_snarf_implicit_bwd_compact(one, one, one, 100, None, one, 1, C.byref(g), one, one, 1 << 20, None) != 0
+    assert b"n_cand" in L.ia_last_error()
+    assert L.ia_snarf_implicit_bwd_compact(one, one, one, 100, one, one, 1, C.byref(g), one, one, 8, None) != 0
+    assert b"workspace" in L.ia_last_error()
+    assert L.ia_snarf_implicit_bwd_compact(one, one, one, 0, one, one, 1, C.byref(g), one, one, 0, None) == 0     # nothing to do
+    assert L.ia_smpl_tfs_bwd(None, None, None, None, None, None, None, None, None) != 0 and b"ia_smpl_tfs_bwd" in L.ia_last_error()
+    assert L.ia_frame_stats(None, None, 0, None, None) != 0 and b"ia_frame_stats" in L.ia_last_error()
+    u = (C.c_uint64 * 3)()
+    assert L.ia_profile_get_units(7, u, 3) != 0 and L.ia_profile_get_units(0, u, 9) != 0
+    assert L.ia_profile_get_units(0, u, 3) == 0 and list(u) == [0, 0, 0]                                           # profiling never enabled

@@ -11,5 +11,7 @@ dev = torch.device("cuda", 0)
 model, body, fp = build_synthetic_model(dev, resolution=128, n_levels=16)
 poses, tr = syn.load_animation_track(os.path.join(ROOT, "tests", "golden", "aist_demo_200.npz"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-r = bench.train_throughput(model, dev, poses, tr, 0, 1, n, res=512, sampler="edge", refine=True, graphed="--eager" not in sys.argv)
+plain = "--plain" in sys.argv   # the config-2 workload (PatchSampler, fresh field) instead of refinement
+r = bench.train_throughput(model, dev, poses, tr, 0, 1, n, res=512, sampler="patch" if plain else "edge", refine=not plain,
+                           graphed="--eager" not in sys.argv)
 print({k: r[k] for k in ("it_per_sec", "launch_mode", "samples_candidates_last_step")})
