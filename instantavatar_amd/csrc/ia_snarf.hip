@@ -598,15 +598,22 @@ __device__ __forceinline__ void fetch_round(const char *__restrict__ vJb, const 
   if (load != 0)
 #endif
   {
-    float4 v[8];
+#ifndef IA_QUAD_GROUP
+#define IA_QUAD_GROUP 8   // corner records in flight per load phase of a round (8: one round trip per round; 4: half the data registers)
+#endif
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_bcast<T>(p.off[c]) + koff));
+    for (int c0 = 0; c0 < 8; c0 += IA_QUAD_GROUP) {
+      float4 v[IA_QUAD_GROUP];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const float w = quad_bcast<T>(p.w[c]);
-      const f2 w2 = (f2){w, w};
-      a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
-      a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
+      for (int c = 0; c < IA_QUAD_GROUP; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_bcast<T>(p.off[c0 + c]) + koff));
+#pragma unroll
+      for (int c = 0; c < IA_QUAD_GROUP; c++) {
+        const float w = quad_bcast<T>(p.w[c0 + c]);
+        const f2 w2 = (f2){w, w};
+        a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
+        a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
+      }
+      if (IA_QUAD_GROUP < 8) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }
   }
   // rows 0..2 (lanes 0..2 of the quad) back to the target lane: out = not_mine ? out : row (v_cndmask with a DPP source)
@@ -617,6 +624,44 @@ __device__ __forceinline__ void fetch_round(const char *__restrict__ vJb, const 
     out[c] = not_mine ? out[c] : r0;
     out[4 + c] = not_mine ? out[4 + c] : r1;
     out[8 + c] = not_mine ? out[8 + c] : r2;
+  }
+}
+
+// two rounds with their loads in flight together (IA_QUAD_PAIR): half the round trips per step, twice the data registers
+template <int T0, int T1>
+__device__ __forceinline__ void fetch_round2(const char *__restrict__ vJb, const FetchPlan &p, uint32_t koff, int k,
+                                             float *__restrict__ out) {
+  const uint32_t l0 = quad_bcast<T0>(p.load), l1 = quad_bcast<T1>(p.load);
+  if (__ballot((l0 | l1) != 0) == 0) return;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f}, b0 = (f2){0.f, 0.f}, b1 = (f2){0.f, 0.f};
+  float4 v[8], u[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_bcast<T0>(p.off[c]) + koff));
+#pragma unroll
+  for (int c = 0; c < 8; c++) u[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_bcast<T1>(p.off[c]) + koff));
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const float w = quad_bcast<T0>(p.w[c]);
+    const f2 w2 = (f2){w, w};
+    a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
+    a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const float w = quad_bcast<T1>(p.w[c]);
+    const f2 w2 = (f2){w, w};
+    b0 = __builtin_elementwise_fma((f2){u[c].x, u[c].y}, w2, b0);
+    b1 = __builtin_elementwise_fma((f2){u[c].z, u[c].w}, w2, b1);
+  }
+  const float a[4] = {a0.x, a0.y, a1.x, a1.y}, b[4] = {b0.x, b0.y, b1.x, b1.y};
+  const bool m0 = k != T0, m1 = k != T1;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float r0 = quad_bcast<0>(a[c]), r1 = quad_bcast<1>(a[c]), r2 = quad_bcast<2>(a[c]);
+    out[c] = m0 ? out[c] : r0; out[4 + c] = m0 ? out[4 + c] : r1; out[8 + c] = m0 ? out[8 + c] : r2;
+    const float s0 = quad_bcast<0>(b[c]), s1 = quad_bcast<1>(b[c]), s2 = quad_bcast<2>(b[c]);
+    out[c] = m1 ? out[c] : s0; out[4 + c] = m1 ? out[4 + c] : s1; out[8 + c] = m1 ? out[8 + c] : s2;
   }
 }
 
@@ -631,10 +676,18 @@ __device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const
   const char *vJb = reinterpret_cast<const char *>(vJ);
 #pragma unroll
   for (int c = 0; c < 12; c++) out[c] = 0.f;
+#ifndef IA_QUAD_PAIR
+#define IA_QUAD_PAIR 0
+#endif
 #ifndef IA_QUAD_FENCE
 #define IA_QUAD_FENCE 0   // 1: keep the compiler from hoisting the next round's loads above this round's arithmetic (fewer registers)
 #endif
 #define IA_QUAD_ROUND_END() do { if (IA_QUAD_FENCE) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#if IA_QUAD_PAIR
+  fetch_round2<0, 1>(vJb, p, koff, k, out); IA_QUAD_ROUND_END();
+  fetch_round2<2, 3>(vJb, p, koff, k, out);
+  return;
+#endif
   fetch_round<0>(vJb, p, koff, k != 0, out); IA_QUAD_ROUND_END();
   fetch_round<1>(vJb, p, koff, k != 1, out); IA_QUAD_ROUND_END();
   fetch_round<2>(vJb, p, koff, k != 2, out); IA_QUAD_ROUND_END();
