@@ -27,4 +27,13 @@ for c in "TCC_ATOMIC_sum TCC_REQ_sum" "TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum"; do
   run pmc3_$(echo $c | tr ' ' '+') "$c" -- python $R/bench.py --train-only --steps 30 --warmup 5 --no-graph
 done
 python $R/tools/pmc_r3.py $O $O/profiles_r03 > $O/pmc_all_summary.txt 2>&1; tail -5 $O/pmc_all_summary.txt
-ls -la $O/profiles_r03
+# the raw per-dispatch CSVs are tens of MB per pass (gpurun copies back at most 64 MiB): keep one condensed row per
+# (kernel, counter) of every pass next to the summaries and drop the raw files
+mkdir -p $O/profiles_r03/r03_pmc
+for d in $O/pmc2_* $O/pmc_enc_* $O/pmc_encc_* $O/pmc3_*; do
+  [ -d "$d" ] || continue
+  python $R/tools/pmc_condense.py $d $O/profiles_r03/r03_pmc/$(basename $d).csv 2>/dev/null
+  rm -rf $d
+done
+rm -rf $O/pmcq_* $O/pmc_s[0-9]* $O/prof_frame $O/prof_refine $O/pmc_records 2>/dev/null
+ls -la $O/profiles_r03 $O/profiles_r03/r03_pmc | head -40; du -sh $O
