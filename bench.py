@@ -643,12 +643,12 @@ def main():
         one_fps = args.steps / (time.perf_counter() - t1)
         g0.finish()
     # secondary figure: the procedural pose track rounds 1-2 quoted, through the same graphs (untimed for `value`)
-    proc_track = None
+    proc_track, dt2, err2, inc2 = None, 0.0, None, 0
+    n_sec = min(max(args.steps, 20), 100)
+    keep = (poses, tr, pose_t, tr_t)
     try:
-        keep = (poses, tr, pose_t, tr_t)
         poses, tr = poses_proc, tr_proc
         pose_t, tr_t = torch.as_tensor(poses, device=dev), torch.as_tensor(tr, device=dev)
-        n_sec = min(max(args.steps, 20), 100)
         run_frames(0, 10)
         torch.cuda.synchronize()
         stat_acc.zero_()
@@ -657,13 +657,18 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
         inc2 = graphed.finish() if graphed is not None else 0
-        proc_track = {"frames_per_s": max_over_ranks(n_sec / dt2) if world_size == 1 else n_sec * world_size / max_over_ranks(dt2),
-                      "frames": n_sec, "samples_per_ray": float(cnt_sum.sum().item()) / n_sec,
+    except Exception as e:
+        err2 = repr(e)[:200]
+    poses, tr, pose_t, tr_t = keep
+    # (collectives outside the try: every rank takes part whether or not its own secondary run succeeded)
+    failed = max_over_ranks(1.0 if err2 else 0.0)
+    dt2 = max_over_ranks(dt2)
+    if failed or dt2 <= 0:
+        proc_track = {"error": err2 or "failed on another rank"}
+    else:
+        proc_track = {"frames_per_s": n_sec * world_size / dt2, "frames": n_sec, "samples_per_ray": float(cnt_sum.sum().item()) / n_sec,
                       "alpha_coverage": float(cov_sum.sum().item()) / n_sec, "frames_incomplete_in_graph": int(inc2) - int(incomplete),
                       "what": "synthetic.procedural_pose_track(200), the workload of the round-1/2 bench lines"}
-        poses, tr, pose_t, tr_t = keep
-    except Exception as e:
-        proc_track = {"error": repr(e)[:200]}
     # per-kernel timing for the roofline block: HIP events around every launch of the two dominant
     # stages on the stream they run on.  Recording ~50 events per frame costs ~10 % of the frame,
     # so `value` comes from the un-instrumented pass above and the SAME K frames are then launched
