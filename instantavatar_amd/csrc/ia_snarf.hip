@@ -539,6 +539,9 @@ __device__ __forceinline__ bool fetch_J(const float *__restrict__ vJ, const Snar
 #ifndef IA_SEARCH_QUAD
 #define IA_SEARCH_QUAD 1
 #endif
+#ifndef IA_SEARCH_QPS
+#define IA_SEARCH_QPS 0   // 1: quad-per-solve state machine (see k_search); takes precedence over IA_SEARCH_QUAD
+#endif
 #ifndef IA_QUAD_PREDICATE
 #define IA_QUAD_PREDICATE 1   // 0: every quad loads in every round (no EXEC juggling, wasted look-ups for idle lanes)
 #endif
@@ -846,6 +849,147 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   __syncthreads();
   const int n_live = s_nlive;
 
+#if IA_SEARCH_QPS
+  // ---- QUAD state machine (quad-per-solve) -----------------------------------------------------------------------------
+  // One solve per quad: lane r (r = 0..2; lane 3 shadows lane 2 and writes nothing) owns ROW r of everything with rows -- the
+  // fetched 3x4 transform, J_inv, the residual / update component r -- while x, the previous residual and the scalars are
+  // replicated.  A Broyden step is then ONE round of 8 loads per lane (row r of the 8 corner records) instead of the four
+  // rounds of the lane-per-solve mapping, the per-lane state shrinks (J_inv row 3 instead of 9 registers, no delivery of
+  // rows to a target lane), and the arithmetic is the reference's sequence element by element: a dot product whose terms
+  // live in different lanes walks from lane 0 to lane 2 (multiply, fma, fma) through DPP, so every rounding happens where
+  // and in the order it did before.
+  // MEASURED (round 3, MI355X; bit-identical results, the parity tests pass with it): 88 VGPRs, 5 waves per SIMD, one round
+  // trip per step -- and slower: 269 us against 219 us for the lane-per-solve kernel with the quad-cooperative fetch (256 x 64;
+  // 256 x 128: 310 us).  A wave-step costs about the same ~450 VALU instructions whether it advances 16 solves or 64 (the fetch
+  // plan, the replicated scalars, the selects and the queue logic do not shrink with the number of solves), so the VALU work
+  // per solve doubles and the kernel, at 62 % VALU issue before, turns VALU bound.  OFF; kept as the measured alternative.
+  const int r_own = min(lane & 3, 2);
+  const bool leader = (lane & 3) == 0, writer = (lane & 3) < 3;
+  const uint32_t koff = (uint32_t)r_own * 16u;
+  const char *vJb = reinterpret_cast<const char *>(vJ);
+  bool active = false, first = false;
+  int item = 0, iter = 0, fetches = 0, solves = 0, loaded = 0;
+  float t_own = 0, xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
+  float Jr[3] = {0.f, 0.f, 0.f};   // row r_own of J_inv
+  bool queue_empty = false;
+  while (true) {
+    if (!queue_empty) {
+      const unsigned long long need = __ballot(!active && leader);
+      if (need) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_next, __popcll(need));
+        base = __shfl(base, 0, 64);
+        if (base >= n_live) queue_empty = true;
+        int my = base + __popcll(need & ((1ull << lane) - 1ull));
+        my = (int)quad_bcast<0>((uint32_t)my);          // the leader's slot, for the whole quad
+        if (!active && my < n_live) {
+          item = s_list[my];
+          const int init = item >> 7, pt = item & (NP - 1);
+          const float ta = s_xd[pt][0], tb = s_xd[pt][1], tc = s_xd[pt][2];
+          t_own = r_own == 0 ? ta : (r_own == 1 ? tb : tc);
+          const float *T = s_T[init];
+          const float ixd = ta - T[3], iyd = tb - T[7], izd = tc - T[11];
+          xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
+          xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
+          xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
+          active = true; first = true; iter = 0;
+          if (leader) solves++;
+        }
+      }
+    }
+    if (!__any(active)) break;
+    const float ix = g.scl[0] * (xl0 + g.off[0]);
+    const float iy = g.scl[1] * (xl1 + g.off[1]);
+    const float iz = g.scl[2] * (xl2 + g.off[2]);
+    // ---- fetch: row r_own of the trilinear blend (weights / offsets computed by every lane of the quad: same inputs, same bits)
+    FetchPlan p;
+    fetch_plan(g, ix, iy, iz, active, p);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
+    if (p.load != 0) {     // uniform within a quad; a fetch with all corners outside is zero without a load
+      float4 v[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(p.off[c] + koff));
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const f2 w2 = (f2){p.w[c], p.w[c]};
+        a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
+        a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
+      }
+    }
+    const float Jrow[4] = {a0.x, a0.y, a1.x, a1.y};   // J[r][0..3]
+    // ---- everything below runs in wave-uniform control flow (DPP inside): idle quads compute on stale values, results unused
+    // residual component r: g_r(x) = J[r] . x + d_r - xd_r  (:325-332 / :356-367)
+    const float n_own = IA_DOT3(Jrow[0], xl0, Jrow[1], xl1, Jrow[2], xl2) + Jrow[3] - t_own;
+    const float n0 = quad_bcast<0>(n_own), n1 = quad_bcast<1>(n_own), n2 = quad_bcast<2>(n_own);
+    bool done = false, ok = false;
+    const unsigned long long any_first = __ballot(active && first);
+    if (any_first) {
+      // :302-311 J_inv0 = (J_3x3)^T: row r of J_inv = column r of J = element r of the three row lanes
+      const float b00 = quad_bcast<0>(Jrow[0]), b01 = quad_bcast<0>(Jrow[1]), b02 = quad_bcast<0>(Jrow[2]);
+      const float b10 = quad_bcast<1>(Jrow[0]), b11 = quad_bcast<1>(Jrow[1]), b12 = quad_bcast<1>(Jrow[2]);
+      const float b20 = quad_bcast<2>(Jrow[0]), b21 = quad_bcast<2>(Jrow[1]), b22 = quad_bcast<2>(Jrow[2]);
+      if (active && first) {
+        Jr[0] = r_own == 0 ? b00 : (r_own == 1 ? b01 : b02);
+        Jr[1] = r_own == 0 ? b10 : (r_own == 1 ? b11 : b12);
+        Jr[2] = r_own == 0 ? b20 : (r_own == 1 ? b21 : b22);
+      }
+    }
+    const bool was_first = first;
+    // Broyden update of J_inv (fuse_J_inv_update, :23-55) with x-arguments u and g-arguments dg = n - gx:
+    //   c_j = J0j u0 + J1j u1 + J2j u2 walks down the rows (lane 0 multiplies, lanes 1 and 2 fma), s and r_r follow
+    const float dg0 = n0 - gx0, dg1 = n1 - gx1, dg2 = n2 - gx2;
+    const float u_own = r_own == 0 ? u0 : (r_own == 1 ? u1 : u2);
+    float c[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float m = Jr[j] * u_own;                                   // valid in lane 0: J0j * u0
+      const float q = __builtin_fmaf(Jr[j], u_own, quad_bcast<0>(m));   // valid in lane 1: fma(J1j, u1, .)
+      const float cc = __builtin_fmaf(Jr[j], u_own, quad_bcast<1>(q));  // valid in lane 2: fma(J2j, u2, .)
+      c[j] = quad_bcast<2>(cc);
+    }
+    const float sden = IA_DOT3(c[0], dg0, c[1], dg1, c[2], dg2);
+    const float r_r = IA_DOT3(-Jr[0], dg0, -Jr[1], dg1, -Jr[2], dg2);
+    if (active) {
+      if (was_first) {
+        gx0 = n0; gx1 = n1; gx2 = n2;
+        first = false;
+      } else {
+        const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
+        if (norm < cvg2) {
+          done = true;
+          ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
+        } else if (norm > dvg2) {
+          done = true;
+        } else {
+          Jr[0] += c[0] * (r_r + u_own) / sden; Jr[1] += c[1] * (r_r + u_own) / sden; Jr[2] += c[2] * (r_r + u_own) / sden;  // :400-411
+          gx0 = n0; gx1 = n1; gx2 = n2;
+          if (++iter == 10) done = true;  // Q1
+        }
+      }
+      if (leader) { fetches++; loaded += p.load ? 1 : 0; }
+    }
+    if (active && done) {
+      const int init = item >> 7, pt = item & (NP - 1);
+      if (leader) {
+        s_x[init][pt][0] = ok ? xl0 : 0.f; s_x[init][pt][1] = ok ? xl1 : 0.f; s_x[init][pt][2] = ok ? xl2 : 0.f;
+        s_valid[init][pt] = ok;
+      }
+      if (writer) {   // Q4: J_inv as it was BEFORE the last rank-1 update (a converged / diverged step does not update it)
+        if (MODE == 0 && J_inv) {
+          const size_t o = ((size_t)(p0 + pt) * n_init + init) * 9 + 3 * r_own;
+          J_inv[o] = ok ? Jr[0] : 0.f; J_inv[o + 1] = ok ? Jr[1] : 0.f; J_inv[o + 2] = ok ? Jr[2] : 0.f;
+        }
+        if (MODE == 2 && ok) { s_Ji[init][pt][3 * r_own] = Jr[0]; s_Ji[init][pt][3 * r_own + 1] = Jr[1]; s_Ji[init][pt][3 * r_own + 2] = Jr[2]; }
+      }
+      active = false;
+    }
+    // :340-351 update = -J_inv g ; x += update (start of the next iteration): component r in lane r, then to the whole quad
+    const float un = IA_DOT3(-Jr[0], gx0, -Jr[1], gx1, -Jr[2], gx2);
+    const float v0 = quad_bcast<0>(un), v1 = quad_bcast<1>(un), v2 = quad_bcast<2>(un);
+    if (active) { u0 = v0; u1 = v1; u2 = v2; xl0 += u0; xl1 += u1; xl2 += u2; }
+  }
+#else
   // ---- lane state machine ----
   bool active = false, first = false;
   // `solves` counts the queued (non-trivial) ones; `fetches` every trilinear fetch of the reference's algorithm, `loaded` those
@@ -950,6 +1094,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
       }
     }
   }
+#endif
   if (prof) {  // bench-only accounting: solves and trilinear fetches
     int f = fetches, n = solves, l = loaded;
 #pragma unroll
