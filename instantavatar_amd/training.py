@@ -105,7 +105,7 @@ class _FieldFn(torch.autograd.Function):
         from . import parallel
         red = parallel.current_reducer()
         last = red is not None and red.active and red.field_backward_done()  # last field call of this step's graph?
-        if last and dx is None:
+        if last and dx is None and not FLAT_ALLREDUCE:
             # level groups, finest first; each finished slice of the table gradient goes to RCCL while the next
             # group is scattered.  The MLP weight gradients travel with the last (small, dense-level) bucket.
             red.reduce_async(g_col)
@@ -148,6 +148,11 @@ def _level_groups(n_levels, n_groups=4):
     cuts = list(range(0, n_levels, per))
     return [(c, min(c + per, n_levels)) for c in reversed(cuts)]
 
+
+#: True (or IA_FLAT_ALLREDUCE=1): no bucketed / overlapped all-reduce from inside the hash-grid backward -- the whole scatter runs as one
+#: launch and `GradReducer.finish` reduces every gradient as one flat collective per tensor afterwards (the fallback, and the
+#: reference point the bucketed path is compared against)
+FLAT_ALLREDUCE = __import__("os").environ.get("IA_FLAT_ALLREDUCE", "0") == "1"
 
 #: MLP backward through the fused MFMA kernel (`ia_field_bwd`).  False = the GEMM formulation
 #: below (kept as the reference the fused kernel is tested against).

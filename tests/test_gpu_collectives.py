@@ -71,6 +71,12 @@ for it in range(3):
     training_step(tmodel, batches[it %% 3], opt, loss_fn, world_size=1)
 parallel.GradReducer.finish = orig
 out["collectives_per_step"] = seen
+# the flat fallback (one collective per gradient tensor after the backward pass) against the bucketed / overlapped path
+import instantavatar_amd.training as TR
+TR.FLAT_ALLREDUCE = True
+flat = run(True, False)
+TR.FLAT_ALLREDUCE = False
+out["params_rel_diff_flat_vs_bucketed"] = float((flat["p"] - forced["p"]).norm() / forced["p"].norm())
 # non-finite skip with the reducer active
 nanrun = run(True, False, n_steps=4, nan_at=2)
 out["nan_skipped"] = nanrun["skipped"]
@@ -101,6 +107,7 @@ def test_training_step_over_rccl_with_one_rank():
     assert o["buckets_cover"] and len(o["buckets"]) == 4 and o["buckets"][0][0] == [12, 16] and o["buckets"][-1][0] == [0, 4]
     assert all(c >= 5 for c in o["collectives_per_step"]), o["collectives_per_step"]     # colour weights + 4 level buckets
     assert o["nan_skipped"] == [0.0, 0.0, 1.0, 0.0]
+    assert o["params_rel_diff_flat_vs_bucketed"] < 5e-3          # IA_FLAT_ALLREDUCE: same result without the overlap
     g = o["graph"]
     assert g["err"] is None and g["replays"] >= 4, g
     assert np.allclose(g["losses"], o["plain_losses"], rtol=5e-3, atol=1e-6) and g["params_rel_diff_vs_plain"] < 5e-3

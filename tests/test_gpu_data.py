@@ -216,3 +216,21 @@ def test_patch_sampler_empty_mask_falls_back_to_uniform_corners():
     r, c = rows.cpu().numpy(), cols.cpu().numpy()
     assert (r >= 0).all() and (r < H - 32).all() and (c >= 0).all() and (c < W - 32).all()
     assert np.array_equal(r, np.floor(np.linspace(0.05, 0.95, 8)[:4].astype(np.float32) * np.float32(H - 32)).astype(np.int32))
+
+
+def test_edge_sampler_on_empty_and_full_masks_stays_inside_the_image():
+    """an all-zero (or all-one) mask has an empty mask set / an empty edge band; `ia_nonzero_select` then returns
+    row = col = -1 and the flat index used to come out negative -- read by `ia_sample_batch` in front of the buffer.  Those
+    draws now fall back to uniform pixels (the reference raises in np.random.randint(0, 0))."""
+    from instantavatar_amd.utils.sampler import EdgeSampler
+    H = W = 64
+    s = EdgeSampler(num_sample=512, ratio_mask=0.6, ratio_edge=0.3, kernel_size=8)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for mask in (torch.zeros((H, W), device=DEV), torch.ones((H, W), device=DEV)):
+        idx = s.sample_indices(mask, generator=g)
+        assert idx.numel() == 512 and int(idx.min()) >= 0 and int(idx.max()) < H * W
+    m = torch.zeros((H, W), device=DEV)
+    m[20:40, 10:30] = 1
+    idx = s.sample_indices(m, generator=g)
+    assert int(idx.min()) >= 0 and int(idx.max()) < H * W
+    assert bool((m.reshape(-1)[idx[:s.num_mask].long()] == 1).all())     # the mask share still comes from the mask
