@@ -20,7 +20,9 @@ SCRIPT = r'''
 import json, os, sys
 sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+import socket
+_s = socket.socket(); _s.bind(("127.0.0.1", 0)); _port = _s.getsockname()[1]; _s.close()
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_port)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from instantavatar_amd import parallel
