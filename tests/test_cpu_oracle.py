@@ -890,3 +890,91 @@ def test_round3_entry_points_validate_arguments_before_any_launch():
     u = (C.c_uint64 * 3)()
     assert L.ia_profile_get_units(7, u, 3) != 0 and L.ia_profile_get_units(0, u, 9) != 0
     assert L.ia_profile_get_units(0, u, 3) == 0 and list(u) == [0, 0, 0]                                           # profiling never enabled
+
+
+def test_affine_inverse_equals_torch_inverse_value_and_gradient():
+    """snarf_deformer.affine_inverse (cofactor inverse of [M t; 0 0 0 1] in tensor ops: no LU status read-back, capturable)
+    against torch.inverse: value to rounding, gradient w.r.t. the three variable rows."""
+    from instantavatar_amd.deformers.snarf_deformer import affine_inverse
+    g = torch.Generator().manual_seed(0)
+    A = torch.eye(4, dtype=torch.float64).repeat(6, 1, 1)
+    A[:, :3, :3] = torch.linalg.qr(torch.randn(6, 3, 3, generator=g, dtype=torch.float64))[0] + 0.05 * torch.randn(6, 3, 3, generator=g, dtype=torch.float64)
+    A[:, :3, 3] = 5 * torch.randn(6, 3, generator=g, dtype=torch.float64)
+    a, b = A.clone().requires_grad_(True), A.clone().requires_grad_(True)
+    x, y = affine_inverse(a), torch.inverse(b)
+    assert (x - y).abs().max() < 1e-12
+    w = torch.randn(6, 4, 4, generator=g, dtype=torch.float64)
+    (x * w).sum().backward()
+    (y * w).sum().backward()
+    assert (a.grad[:, :3] - b.grad[:, :3]).abs().max() < 1e-10
+    x32 = affine_inverse(A.float())
+    assert (x32.double() - y.detach()).abs().max() < 5e-6
+
+
+def test_smpl_chain_backward_formulas_match_autograd():
+    """The chain rule `k_smpl_tfs_bwd` writes out (E_j = D_j B_j^T, dA_j = R_W^T E_j, dW = sum E_j A_j^T, dA_0 -= W^T dW W^T,
+    children-before-parents, Rodrigues), restated in float64 numpy and checked against autograd through the product's
+    lbs.py-style torch ops: the derivation the kernel transcribes (the kernel itself is compared on the GPU:
+    test_smpl_chain_backward_kernel_equals_autograd_through_lbs)."""
+    from instantavatar_amd import synthetic as syn
+    from instantavatar_amd.deformers.smplx import SMPL
+    from instantavatar_amd.deformers.snarf_deformer import affine_inverse
+    smpl = SMPL.from_dict(syn.make_body(42)).double()
+    betas = torch.zeros(1, 10, dtype=torch.float64)
+    rest = smpl(betas=betas, body_pose=torch.as_tensor(syn.cano_pose("A_pose"))[None].double())
+    Binv = torch.inverse(rest.A)[0]
+    poses, tr = syn.procedural_pose_track(8)
+    pose = torch.tensor(poses[3:4]).double().requires_grad_(True)
+    tau = torch.tensor(tr[3:4]).double().requires_grad_(True)
+    out = smpl(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3], transl=tau, return_verts=False)
+    tfs = (affine_inverse(out.A[:, 0])[:, None] @ out.A @ Binv)[0]
+    D = torch.randn(24, 4, 4, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    D[:, 3] = 0
+    (tfs * D).sum().backward()
+    J, par = smpl.rest_joints(betas).numpy(), smpl.parents_list
+    th, t = poses[3].astype(np.float64).reshape(24, 3), tr[3].astype(np.float64)
+    R, K, KK = np.zeros((24, 3, 3)), np.zeros((24, 3, 3)), np.zeros((24, 3, 3))
+    ang, sn, cs = np.zeros(24), np.zeros(24), np.zeros(24)
+    rel = J.copy()
+    for j in range(1, 24):
+        rel[j] = J[j] - J[par[j]]
+    for j in range(24):
+        a = np.sqrt(((th[j] + 1e-8) ** 2).sum())
+        d = th[j] / a
+        K[j] = np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+        KK[j] = K[j] @ K[j]
+        ang[j], sn[j], cs[j] = a, np.sin(a), np.cos(a)
+        R[j] = np.eye(3) + sn[j] * K[j] + (1 - cs[j]) * KK[j]
+    G = np.zeros((24, 4, 4))
+    for j in range(24):
+        L = np.eye(4)
+        L[:3, :3], L[:3, 3] = R[j], rel[j]
+        G[j] = L if j == 0 else G[par[j]] @ L
+    A = G.copy()
+    for j in range(24):
+        A[j, :3, 3] = G[j, :3, 3] - G[j, :3, :3] @ J[j] + t
+    W, B, Dn = np.linalg.inv(A[0]), Binv.numpy(), D.numpy()
+    E = np.einsum("jaq,jbq->jab", Dn[:, :3, :], B)
+    dA = np.einsum("qa,jqb->jab", W[:3, :3], E)
+    dW = np.zeros((4, 4))
+    dW[:3] = np.einsum("jaq,jbq->ab", E, A)
+    dA[0] -= (W.T @ dW @ W.T)[:3]
+    dRG, dg = dA[:, :, :3] - dA[:, :, 3:4] * J[:, None, :], dA[:, :, 3].copy()
+    d_tau = dg.sum(0)
+    dRl = np.zeros((24, 3, 3))
+    for i in range(23, 0, -1):
+        p = par[i]
+        dRl[i] = G[p, :3, :3].T @ dRG[i]
+        dRG[p] += dRG[i] @ R[i].T + np.outer(dg[i], rel[i])
+        dg[p] += dg[i]
+    dRl[0] = dRG[0]
+    d_pose = np.zeros((24, 3))
+    for j in range(24):
+        dR = dRl[j]
+        dK = sn[j] * dR + (1 - cs[j]) * (dR @ K[j].T + K[j].T @ dR)
+        d_ang = cs[j] * (dR * K[j]).sum() + sn[j] * (dR * KK[j]).sum()
+        d_dir = np.array([dK[2, 1] - dK[1, 2], dK[0, 2] - dK[2, 0], dK[1, 0] - dK[0, 1]])
+        d_pose[j] = d_dir / ang[j] + (d_ang - (d_dir @ th[j]) / ang[j] ** 2) * (th[j] + 1e-8) / ang[j]
+    ref = pose.grad[0].numpy()
+    assert np.abs(d_pose.reshape(-1) - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(d_tau).max() < 1e-12 and np.abs(tau.grad.numpy()).max() < 1e-12      # root-frame transforms: no gradient to the translation
