@@ -202,13 +202,15 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
  * (the matrix before the last rank-1 update, fuse_cuda_kernel_fast.cu:383-391), compacted exactly like
  * cand_xc -- what the reference gathers with `others['J_inv'][others['valid_ids']]` from a dense
  * [1,P,13,3,3] tensor.  Input of ia_snarf_implicit_bwd_compact.                                    */
+size_t ia_snarf_search_jinv_workspace_bytes(int P, int n_init);   /* P x n_init x 9 floats: J_inv of the valid solves before compaction */
 int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
                                  const float *voxel_J, const float *tfs,
                                  const int32_t *bone_ids, int n_init,
                                  const ia_snarf_grid *grid, float cvg_thresh,
                                  float dvg_thresh, float *cand_xc, float *cand_Jinv,
                                  int32_t cand_cap, int32_t *pt_off, uint8_t *pt_cnt,
-                                 int32_t *n_cand, int zero_counter, void *stream);
+                                 int32_t *n_cand, int zero_counter, void *ws, size_t ws_bytes,
+                                 void *stream);
 
 /* ---- a7: implicit differentiation of the roots ----------------------------------------
  * Backward of ForwardDeformer.forward's training branch (deformer_torch.py:50-67 with

@@ -57,7 +57,8 @@ _SIGS = {
                                           _VP, C.c_int, _VP]),
     "ia_snarf_search_compact_jinv": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                                C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, _VP, C.c_int32, _VP, _VP,
-                                               _VP, C.c_int, _VP]),
+                                               _VP, C.c_int, _VP, C.c_size_t, _VP]),
+    "ia_snarf_search_jinv_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_field_fwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP]),
     "ia_field_act_stride": (C.c_int, [C.c_int]),
     "ia_field_fwd_train": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),

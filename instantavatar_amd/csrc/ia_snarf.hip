@@ -246,7 +246,6 @@ __global__ void k_smpl_tfs_bwd(const float *__restrict__ joints, const int32_t *
     dA[0][a * 4 + b] -= v;
   }
   __syncthreads();
-  float d_tau[3] = {0, 0, 0};
   if (j < 24) {
     const float jx[3] = {joints[j * 3], joints[j * 3 + 1], joints[j * 3 + 2]};
     for (int a = 0; a < 3; a++) {
@@ -255,29 +254,31 @@ __global__ void k_smpl_tfs_bwd(const float *__restrict__ joints, const int32_t *
     }
   }
   __syncthreads();
-  if (j == 0) {
-    for (int a = 0; a < 3; a++) { float v = 0.f; for (int i = 0; i < 24; i++) v += dg[i][a]; d_tau[a] = v; }
-    if (d_transl) { d_transl[0] = d_tau[0]; d_transl[1] = d_tau[1]; d_transl[2] = d_tau[2]; }
-    // children before parents (parents[i] < i in the SMPL tree)
-    for (int i = 23; i >= 1; i--) {
-      const int p = s_par[i];
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-          float v = 0.f;
-          for (int q = 0; q < 3; q++) v += chain[p][q * 4 + a] * dRG[i][q * 3 + b];   // dR_i = RG_p^T dRG_i
-          dRl[i][a * 3 + b] = v;
-        }
-      for (int a = 0; a < 3; a++) {
-        for (int b = 0; b < 3; b++) {
-          float v = dg[i][a] * tm[i][b * 4 + 3];                                       // dg_i rel_i^T
-          for (int q = 0; q < 3; q++) v += dRG[i][a * 3 + q] * tm[i][b * 4 + q];        // dRG_i R_i^T
-          dRG[p][a * 3 + b] += v;
-        }
-        dg[p][a] += dg[i][a];
-      }
-    }
-    for (int a = 0; a < 9; a++) dRl[0][a] = dRG[0][a];
+  if (j < 3 && d_transl) {   // d tau = sum_j dg_j, joints in a fixed order
+    float v = 0.f;
+    for (int i = 0; i < 24; i++) v += dg[i][j];
+    d_transl[j] = v;
   }
+  __syncthreads();
+  // children before parents (parents[i] < i in the SMPL tree): lane (a, b) of the first nine owns one element of the three
+  // 3x3 products of a step, lanes 9..11 the translation gradient (one lane walking all 23 joints alone took 35 of the
+  // kernel's 44 us).  Every sum keeps its order: dRG_i R_i^T first, then + dg_i rel_i^T, accumulated onto the parent.
+  for (int i = 23; i >= 1; i--) {
+    const int p = s_par[i];
+    if (j < 9) {
+      const int a = j / 3, b = j - 3 * a;
+      float v = 0.f;
+      for (int q = 0; q < 3; q++) v += chain[p][q * 4 + a] * dRG[i][q * 3 + b];   // dR_i = RG_p^T dRG_i
+      dRl[i][j] = v;
+      float w = dg[i][a] * tm[i][b * 4 + 3];                                       // dg_i rel_i^T
+      for (int q = 0; q < 3; q++) w += dRG[i][a * 3 + q] * tm[i][b * 4 + q];        // + dRG_i R_i^T
+      dRG[p][j] += w;
+    } else if (j < 12) {
+      dg[p][j - 9] += dg[i][j - 9];
+    }
+    __syncthreads();
+  }
+  if (j < 9) dRl[0][j] = dRG[0][j];
   __syncthreads();
   if (j < 24) {
     // Rodrigues backward: R = I + sin(a) K + (1 - cos a) K^2
@@ -787,9 +788,11 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     // MODE 1 / 2 (2 = 1 + the Broyden J_inv of every surviving root, compacted like cand_xc: the training route
     // with SMPL parameters under optimisation needs it for the implicit differentiation, deformer_torch.py:58-60)
     float *__restrict__ cand_xc, int cand_cap, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
-    int32_t *__restrict__ n_cand, unsigned long long *prof, float *__restrict__ cand_Jinv) {
+    int32_t *__restrict__ n_cand, unsigned long long *prof, float *__restrict__ cand_Jinv, float *__restrict__ jinv_dense) {
   constexpr int NP = IA_SEARCH_NP;
-  __shared__ float s_Ji[MODE == 2 ? IA_N_INIT_MAX : 1][MODE == 2 ? NP : 1][9];
+  // (MODE 2: the J_inv of a converged solve goes to `jinv_dense` [P][n_init][9] in global memory -- written for valid solves
+  // only, read back by the same workgroup at compaction; 30 KB of LDS for it cost the kernel a wave per SIMD: 282 us per
+  // refine step)
   __shared__ float s_x[IA_N_INIT_MAX][NP][3];
   __shared__ float s_xd[NP][3];
   __shared__ uint8_t s_valid[IA_N_INIT_MAX][NP];
@@ -980,7 +983,10 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
           const size_t o = ((size_t)(p0 + pt) * n_init + init) * 9 + 3 * r_own;
           J_inv[o] = ok ? Jr[0] : 0.f; J_inv[o + 1] = ok ? Jr[1] : 0.f; J_inv[o + 2] = ok ? Jr[2] : 0.f;
         }
-        if (MODE == 2 && ok) { s_Ji[init][pt][3 * r_own] = Jr[0]; s_Ji[init][pt][3 * r_own + 1] = Jr[1]; s_Ji[init][pt][3 * r_own + 2] = Jr[2]; }
+        if (MODE == 2 && ok) {
+          float *o = jinv_dense + ((size_t)(p0 + pt) * n_init + init) * 9 + 3 * r_own;
+          o[0] = Jr[0]; o[1] = Jr[1]; o[2] = Jr[2];
+        }
       }
       active = false;
     }
@@ -1082,7 +1088,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
         }
         if (MODE == 2 && ok) {
 #pragma unroll
-          for (int k = 0; k < 9; k++) s_Ji[init][pt][k] = Ji[k];  // Q4 as above
+          for (int k = 0; k < 9; k++) jinv_dense[((size_t)(p0 + pt) * n_init + init) * 9 + k] = Ji[k];  // Q4 as above
         }
         active = false;
       } else {
@@ -1167,7 +1173,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
       cand_xc[(size_t)o * 3 + 2] = s_x[init][pt][2];
       if (MODE == 2) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) cand_Jinv[(size_t)o * 9 + k] = s_Ji[init][pt][k];
+        for (int k = 0; k < 9; k++) cand_Jinv[(size_t)o * 9 + k] = jinv_dense[((size_t)(p0 + pt) * n_init + init) * 9 + k];
       }
     }
   }
@@ -1254,7 +1260,7 @@ extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, con
                      (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
                      ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
                      valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
-                     (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr);
+                     (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr, (float *)nullptr);
   IA_LAUNCH_CHECK("k_search<0>");
   return IA_OK;
 }
@@ -1263,7 +1269,7 @@ static int ia_search_compact_impl(const char *who, const float *xd, int P, const
                                   const float *tfs, const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
                                   float cvg_thresh, float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
                                   int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, bool with_jinv,
-                                  hipStream_t s) {
+                                  hipStream_t s, float *jinv_dense = nullptr) {
   IA_CHECK_ARG(P >= 0, "%s: P < 0", who);
   IA_CHECK_ARG(n_cand, "%s: n_cand is null", who);
   if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
@@ -1278,12 +1284,12 @@ static int ia_search_compact_impl(const char *who, const float *xd, int P, const
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<2>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
                        cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
                        (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
-                       ia_prof_units(IA_PROF_SEARCH), cand_Jinv);
+                       ia_prof_units(IA_PROF_SEARCH), cand_Jinv, jinv_dense);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
                        cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
                        (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
-                       ia_prof_units(IA_PROF_SEARCH), (float *)nullptr);
+                       ia_prof_units(IA_PROF_SEARCH), (float *)nullptr, (float *)nullptr);
   ia_prof_end(IA_PROF_SEARCH, s);
   IA_LAUNCH_CHECK("k_search<compact>");
   return IA_OK;
@@ -1299,15 +1305,21 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
                                 (hipStream_t)stream);
 }
 
+extern "C" size_t ia_snarf_search_jinv_workspace_bytes(int P, int n_init) {
+  return P > 0 && n_init > 0 ? (size_t)P * (size_t)n_init * 9 * sizeof(float) : 0;
+}
+
 extern "C" int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
                                             const float *voxel_J, const float *tfs, const int32_t *bone_ids,
                                             int n_init, const ia_snarf_grid *grid, float cvg_thresh,
                                             float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
                                             int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter,
-                                            void *stream) {
+                                            void *ws, size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(P <= 0 || (ws && ws_bytes >= ia_snarf_search_jinv_workspace_bytes(P, n_init)),
+               "ia_snarf_search_compact_jinv: workspace of %zu bytes, %zu needed", ws_bytes, ia_snarf_search_jinv_workspace_bytes(P, n_init));
   return ia_search_compact_impl("ia_snarf_search_compact_jinv", xd, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid,
                                 cvg_thresh, dvg_thresh, cand_xc, cand_Jinv, cand_cap, pt_off, pt_cnt, n_cand, zero_counter,
-                                true, (hipStream_t)stream);
+                                true, (hipStream_t)stream, static_cast<float *>(ws));
 }
 
 // ---------------------------------------------------------------------------

@@ -870,14 +870,18 @@ def test_round3_entry_points_validate_arguments_before_any_launch():
     one = C.c_void_p(16)
     bones = _lib.bone_array([0, 1, 2])
     tail = (C.c_float(1e-5), C.c_float(1e-1))
-    # n_cand is required; P < 0 is rejected; P == 0 returns before touching anything; the J_inv output is required
-    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, None, 0, None) != 0
+    # n_cand is required; P < 0 is rejected; P == 0 returns before touching anything; the J_inv output and the workspace are required
+    big = 1 << 20
+    assert L.ia_snarf_search_jinv_workspace_bytes(4, 3) == 4 * 3 * 9 * 4
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, None, 0, one, big, None) != 0
     assert b"n_cand" in L.ia_last_error()
-    assert L.ia_snarf_search_compact_jinv(one, -1, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, None) != 0
-    assert L.ia_snarf_search_compact_jinv(None, 0, None, None, None, bones, 3, C.byref(g), *tail, None, None, 0, None, None, one, 0, None) == 0
-    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, None, 16, one, one, one, 0, None) != 0
+    assert L.ia_snarf_search_compact_jinv(one, -1, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, one, big, None) != 0
+    assert L.ia_snarf_search_compact_jinv(None, 0, None, None, None, bones, 3, C.byref(g), *tail, None, None, 0, None, None, one, 0, None, 0, None) == 0
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, None, 16, one, one, one, 0, one, big, None) != 0
     assert b"null pointer" in L.ia_last_error()
-    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 99, C.byref(g), *tail, one, one, 16, one, one, one, 0, None) != 0
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, one, 8, None) != 0
+    assert b"workspace" in L.ia_last_error()
+    assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 99, C.byref(g), *tail, one, one, 16, one, one, one, 0, one, big, None) != 0
     assert b"n_init" in L.ia_last_error()
     # compact implicit backward: the device-side count is mandatory, the workspace is checked
     assert L.ia_snarf_implicit_bwd_compact(one, one, one, 100, None, one, 1, C.byref(g), one, one, 1 << 20, None) != 0
