@@ -14,4 +14,4 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 plain = "--plain" in sys.argv   # the config-2 workload (PatchSampler, fresh field) instead of refinement
 r = bench.train_throughput(model, dev, poses, tr, 0, 1, n, res=512, sampler="patch" if plain else "edge", refine=not plain,
                            graphed="--eager" not in sys.argv)
-print({k: r[k] for k in ("it_per_sec", "launch_mode", "samples_candidates_last_step")})
+print({k: r.get(k) for k in ("it_per_sec", "launch_mode", "samples_candidates_last_step", "mse_first", "mse_last", "train_overflow", "smpl_tables_max_abs_change", "graph_capture_error")})
