@@ -230,6 +230,21 @@ def _train_worker(rank, world, port, q):
     losses = training.training_step(model, batch, opt, loss_fn, world_size=world)
     skipped = bool(losses["skipped_non_finite"])
     same_after_skip = all(torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    # a candidate-capacity overflow on ONE rank (round 3): that rank's loss is turned into NaN before the backward pass, the
+    # gradient average carries it to the other rank, both skip -- no extra collective, replicas stay identical
+    before2 = [p.detach().clone() for p in model.parameters()]
+    batch = {"pts": torch.randn(16, 3), "rgb": torch.rand(16, 3), "alpha": torch.rand(16)}
+    fwd = model.forward
+
+    def forward_with_overflow(b, eval_mode=False, noise=0):
+        out = fwd(b, eval_mode=eval_mode, noise=noise)
+        model.renderer.train_overflow_flag = torch.tensor(1.0 if rank == 0 else 0.0)     # what render_train_fused sets
+        return out
+    model.forward = forward_with_overflow
+    losses2 = training.training_step(model, batch, opt, loss_fn, world_size=world)
+    model.forward = fwd
+    skipped = skipped and bool(losses2["skipped_non_finite"]) and float(losses2["skipped_overflow"]) == (1.0 if rank == 0 else 0.0)
+    same_after_skip = same_after_skip and all(torch.equal(a, b.detach()) for a, b in zip(before2, model.parameters()))
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()] + [model.renderer.density_grid_train.density_cached.reshape(-1)])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -253,7 +268,7 @@ def test_gloo_world2_real_training_step_plumbing():
         assert ok, "averaged gradient != mean of the local gradients"
         assert identical, "replicas (parameters + cached densities) diverged"
         assert skipped and same_after_skip, "a non-finite gradient must skip the optimiser step on every rank"
-        assert gstep == 23 and updates == 24   # 23 steps + the start-up broadcast
+        assert gstep == 24 and updates == 25   # 24 steps + the start-up broadcast
     assert res[0][5] == res[1][5], "start-up broadcast did not equalise the replicas"
 
 
