@@ -615,6 +615,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timed_frames = int(frames_done[0])          # what THIS rank rendered inside the timed region (the secondary runs below count on)
     main_samples_per_ray = float(cnt_sum.sum().item()) / args.steps
     main_alpha_coverage = float(cov_sum.sum().item()) / args.steps
     # frames whose wave-front loop needed more iterations than the graph holds (deferred check) are
@@ -756,12 +757,12 @@ def main():
     frames_per_rank = [args.steps]
     if world_size > 1:   # what every rank really rendered inside the timed region (gathered, not assumed)
         got = [None] * world_size
-        torch.distributed.all_gather_object(got, int(frames_done[0]))
+        torch.distributed.all_gather_object(got, timed_frames)
         frames_per_rank = [int(g) for g in got]
         frames = sum(frames_per_rank)
         fps = frames / dt
     else:
-        frames_per_rank = [int(frames_done[0])]
+        frames_per_rank = [timed_frames]
     result = {
         "metric": "novel_pose_render_frames_per_sec_512x512", "value": fps, "unit": "frames/s",
         "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
