@@ -537,6 +537,7 @@ __device__ __forceinline__ bool fetch_J(const float *__restrict__ vJ, const Snar
 // 485 -> 501 frames/s for the whole frame.  IA_QUAD_GROUP-style splitting of a round, a forced fifth wave (96 VGPRs,
 // spills: 380 us) and 128 x 32 / 128 x 64 / 256 x 128 / 512 x 128 / 64 x 16 workgroups (234 / 224 / 224 / 226 / 259 us)
 // measured and rejected.  tools/ab_search.sh "-DIA_SEARCH_QUAD=0" gives the lane-per-fetch path.
+// Later in round 3 the way the rows travel changed (IA_QUAD_LDS_DELIVER below): 199 us.
 #ifndef IA_SEARCH_QUAD
 #define IA_SEARCH_QUAD 1
 #endif
@@ -575,11 +576,17 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
   const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
   const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
   const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
+  // byte offsets as sums of three per-axis terms: six 24-bit multiplies (full rate) and twelve adds instead of fourteen
+  // 32-bit multiplies (quarter rate) -- the clamped indices and the strides are far below 2^24 (no measurable change: 201 us)
+  const uint32_t sy = (uint32_t)g.W * 48u, sz = (uint32_t)(g.W * g.H) * 48u;
+  const uint32_t xo[2] = {(uint32_t)__umul24((uint32_t)cx0, 48u), (uint32_t)__umul24((uint32_t)cx1, 48u)};
+  const uint32_t yo[2] = {(uint32_t)__umul24((uint32_t)cy0, sy), (uint32_t)__umul24((uint32_t)cy1, sy)};
+  const uint32_t zo[2] = {(uint32_t)__umul24((uint32_t)cz0, sz), (uint32_t)__umul24((uint32_t)cz1, sz)};
+  const uint32_t zy[4] = {zo[0] + yo[0], zo[0] + yo[1], zo[1] + yo[0], zo[1] + yo[1]};
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int xx = (k & 1) ? cx1 : cx0, yy = (k & 2) ? cy1 : cy0, zz = (k & 4) ? cz1 : cz0;
     const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
-    p.off[k] = (uint32_t)((zz * g.H + yy) * g.W + xx) * 48u;
+    p.off[k] = zy[k >> 1] + xo[k & 1];
     p.w[k] = in ? wgt[k] : 0.f;
   }
   p.load = (active && (bx0 || bx1) && (by0 || by1) && (bz0 || bz1)) ? 1u : 0u;
@@ -589,9 +596,145 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
 // clamped into the grid, so a load is always legal; the fourth lane of a quad repeats the third piece -- the same 16 bytes,
 // no extra look-up), and a fetch with all corners outside has all weights 0: fma(v, 0, +0) = +0 for the finite table values,
 // exactly the zeros the reference's skipped corners leave.
+// IA_QUAD_LDS_DELIVER -- how the rows get back to the lane that needs them (all variants bit-identical, the parity tests pass
+// with each; compact search of a frame's 213 k sample points, tools/bench_search.py, MI355X):
+//   0  four rounds, rows return by DPP (12 moves + 12 selects per round)                                          218.6 us
+//   1  four rounds, rows return through LDS: one 16-byte store per row lane and round, three 16-byte loads per
+//      lane and step (12 KB per workgroup); the compiler also drops lane 3's duplicate loads                     212.4 us
+//   2  as 1, and the 12 (target, row) pairs of a quad are dealt to its FOUR lanes in THREE rounds (below)         198.9 us
+//   3  the deal of 2 in TWO round trips of 12 loads (128 VGPRs, still 4 waves)                                     204.0 us
+// (3 against 2: the number of dependent round trips is not what bounds the step; the load instructions are -- 32 / 32 / 24 / 24.)
+#ifndef IA_QUAD_LDS_DELIVER
+#define IA_QUAD_LDS_DELIVER 2
+#endif
+#if IA_QUAD_LDS_DELIVER >= 2
+// Round R, lane k serves pair 4R + k = (target (4R + k) / 3, row (4R + k) % 3): the source lane of every DPP read is a per-lane
+// constant of the round -- quad_perm [0,0,0,1], [1,1,2,2], [2,3,3,3] -- and the row lands in float4 number 4R + k of the quad's
+// 12-float4 block in LDS, which is exactly where target lane t reads its rows 3t .. 3t + 2.  No lane idles (the 4-round deal
+// leaves lane 3 without a row), a step is three dependent load round trips instead of four, 24 load instructions instead of 32.
+template <int PERM> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, PERM, 0xF, 0xF, true);
+}
+template <int PERM> __device__ __forceinline__ float quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), PERM, 0xF, 0xF, true));
+}
+template <int R>
+__device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const FetchPlan &p, float4 *__restrict__ s_quad_k) {
+  constexpr int PERM = R == 0 ? 0x40 : (R == 1 ? 0xA5 : 0xFE);
+  const uint32_t load = quad_perm<PERM>(p.load);
+  if (__ballot(load != 0) == 0) return;
+  // (all DPP reads before the divergent part: a source lane that sits out this round must still be enabled when it is read)
+  uint32_t off[8];
+  float w[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) { off[c] = quad_perm<PERM>(p.off[c]); w[c] = quad_perm<PERM>(p.w[c]); }
+  const uint32_t koff = (uint32_t)(((threadIdx.x & 3) + R) % 3) * 16u;   // row (4R + k) % 3 = (k + R) % 3
+  if (load != 0) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(off[c] + koff));
+    f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const f2 w2 = (f2){w[c], w[c]};
+      a0 = __builtin_elementwise_fma((f2){v[c].x, v[c].y}, w2, a0);
+      a1 = __builtin_elementwise_fma((f2){v[c].z, v[c].w}, w2, a1);
+    }
+    s_quad_k[4 * R] = make_float4(a0.x, a0.y, a1.x, a1.y);
+  }
+}
+// IA_QUAD_LDS_DELIVER == 3: the same deal in TWO round trips of 12 loads -- pair k whole and the first four corners of pair 4 + k,
+// then the last four corners of pair 4 + k (the fma chain of a row continues in its own registers) and pair 8 + k whole.
+template <int PERM, int C0, int C1>
+__device__ __forceinline__ void quad_issue(const char *__restrict__ vJb, const FetchPlan &p, uint32_t koff, float4 *__restrict__ v) {
+#pragma unroll
+  for (int c = C0; c < C1; c++) v[c - C0] = *reinterpret_cast<const float4 *>(vJb + (size_t)(quad_perm<PERM>(p.off[c]) + koff));
+}
+typedef float iaf2 __attribute__((ext_vector_type(2)));
+template <int C0, int C1>
+__device__ __forceinline__ void quad_chain(const float4 *__restrict__ v, const float *__restrict__ w, iaf2 &a0, iaf2 &a1) {
+#pragma unroll
+  for (int c = C0; c < C1; c++) {
+    const iaf2 w2 = (iaf2){w[c], w[c]};
+    a0 = __builtin_elementwise_fma((iaf2){v[c - C0].x, v[c - C0].y}, w2, a0);
+    a1 = __builtin_elementwise_fma((iaf2){v[c - C0].z, v[c - C0].w}, w2, a1);
+  }
+}
+__device__ __forceinline__ void fetch_rounds_2x12(const char *__restrict__ vJb, const FetchPlan &p, float4 *__restrict__ s_quad_k) {
+  constexpr int P0 = 0x40, P1 = 0xA5, P2 = 0xFE;
+  const uint32_t l0 = quad_perm<P0>(p.load), l1 = quad_perm<P1>(p.load), l2 = quad_perm<P2>(p.load);
+  if (__ballot((l0 | l1 | l2) != 0) == 0) return;
+  const int k = threadIdx.x & 3;
+  const uint32_t k0 = (uint32_t)(k % 3) * 16u, k1 = (uint32_t)((k + 1) % 3) * 16u, k2 = (uint32_t)((k + 2) % 3) * 16u;
+  // (every DPP read in wave-uniform control flow: the source lane must be enabled; addresses before the loads, weights after
+  // their issue, so that the 12 x 4 registers of load data are the only large live set)
+  float4 va[8], vb[4];
+  {
+    uint32_t oa[8], ob[4];
+#pragma unroll
+    for (int c = 0; c < 8; c++) oa[c] = quad_perm<P0>(p.off[c]) + k0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) ob[c] = quad_perm<P1>(p.off[c]) + k1;
+    if (l0 != 0) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) va[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)oa[c]);
+    }
+    if (l1 != 0) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) vb[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)ob[c]);
+    }
+  }
+  iaf2 b0 = (iaf2){0.f, 0.f}, b1 = (iaf2){0.f, 0.f};
+  {
+    float wa[8], wb[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) wa[c] = quad_perm<P0>(p.w[c]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) wb[c] = quad_perm<P1>(p.w[c]);
+    if (l0 != 0) {
+      iaf2 a0 = (iaf2){0.f, 0.f}, a1 = (iaf2){0.f, 0.f};
+      quad_chain<0, 8>(va, wa, a0, a1);
+      s_quad_k[0] = make_float4(a0.x, a0.y, a1.x, a1.y);
+    }
+    if (l1 != 0) quad_chain<0, 4>(vb, wb, b0, b1);
+  }
+  {
+    uint32_t oa[8], ob[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) ob[c] = quad_perm<P1>(p.off[4 + c]) + k1;
+#pragma unroll
+    for (int c = 0; c < 8; c++) oa[c] = quad_perm<P2>(p.off[c]) + k2;
+    if (l1 != 0) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) vb[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)ob[c]);
+    }
+    if (l2 != 0) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) va[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)oa[c]);
+    }
+  }
+  {
+    float wa[8], wb[8];
+#pragma unroll
+    for (int c = 4; c < 8; c++) wb[c] = quad_perm<P1>(p.w[c]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) wa[c] = quad_perm<P2>(p.w[c]);
+    if (l1 != 0) {
+      quad_chain<4, 8>(vb, wb, b0, b1);
+      s_quad_k[4] = make_float4(b0.x, b0.y, b1.x, b1.y);
+    }
+    if (l2 != 0) {
+      iaf2 a0 = (iaf2){0.f, 0.f}, a1 = (iaf2){0.f, 0.f};
+      quad_chain<0, 8>(va, wa, a0, a1);
+      s_quad_k[8] = make_float4(a0.x, a0.y, a1.x, a1.y);
+    }
+  }
+}
+#endif
 template <int T>
 __device__ __forceinline__ void fetch_round(const char *__restrict__ vJb, const FetchPlan &p, uint32_t koff, bool not_mine,
-                                            float *__restrict__ out) {
+                                            float *__restrict__ out, float4 *__restrict__ s_del = nullptr) {
   const uint32_t load = quad_bcast<T>(p.load);
   if (__ballot(load != 0) == 0) return;   // no lane T of this wave needs anything: `out` stays zero (cleared by the caller)
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -620,6 +763,13 @@ __device__ __forceinline__ void fetch_round(const char *__restrict__ vJb, const 
       if (IA_QUAD_GROUP < 8) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }
   }
+#if IA_QUAD_LDS_DELIVER
+  // row k of target T's transform: one ds_write_b128 into the target lane's slot (the target reads its three rows after the
+  // fourth round; LDS operations of one wave execute in order, the quad is inside one wave)
+  if (load != 0 && (threadIdx.x & 3) < 3)
+    s_del[((threadIdx.x & ~3u) | T) * 3 + (threadIdx.x & 3)] = make_float4(a0.x, a0.y, a1.x, a1.y);
+  return;
+#endif
   // rows 0..2 (lanes 0..2 of the quad) back to the target lane: out = not_mine ? out : row (v_cndmask with a DPP source)
   const float a[4] = {a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
@@ -671,13 +821,45 @@ __device__ __forceinline__ void fetch_round2(const char *__restrict__ vJb, const
 
 // the fetch of every lane of the wave (call in wave-uniform control flow); `loaded`: this lane's fetch touched memory
 __device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const SnarfGridDev &g, float gx, float gy, float gz,
-                                             bool active, float *__restrict__ out, bool &loaded) {
+                                             bool active, float *__restrict__ out, bool &loaded, float4 *__restrict__ s_del = nullptr) {
   FetchPlan p;
   fetch_plan(g, gx, gy, gz, active, p);
   loaded = p.load != 0;
   const int k = threadIdx.x & 3;
   const uint32_t koff = (uint32_t)min(k, 2) * 16u;
   const char *vJb = reinterpret_cast<const char *>(vJ);
+#if IA_QUAD_LDS_DELIVER
+  if (p.load == 0) {   // nobody will write this lane's slot: an active lane with all corners outside reads zeros
+    s_del[threadIdx.x * 3] = make_float4(0.f, 0.f, 0.f, 0.f); s_del[threadIdx.x * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_del[threadIdx.x * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __builtin_amdgcn_wave_barrier();
+#if IA_QUAD_LDS_DELIVER >= 2
+  {
+    float4 *const s_quad_k = s_del + (threadIdx.x & ~3u) * 3 + k;
+#if IA_QUAD_LDS_DELIVER == 3
+    fetch_rounds_2x12(vJb, p, s_quad_k);
+#else
+    fetch_round3<0>(vJb, p, s_quad_k);
+    fetch_round3<1>(vJb, p, s_quad_k);
+    fetch_round3<2>(vJb, p, s_quad_k);
+#endif
+  }
+#else
+  fetch_round<0>(vJb, p, koff, k != 0, out, s_del);
+  fetch_round<1>(vJb, p, koff, k != 1, out, s_del);
+  fetch_round<2>(vJb, p, koff, k != 2, out, s_del);
+  fetch_round<3>(vJb, p, koff, k != 3, out, s_del);
+#endif
+  __builtin_amdgcn_wave_barrier();
+  {
+    const float4 r0 = s_del[threadIdx.x * 3], r1 = s_del[threadIdx.x * 3 + 1], r2 = s_del[threadIdx.x * 3 + 2];
+    out[0] = r0.x; out[1] = r0.y; out[2] = r0.z; out[3] = r0.w; out[4] = r1.x; out[5] = r1.y; out[6] = r1.z; out[7] = r1.w;
+    out[8] = r2.x; out[9] = r2.y; out[10] = r2.z; out[11] = r2.w;
+  }
+  __builtin_amdgcn_wave_barrier();   // the next step's zero-fill / rows must not overtake these reads
+  return;
+#endif
 #pragma unroll
   for (int c = 0; c < 12; c++) out[c] = 0.f;
 #ifndef IA_QUAD_PAIR
@@ -699,6 +881,9 @@ __device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const
 }
 
 // fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55)
+#ifndef IA_SHARED_RCP
+#define IA_SHARED_RCP 1
+#endif
 __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float x2, float g0, float g1,
                                             float g2) {
   const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
@@ -710,6 +895,41 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
   const float r0 = IA_DOT3(-J00, g0, -J01, g1, -J02, g2);
   const float r1 = IA_DOT3(-J10, g0, -J11, g1, -J12, g2);
   const float r2 = IA_DOT3(-J20, g0, -J21, g1, -J22, g2);
+#if IA_SHARED_RCP
+  // Nine IEEE divisions by the same s.  The compiler expands each a / b into v_div_scale x 2, v_rcp, a ten-instruction Newton
+  // chain, v_div_fmas, v_div_fixup.  v_div_scale only rescales its operands at the edges of the exponent range (a denormal
+  // or huge denominator, a numerator below 2^-103, a quotient near overflow / underflow -- CDNA3 ISA, V_DIV_SCALE_F32); away from
+  // those it returns them unchanged with VCC = 0, and v_div_fmas is then a plain fma.  In that range the reciprocal half of
+  // the chain (v_rcp + two fma) depends on s alone and is computed ONCE here; the numerator half is the same five instructions
+  // the compiler emits, v_div_fixup keeps the zero / inf / NaN cases, so the quotients are bit-identical.  The range test is
+  // on the binary exponents of the factors (a numerator is a product c_j t_i: zero, or within 2^-101 .. 2^18 when c, t are
+  // zero or within 2^-50 .. 2^8; s within 2^-68 .. 2^22 keeps every exponent difference inside (-126, 96)); if ANY lane of the
+  // wave fails it, the wave takes the compiler's divisions.  (v_frexp_exp returns 0 for zero, inf and NaN: those pass and are
+  // v_div_fixup's cases, which do not look at the quotient.)  MEASURED: 202.0 -> 199.6 us (tools/bench_search.py), parity green.
+  const float t0 = r0 + x0, t1 = r1 + x1, t2 = r2 + x2;
+  const int e_hi = max(max(max(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
+                       max(max(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
+  const int e_lo = min(min(min(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
+                       min(min(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
+  const int e_s = __builtin_amdgcn_frexp_expf(s);
+  const bool plain = e_hi <= 8 && e_lo >= -48 && e_s >= -66 && e_s <= 22;
+  if (__ballot(!plain) == 0) {
+    const float ra = __builtin_amdgcn_rcpf(s);
+    const float rb = __builtin_fmaf(__builtin_fmaf(-s, ra, 1.0f), ra, ra);
+    const float tt[3] = {t0, t1, t2}, cc[3] = {c0, c1, c2};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float n = cc[j] * tt[i];
+        const float q0 = n * rb;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-s, q0, n), rb, q0);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(-s, q1, n), rb, q1);
+        Ji[3 * i + j] += __builtin_amdgcn_div_fixupf(q2, s, n);
+      }
+    return;
+  }
+#endif
   Ji[0] += c0 * (r0 + x0) / s; Ji[1] += c1 * (r0 + x0) / s; Ji[2] += c2 * (r0 + x0) / s;
   Ji[3] += c0 * (r1 + x1) / s; Ji[4] += c1 * (r1 + x1) / s; Ji[5] += c2 * (r1 + x1) / s;
   Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
@@ -805,6 +1025,8 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   __shared__ int s_prof[3];
   __shared__ uint16_t s_list[IA_N_INIT_MAX * NP];
   __shared__ float s_T[IA_N_INIT_MAX][12];  // rows 0..2 of the init bones' transforms (same indexing as the 4x4)
+  __shared__ float4 s_del_store[(IA_SEARCH_QUAD != 0 && IA_QUAD_LDS_DELIVER != 0) ? IA_SEARCH_THREADS * 3 : 1];
+  float4 *const s_del = s_del_store;
   if (n_pts_dev) P = min(P, *n_pts_dev);
   const int tid = threadIdx.x, lane = tid & 63;
   // (an XCD-aware remap -- XCD x takes the x-th contiguous eighth of the point list -- was measured:
@@ -1000,8 +1222,11 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   bool active = false, first = false;
   // `solves` counts the queued (non-trivial) ones; `fetches` every trilinear fetch of the reference's algorithm, `loaded` those
   // that touched memory (a fetch with all 8 corners outside the grid is zero by construction and loads nothing)
-  int item = 0, iter = 0, fetches = 0, solves = 0, loaded = 0;
-  float t0 = 0, t1 = 0, t2 = 0, xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
+  // (packed: registers are what bounds the waves per SIMD here -- `counts` = fetches | loaded << 16, a lane sees at most
+  // 13 * NP * 11 < 2^16 fetches per launch; `it_solves` = iter | solves << 8; the target x_d is re-read from LDS where it is used)
+  int item = 0;
+  uint32_t counts = 0, it_solves = 0;
+  float xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
   float Ji[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) Ji[k] = 0.f;
@@ -1026,14 +1251,14 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
         if (!active && my < n_live) {
           item = s_list[my];
           const int init = item >> 7, pt = item & (NP - 1);
-          t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
+          const float t0 = s_xd[pt][0], t1 = s_xd[pt][1], t2 = s_xd[pt][2];
           const float *T = s_T[init];
           // :287-293  x0 = R^T (xd - t)
           const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
           xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
           xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
           xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
-          active = true; first = true; iter = 0; solves++;
+          active = true; first = true; it_solves = (it_solves & ~0xFFu) + 0x100u;
         }
       }
     }
@@ -1044,14 +1269,15 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     float Jl[12];
     bool ld = false;
 #if IA_SEARCH_QUAD
-    fetch_J_quad(vJ, g, ix, iy, iz, active, Jl, ld);   // all lanes: the quad serves its four fetches in four rounds
+    fetch_J_quad(vJ, g, ix, iy, iz, active, Jl, ld, s_del);   // all lanes: the quad serves its four fetches together
 #else
     if (active) ld = fetch_J(vJ, g, ix, iy, iz, Jl);
 #endif
     if (active) {
-      fetches++;
-      loaded += ld ? 1 : 0;
+      counts += ld ? 0x10001u : 1u;
       bool done = false, ok = false;
+      const float *txd = s_xd[item & (NP - 1)];
+      const float t0 = txd[0], t1 = txd[1], t2 = txd[2];
       // residual g(x) = J x + d - x_d at the current point (:325-332 initial, :356-367 updated)
       const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
       const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
@@ -1073,7 +1299,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
         } else {
           jinv_update(Ji, u0, u1, u2, n0 - gx0, n1 - gx1, n2 - gx2);  // :400-411
           gx0 = n0; gx1 = n1; gx2 = n2;
-          if (++iter == 10) done = true;  // Q1: not converged after 10 iterations -> invalid
+          if ((++it_solves & 0xFFu) == 10u) done = true;  // Q1: not converged after 10 iterations -> invalid
         }
       }
       if (done) {
@@ -1102,7 +1328,11 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   }
 #endif
   if (prof) {  // bench-only accounting: solves and trilinear fetches
+#if IA_SEARCH_QPS
     int f = fetches, n = solves, l = loaded;
+#else
+    int f = (int)(counts & 0xFFFFu), n = (int)(it_solves >> 8), l = (int)(counts >> 16);
+#endif
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); l += __shfl_xor(l, o, 64); }
     if (lane == 0) { atomicAdd(&s_prof[0], n); atomicAdd(&s_prof[1], f); atomicAdd(&s_prof[2], l); }

@@ -200,7 +200,11 @@ def test_refine_step_replays_from_a_hip_graph():
     print("eager", e, "graph", g)
     assert np.allclose(e, g, rtol=2e-2, atol=1e-6), (e, g)
     assert np.abs(tables[1] - G["table_body_pose"]).max() > 1e-5          # the replayed steps really optimise the SMPL tables
-    assert np.abs(tables[0] - tables[1]).max() < 4e-5
+    # eager and replayed steps end at the same tables up to what the order of the atomics does: Adam normalises every element's
+    # step to ~lr = 1e-5, so an element whose gradient is noise can differ by a few lr between two runs (8 steps: <= 1.6e-4);
+    # on average the difference is a small fraction of the distance travelled
+    travel, diff = np.abs(tables[1] - G["table_body_pose"]), np.abs(tables[0] - tables[1])
+    assert diff.mean() < 0.2 * travel.mean() and diff.max() < 1.6e-4, (diff.mean(), travel.mean(), diff.max())
 
 
 def test_smpl_chain_backward_kernel_equals_autograd_through_lbs():
