@@ -961,6 +961,8 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 #ifndef IA_SEARCH_NP
 #if IA_SEARCH_QUAD
 #define IA_SEARCH_NP 64        // quad-cooperative fetch, round 3: 256 x 64 218 us, 128 x 32 234, 128 x 64 224, 256 x 128 224, 512 x 128 226, 64 x 16 259
+                               // re-measured with the three-round deal: 256 x 64 199.6, 128 x 32 206.7, 512 x 128 206.7, 256 x 128 212.1,
+                               // 128 x 64 215.3, 64 x 32 223.0, 256 x 32 228.6, 512 x 64 229.2, 1024 x 64 326.3 (threads x points)
 #else
 #define IA_SEARCH_NP 32        // points per workgroup (power of two, <= 128): 9.6 KB of LDS, 16 workgroups per CU
 #endif
