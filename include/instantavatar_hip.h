@@ -533,6 +533,19 @@ int ia_profile_get_units(int kernel_id, uint64_t *units, int n);
 /* registers per lane, static LDS bytes and threads per workgroup, resident workgroups per CU of the Broyden-search
  * kernel as compiled into this library (measurement only).                                                        */
 int ia_search_kernel_info(int *vgprs, int *lds_bytes, int *threads, int *workgroups_per_cu);
+/* Device self-tests of the Broyden update's shared-reciprocal division (fuse_cuda_kernel_fast.cu:23-55 divides nine
+ * numerators by the same scalar; k_search computes the reciprocal chain of IEEE division once).  They launch the same
+ * device functions the search kernel uses; called by tests/ only.
+ *   ia_selftest_shared_rcp:  q_shared[i] = shared-reciprocal quotient num[i] / den[i], q_ieee[i] = the compiler's
+ *                            division of the same operands (all device pointers, n floats each).
+ *   ia_selftest_jinv_update: the rank-1 update of n J_inv matrices Ji [n][9] with steps x [n][3] and residual
+ *                            differences g [n][3], once as k_search runs it (the shared reciprocal per wave of 64
+ *                            consecutive rows when all of them are inside its exponent range -> took_shared[i] = 1,
+ *                            the compiler's divisions otherwise) and once with the compiler's divisions only.
+ *                            n % 64 == 0.                                                                              */
+int ia_selftest_shared_rcp(const float *num, const float *den, int n, float *q_shared, float *q_ieee, void *stream);
+int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int n, float *out_shared, float *out_plain,
+                            uint8_t *took_shared, void *stream);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,8 @@ _SIGS = {
     "ia_profile_get_units": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "ia_selftest_shared_rcp": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
+    "ia_selftest_jinv_update": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
 }
 EXPORTED = sorted(_SIGS)
 

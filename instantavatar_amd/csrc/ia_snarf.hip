@@ -884,8 +884,41 @@ __device__ __forceinline__ void fetch_J_quad(const float *__restrict__ vJ, const
 #ifndef IA_SHARED_RCP
 #define IA_SHARED_RCP 1
 #endif
-__device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float x2, float g0, float g1,
-                                            float g2) {
+// ---- nine IEEE divisions by the same denominator ----------------------------------------------------------------------
+// The compiler expands a / b into v_div_scale x 2, v_rcp, a Newton chain (fma, fma on the reciprocal; mul, fma, fma, fma on
+// the quotient), v_div_fmas, v_div_fixup.  v_div_scale only rescales its operands at the edges of the exponent range (a
+// denormal or huge denominator, a numerator below 2^-103, a quotient near overflow / underflow -- CDNA3 ISA, V_DIV_SCALE_F32);
+// away from those it returns them unchanged with VCC = 0, and v_div_fmas is then a plain fma.  In that range the reciprocal
+// half of the chain depends on the denominator alone (`rcp_refined`, once per update) and the numerator half is the same five
+// instructions the compiler emits (`div_shared`); v_div_fixup keeps the zero / inf / NaN cases (it does not look at the
+// quotient for those), so the quotients are bit-identical to a / b.  `ia_selftest_shared_rcp` sweeps the exponent range on
+// the device (tests/test_gpu_edge_cases.py).
+__device__ __forceinline__ float rcp_refined(float s) {
+  const float ra = __builtin_amdgcn_rcpf(s);
+  return __builtin_fmaf(__builtin_fmaf(-s, ra, 1.0f), ra, ra);
+}
+__device__ __forceinline__ float div_shared(float n, float s, float rb) {
+  const float q0 = n * rb;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-s, q0, n), rb, q0);
+  const float q2 = __builtin_fmaf(__builtin_fmaf(-s, q1, n), rb, q1);
+  return __builtin_amdgcn_div_fixupf(q2, s, n);
+}
+// The range in which `div_shared` IS the compiler's division, as a test on binary exponents (v_frexp_exp: |v| in
+// [2^(e-1), 2^e); 0 for zero, inf and NaN, which pass and are v_div_fixup's cases).  A numerator is a product c_j t_i: with
+// c, t zero or in [2^-49, 2^8) it is zero or in [2^-98, 2^16); with s in [2^-67, 2^22) every exponent difference stays inside
+// (-126, 96), no operand is denormal and no numerator is below 2^-103.
+__device__ __forceinline__ bool div_shared_range(float c0, float c1, float c2, float t0, float t1, float t2, float s) {
+  const int e_hi = max(max(max(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
+                       max(max(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
+  const int e_lo = min(min(min(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
+                       min(min(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
+  const int e_s = __builtin_amdgcn_frexp_expf(s);
+  return e_hi <= 8 && e_lo >= -48 && e_s >= -66 && e_s <= 22;
+}
+// fuse_J_inv_update (fuse_cuda_kernel_fast.cu:23-55).  SHARED: the shared reciprocal when EVERY lane of the wave is inside
+// the range, the compiler's divisions otherwise; returns which one ran.  MEASURED: 202.0 -> 199.6 us (tools/bench_search.py).
+template <bool SHARED>
+__device__ __forceinline__ bool jinv_update_impl(float *Ji, float x0, float x1, float x2, float g0, float g1, float g2) {
   const float J00 = Ji[0], J01 = Ji[1], J02 = Ji[2], J10 = Ji[3], J11 = Ji[4], J12 = Ji[5], J20 = Ji[6],
               J21 = Ji[7], J22 = Ji[8];
   const float c0 = IA_DOT3(J00, x0, J10, x1, J20, x2);
@@ -895,44 +928,25 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
   const float r0 = IA_DOT3(-J00, g0, -J01, g1, -J02, g2);
   const float r1 = IA_DOT3(-J10, g0, -J11, g1, -J12, g2);
   const float r2 = IA_DOT3(-J20, g0, -J21, g1, -J22, g2);
-#if IA_SHARED_RCP
-  // Nine IEEE divisions by the same s.  The compiler expands each a / b into v_div_scale x 2, v_rcp, a ten-instruction Newton
-  // chain, v_div_fmas, v_div_fixup.  v_div_scale only rescales its operands at the edges of the exponent range (a denormal
-  // or huge denominator, a numerator below 2^-103, a quotient near overflow / underflow -- CDNA3 ISA, V_DIV_SCALE_F32); away from
-  // those it returns them unchanged with VCC = 0, and v_div_fmas is then a plain fma.  In that range the reciprocal half of
-  // the chain (v_rcp + two fma) depends on s alone and is computed ONCE here; the numerator half is the same five instructions
-  // the compiler emits, v_div_fixup keeps the zero / inf / NaN cases, so the quotients are bit-identical.  The range test is
-  // on the binary exponents of the factors (a numerator is a product c_j t_i: zero, or within 2^-101 .. 2^18 when c, t are
-  // zero or within 2^-50 .. 2^8; s within 2^-68 .. 2^22 keeps every exponent difference inside (-126, 96)); if ANY lane of the
-  // wave fails it, the wave takes the compiler's divisions.  (v_frexp_exp returns 0 for zero, inf and NaN: those pass and are
-  // v_div_fixup's cases, which do not look at the quotient.)  MEASURED: 202.0 -> 199.6 us (tools/bench_search.py), parity green.
-  const float t0 = r0 + x0, t1 = r1 + x1, t2 = r2 + x2;
-  const int e_hi = max(max(max(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
-                       max(max(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
-  const int e_lo = min(min(min(__builtin_amdgcn_frexp_expf(c0), __builtin_amdgcn_frexp_expf(c1)), __builtin_amdgcn_frexp_expf(c2)),
-                       min(min(__builtin_amdgcn_frexp_expf(t0), __builtin_amdgcn_frexp_expf(t1)), __builtin_amdgcn_frexp_expf(t2)));
-  const int e_s = __builtin_amdgcn_frexp_expf(s);
-  const bool plain = e_hi <= 8 && e_lo >= -48 && e_s >= -66 && e_s <= 22;
-  if (__ballot(!plain) == 0) {
-    const float ra = __builtin_amdgcn_rcpf(s);
-    const float rb = __builtin_fmaf(__builtin_fmaf(-s, ra, 1.0f), ra, ra);
-    const float tt[3] = {t0, t1, t2}, cc[3] = {c0, c1, c2};
+  if (SHARED) {
+    const float t0 = r0 + x0, t1 = r1 + x1, t2 = r2 + x2;
+    if (__ballot(!div_shared_range(c0, c1, c2, t0, t1, t2, s)) == 0) {
+      const float rb = rcp_refined(s);
+      const float tt[3] = {t0, t1, t2}, cc[3] = {c0, c1, c2};
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const float n = cc[j] * tt[i];
-        const float q0 = n * rb;
-        const float q1 = __builtin_fmaf(__builtin_fmaf(-s, q0, n), rb, q0);
-        const float q2 = __builtin_fmaf(__builtin_fmaf(-s, q1, n), rb, q1);
-        Ji[3 * i + j] += __builtin_amdgcn_div_fixupf(q2, s, n);
-      }
-    return;
+        for (int j = 0; j < 3; j++) Ji[3 * i + j] += div_shared(cc[j] * tt[i], s, rb);
+      return true;
+    }
   }
-#endif
   Ji[0] += c0 * (r0 + x0) / s; Ji[1] += c1 * (r0 + x0) / s; Ji[2] += c2 * (r0 + x0) / s;
   Ji[3] += c0 * (r1 + x1) / s; Ji[4] += c1 * (r1 + x1) / s; Ji[5] += c2 * (r1 + x1) / s;
   Ji[6] += c0 * (r2 + x2) / s; Ji[7] += c1 * (r2 + x2) / s; Ji[8] += c2 * (r2 + x2) / s;
+  return false;
+}
+__device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float x2, float g0, float g1, float g2) {
+  (void)jinv_update_impl<IA_SHARED_RCP != 0>(Ji, x0, x1, x2, g0, g1, g2);
 }
 
 
@@ -980,6 +994,9 @@ __device__ __forceinline__ void jinv_update(float *Ji, float x0, float x1, float
 #define IA_SEARCH_ATTR
 #endif
 
+#ifndef IA_SEARCH_T_LDS
+#define IA_SEARCH_T_LDS 0      // the solve's target x_d: 1 = re-read from LDS at every step (106 VGPRs, 197.7 us), 0 = three registers (108, 196.5 us)
+#endif
 #ifndef IA_REFILL_GROUP
 // lanes refilled together; measured r02 (k_search per launch, frames/s with two frames in flight): 1: 196 us / 485,
 // 2: 220 / 455, 4: 234 / 440, 8: 228 / 444 -- waiting for whole quads idles more lanes than the shared L1 look-ups save
@@ -1225,9 +1242,12 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   // `solves` counts the queued (non-trivial) ones; `fetches` every trilinear fetch of the reference's algorithm, `loaded` those
   // that touched memory (a fetch with all 8 corners outside the grid is zero by construction and loads nothing)
   // (packed: registers are what bounds the waves per SIMD here -- `counts` = fetches | loaded << 16, a lane sees at most
-  // 13 * NP * 11 < 2^16 fetches per launch; `it_solves` = iter | solves << 8; the target x_d is re-read from LDS where it is used)
+  // 13 * NP * 11 < 2^16 fetches per launch; `it_solves` = iter | solves << 8; IA_SEARCH_T_LDS: the target x_d re-read from LDS)
   int item = 0;
   uint32_t counts = 0, it_solves = 0;
+#if !IA_SEARCH_T_LDS
+  float t0 = 0, t1 = 0, t2 = 0;
+#endif
   float xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
   float Ji[9];
 #pragma unroll
@@ -1253,7 +1273,11 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
         if (!active && my < n_live) {
           item = s_list[my];
           const int init = item >> 7, pt = item & (NP - 1);
+#if IA_SEARCH_T_LDS
           const float t0 = s_xd[pt][0], t1 = s_xd[pt][1], t2 = s_xd[pt][2];
+#else
+          t0 = s_xd[pt][0]; t1 = s_xd[pt][1]; t2 = s_xd[pt][2];
+#endif
           const float *T = s_T[init];
           // :287-293  x0 = R^T (xd - t)
           const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
@@ -1278,8 +1302,10 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     if (active) {
       counts += ld ? 0x10001u : 1u;
       bool done = false, ok = false;
+#if IA_SEARCH_T_LDS
       const float *txd = s_xd[item & (NP - 1)];
       const float t0 = txd[0], t1 = txd[1], t2 = txd[2];
+#endif
       // residual g(x) = J x + d - x_d at the current point (:325-332 initial, :356-367 updated)
       const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
       const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
@@ -1711,6 +1737,51 @@ extern "C" int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *
   IA_CHECK_ARG(n_cand, "ia_snarf_implicit_bwd_compact: n_cand is null");
   return ia_implicit_bwd_impl("ia_snarf_implicit_bwd_compact", cand_xc, cand_Jinv, nullptr, grad_xc, cap, n_cand, voxel_w,
                               grid, d_tfs, ws, ws_bytes, (hipStream_t)stream, channel_last != 0);
+}
+
+// ---- device self-tests of the shared-reciprocal division (called by tests/ only; they launch the SAME device functions
+// k_search uses) ----
+__global__ void k_selftest_shared_rcp(const float *__restrict__ num, const float *__restrict__ den, int n,
+                                      float *__restrict__ q_shared, float *__restrict__ q_ieee) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = num[i], b = den[i];
+  q_shared[i] = div_shared(a, b, rcp_refined(b));
+  q_ieee[i] = a / b;
+}
+__global__ void k_selftest_jinv_update(const float *__restrict__ Ji, const float *__restrict__ x, const float *__restrict__ g, int n,
+                                       float *__restrict__ out_shared, float *__restrict__ out_plain, uint8_t *__restrict__ took_shared) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // n is a multiple of the wave size: whole waves run the update
+  if (i >= n) return;
+  float A[9], B[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { A[k] = Ji[(size_t)i * 9 + k]; B[k] = A[k]; }
+  const bool sh = jinv_update_impl<true>(A, x[i * 3], x[i * 3 + 1], x[i * 3 + 2], g[i * 3], g[i * 3 + 1], g[i * 3 + 2]);
+  (void)jinv_update_impl<false>(B, x[i * 3], x[i * 3 + 1], x[i * 3 + 2], g[i * 3], g[i * 3 + 1], g[i * 3 + 2]);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { out_shared[(size_t)i * 9 + k] = A[k]; out_plain[(size_t)i * 9 + k] = B[k]; }
+  took_shared[i] = sh;
+}
+// q_shared[i] = the shared-reciprocal quotient num[i] / den[i], q_ieee[i] = the compiler's division (device pointers)
+extern "C" int ia_selftest_shared_rcp(const float *num, const float *den, int n, float *q_shared, float *q_ieee, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  IA_CHECK_ARG(n >= 0 && (n == 0 || (num && den && q_shared && q_ieee)), "ia_selftest_shared_rcp: bad arguments");
+  if (n == 0) return IA_OK;
+  hipLaunchKernelGGL(k_selftest_shared_rcp, dim3((n + 255) / 256), dim3(256), 0, stream, num, den, n, q_shared, q_ieee);
+  IA_LAUNCH_CHECK("ia_selftest_shared_rcp");
+  return IA_OK;
+}
+// the Broyden rank-1 update of n J_inv matrices [n][9] with steps x [n][3] and residual differences g [n][3], once with the
+// shared reciprocal (as k_search runs it: per wave, only when all 64 lanes are in range -> took_shared[i]) and once with the
+// compiler's divisions; n must be a multiple of 64
+extern "C" int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int n, float *out_shared, float *out_plain,
+                                       uint8_t *took_shared, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  IA_CHECK_ARG(n >= 0 && n % 64 == 0 && (n == 0 || (Ji && x && g && out_shared && out_plain && took_shared)), "ia_selftest_jinv_update: bad arguments (n % 64 == 0)");
+  if (n == 0) return IA_OK;
+  hipLaunchKernelGGL(k_selftest_jinv_update, dim3(n / 256 + 1), dim3(256), 0, stream, Ji, x, g, n, out_shared, out_plain, took_shared);
+  IA_LAUNCH_CHECK("ia_selftest_jinv_update");
+  return IA_OK;
 }
 
 // Resource usage of the search kernel as compiled into THIS library (bench.py reports it next to the counters instead

@@ -894,6 +894,11 @@ def test_round3_entry_points_validate_arguments_before_any_launch():
     u = (C.c_uint64 * 3)()
     assert L.ia_profile_get_units(7, u, 3) != 0 and L.ia_profile_get_units(0, u, 9) != 0
     assert L.ia_profile_get_units(0, u, 3) == 0 and list(u) == [0, 0, 0]                                           # profiling never enabled
+    # device self-tests of the shared-reciprocal division: null pointers / a ragged wave are refused, n = 0 is a no-op
+    assert L.ia_selftest_shared_rcp(None, None, 4, None, None, None) != 0 and b"ia_selftest_shared_rcp" in L.ia_last_error()
+    assert L.ia_selftest_shared_rcp(None, None, 0, None, None, None) == 0
+    assert L.ia_selftest_jinv_update(one, one, one, 65, one, one, one, None) != 0 and b"n % 64" in L.ia_last_error()
+    assert L.ia_selftest_jinv_update(None, None, None, 0, None, None, None, None) == 0
 
 
 def test_affine_inverse_equals_torch_inverse_value_and_gradient():

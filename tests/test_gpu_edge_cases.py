@@ -224,3 +224,84 @@ def test_field_follows_centre_and_scale_changed_in_place():
         r2, s2 = fresh.net_coarse(x)
     assert not torch.equal(s0, s1)
     assert torch.equal(s1, s2) and torch.equal(r1, r2)
+
+
+def test_shared_reciprocal_division_is_the_ieee_division_in_its_range():
+    """k_search divides the nine numerators of the Broyden update (fuse_cuda_kernel_fast.cu:23-55) by their common scalar with ONE
+    reciprocal chain (`rcp_refined` / `div_shared` in ia_snarf.hip) where the reference compiles nine IEEE divisions.  Inside the
+    exponent range the kernel's guard admits -- numerators zero or in [2^-98, 2^16), denominators in [2^-67, 2^22), plus zero /
+    inf / NaN operands -- the two must agree BIT FOR BIT: swept here on the device over every exponent pair and random mantissas."""
+    L = _lib.lib()
+    rs = np.random.RandomState(0)
+
+    def mant(n):
+        m = 1.0 + rs.rand(n)
+        m[rs.rand(n) < 0.05] = 1.0                                   # exact powers of two
+        m[rs.rand(n) < 0.05] = 2.0 - 2.0 ** -23                      # all-ones mantissas
+        return m * rs.choice([-1.0, 1.0], n)
+    en, ed = np.arange(-98, 16), np.arange(-67, 22)
+    EN, ED = np.meshgrid(en, ed, indexing="ij")
+    reps = 96
+    EN, ED = np.repeat(EN.reshape(-1), reps), np.repeat(ED.reshape(-1), reps)
+    num = (mant(len(EN)) * np.exp2(EN.astype(np.float64))).astype(np.float32)
+    den = (mant(len(ED)) * np.exp2(ED.astype(np.float64))).astype(np.float32)
+    # the cases v_div_fixup decides: zero numerators of both signs, zero / inf / NaN denominators and numerators
+    special_n = np.array([0.0, -0.0, 0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1.0, 0.0, 3.5, np.inf], np.float32)
+    special_d = np.array([1.5, 2.5, -3.0, 0.0, -0.0, 2.0, 2.0, 2.0, np.inf, 0.0, np.nan, np.inf], np.float32)
+    num, den = np.concatenate([num, special_n]), np.concatenate([den, special_d])
+    n = len(num)
+    tn, td = torch.from_numpy(num).to(DEV), torch.from_numpy(den).to(DEV)
+    qs, qi = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    _lib.check(L.ia_selftest_shared_rcp(_lib.ptr(tn), _lib.ptr(td), n, _lib.ptr(qs), _lib.ptr(qi), _lib.stream()), "ia_selftest_shared_rcp")
+    torch.cuda.synchronize()
+    a, b = qs.cpu().numpy(), qi.cpu().numpy()
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan)
+    bad = (a.view(np.int32) != b.view(np.int32)) & ~nan
+    assert not bad.any(), (int(bad.sum()), num[bad][:5], den[bad][:5], a[bad][:5], b[bad][:5])
+    assert np.array_equal(b[:-12][::977], (num[:-12][::977].astype(np.float64) / den[:-12][::977]).astype(np.float32))   # and that IS num / den
+    assert n > 900000
+
+
+def test_broyden_update_with_shared_reciprocal_equals_the_update_with_nine_divisions():
+    """`jinv_update` as k_search runs it (per wave: the shared reciprocal when all 64 lanes are inside its range, the compiler's
+    divisions otherwise) against the same update with the compiler's divisions only, bit for bit: realistic magnitudes (every
+    wave takes the shared path), magnitudes swept across the edges of the range wave by wave, degenerate rows (zero step, zero
+    residual difference: s = 0 -> inf / NaN exactly as the reference produces them), and waves that one lane pushes out of range."""
+    L = _lib.lib()
+    rs = np.random.RandomState(1)
+    n_waves = 512
+    n = n_waves * 64
+    Ji = (np.linalg.qr(rs.randn(n, 3, 3))[0] * (1 + 0.2 * rs.randn(n, 1, 1)) + 0.05 * rs.randn(n, 3, 3)).reshape(n, 9).astype(np.float32)
+    x = (rs.randn(n, 3) * np.exp(rs.uniform(np.log(1e-6), np.log(1e-1), (n, 1)))).astype(np.float32)
+    g = (rs.randn(n, 3) * np.exp(rs.uniform(np.log(1e-6), np.log(1e-1), (n, 1)))).astype(np.float32)
+    wave = np.arange(n) // 64
+    # waves 128..383: everything scaled by 2^k, k from -70 to 57 twice: in range, at the edge, beyond it
+    k = np.where((wave >= 128) & (wave < 384), (wave - 128) % 128 - 70, 0)
+    x = (x * np.exp2(k)[:, None].astype(np.float64)).astype(np.float32)
+    g = (g * np.exp2(k // 2)[:, None].astype(np.float64)).astype(np.float32)
+    # waves 384..447: degenerate rows sprinkled in
+    deg = (wave >= 384) & (wave < 448)
+    x[deg & (rs.rand(n) < 0.2)] = 0.0
+    g[deg & (rs.rand(n) < 0.2)] = 0.0
+    # waves 448..: ONE lane far out of range
+    x[(wave >= 448) & (np.arange(n) % 64 == 17)] *= np.float32(2.0 ** 40)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    tJ, tx, tg = t(Ji), t(x), t(g)
+    oa, ob = torch.empty(n, 9, device=DEV), torch.empty(n, 9, device=DEV)
+    took = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    _lib.check(L.ia_selftest_jinv_update(_lib.ptr(tJ), _lib.ptr(tx), _lib.ptr(tg), n, _lib.ptr(oa), _lib.ptr(ob), _lib.ptr(took), _lib.stream()),
+               "ia_selftest_jinv_update")
+    torch.cuda.synchronize()
+    a, b, took = oa.cpu().numpy(), ob.cpu().numpy(), took.cpu().numpy().astype(bool)
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan)
+    bad = (a.view(np.int32) != b.view(np.int32)) & ~nan
+    assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:5])
+    tw = took.reshape(n_waves, 64)
+    assert (tw.all(1) | ~tw.any(1)).all()                               # a wave takes ONE path
+    assert tw[:128].all()                                               # realistic magnitudes: always the shared reciprocal
+    assert not tw[448:].any()                                           # one lane out of range: the whole wave divides
+    swept = tw[128:384, 0]
+    assert swept.any() and not swept.all()                              # the sweep crosses the edge of the range
+    assert np.isinf(b).any() or nan.any()                               # the degenerate rows really produce inf / NaN
