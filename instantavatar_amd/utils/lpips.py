@@ -12,6 +12,10 @@ buffers `scaling_layer.shift/scale`), so the reference's own weight files load u
     reference lets torchvision download it; there is no network here, so the file has to be provided).
 
 Without both files NGPLoss(w_lpips > 0) refuses to run rather than optimise against random features.
+
+`LPIPS(net="alex")` is the metric of the reference's eval.py (eval.py:13-34: torchmetrics'
+LearnedPerceptualImagePatchSimilarity(net_type="alex"), which wraps the same v0.1 network): AlexNet feature trunk
+(torchvision `alexnet().features`, relu1..relu5 = 64 / 192 / 384 / 256 / 256 channels) + `weights/v0.1/alex.pth`.
 """
 import torch
 import torch.nn as nn
@@ -67,6 +71,47 @@ class VGG16Trunk(nn.Module):
         self.load_state_dict(own, strict=True)
 
 
+# torchvision's AlexNet feature stack (indices = positions in its nn.Sequential) and the slice boundaries of the reference's
+# trunk wrapper (third_parties/lpips/pretrained_networks.py:56-95): relu1 = [0,2), relu2 = [2,5), relu3 = [5,8), [8,10), [10,12)
+_ALEX_SLICE_ENDS = (2, 5, 8, 10, 12)
+ALEX_CHANNELS = (64, 192, 384, 256, 256)
+
+
+def _alex_slices():
+    layers = [nn.Conv2d(3, 64, kernel_size=11, stride=4, padding=2), nn.ReLU(inplace=False), nn.MaxPool2d(kernel_size=3, stride=2),
+              nn.Conv2d(64, 192, kernel_size=5, padding=2), nn.ReLU(inplace=False), nn.MaxPool2d(kernel_size=3, stride=2),
+              nn.Conv2d(192, 384, kernel_size=3, padding=1), nn.ReLU(inplace=False),
+              nn.Conv2d(384, 256, kernel_size=3, padding=1), nn.ReLU(inplace=False),
+              nn.Conv2d(256, 256, kernel_size=3, padding=1), nn.ReLU(inplace=False)]
+    slices, start = [], 0
+    for end in _ALEX_SLICE_ENDS:
+        seq = nn.Sequential()
+        for i in range(start, end):
+            seq.add_module(str(i), layers[i])
+        slices.append(seq)
+        start = end
+    return slices
+
+
+class AlexTrunk(nn.Module):
+    """relu1 .. relu5 of AlexNet."""
+
+    def __init__(self):
+        super().__init__()
+        self.slice1, self.slice2, self.slice3, self.slice4, self.slice5 = _alex_slices()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        outs = []
+        for s in (self.slice1, self.slice2, self.slice3, self.slice4, self.slice5):
+            x = s(x)
+            outs.append(x)
+        return outs
+
+    load_torchvision_features = VGG16Trunk.load_torchvision_features
+
+
 class _Lin(nn.Module):
     """1x1 convolution without bias; index 1 inside `model` (index 0 is the reference's dropout, inactive in eval mode)."""
 
@@ -92,11 +137,15 @@ class _Scaling(nn.Module):
 class LPIPS(nn.Module):
     """d(x, y) = sum_l mean_hw( w_l . (f_l(x)/|f_l(x)| - f_l(y)/|f_l(y)|)^2 ), inputs NCHW in [0, 1] (normalize=True)."""
 
-    def __init__(self):
+    def __init__(self, net="vgg"):
         super().__init__()
+        if net not in ("vgg", "alex"):
+            raise ValueError("LPIPS: net must be 'vgg' (the training loss) or 'alex' (eval.py's metric), got %r" % (net,))
+        self.pnet_type = net
         self.scaling_layer = _Scaling()
-        self.net = VGG16Trunk()
-        for k, c in enumerate(CHANNELS):
+        self.net = VGG16Trunk() if net == "vgg" else AlexTrunk()
+        self.chns = CHANNELS if net == "vgg" else ALEX_CHANNELS
+        for k, c in enumerate(self.chns):
             setattr(self, "lin%d" % k, _Lin(c))
         for p in self.parameters():
             p.requires_grad = False
@@ -105,13 +154,13 @@ class LPIPS(nn.Module):
 
     @property
     def lins(self):
-        return [getattr(self, "lin%d" % k) for k in range(len(CHANNELS))]
+        return [getattr(self, "lin%d" % k) for k in range(len(self.chns))]
 
     def load_lin_weights(self, path_or_state):
         sd = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, bytes)) or hasattr(path_or_state, "__fspath__") else path_or_state
         missing = [k for k in ("lin%d.model.1.weight" % i for i in range(len(CHANNELS))) if k not in sd]
         if missing:
-            raise KeyError("LPIPS lin weights: missing %s (expected third_parties/lpips/weights/v0.1/vgg.pth)" % missing)
+            raise KeyError("LPIPS lin weights: missing %s (expected third_parties/lpips/weights/v0.1/%s.pth)" % (missing, self.pnet_type))
         self.load_state_dict({k: v for k, v in sd.items() if k.startswith("lin")}, strict=False)
         self.weights_loaded["lin"] = True
         return self

@@ -551,6 +551,35 @@ def test_lpips_module_matches_reference_golden():
     assert m2.weights_loaded == {"trunk": True, "lin": True}
 
 
+def test_lpips_alex_matches_reference_golden():
+    """utils.lpips.LPIPS(net="alex") -- the network behind eval.py's LPIPS figure -- against the REFERENCE's third_parties/lpips
+    module (net="alex", v0.1, its pretrained lin layers; formula trunk weights): parameter names, per-layer and total distances,
+    both with the [0,1] -> [-1,1] rescaling and without it (what eval.py effectively computes: torchmetrics' default
+    normalize=False on [0, 1] images)."""
+    import torch
+    from instantavatar_amd.utils.lpips import LPIPS, ALEX_CHANNELS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_alex_golden.npz"))
+    m = LPIPS(net="alex")
+    m.load_lin_weights({k.replace("__", "."): torch.as_tensor(g[k]) for k in g.files if k.startswith("lin")})
+    assert [tuple(l.model[0].weight.shape) for l in m.lins] == [(1, c, 1, 1) for c in ALEX_CHANNELS]
+    names = sorted(n for n, _ in m.net.named_parameters())
+    assert names == [str(s) for s in g["param_order"]]
+    x, y = torch.as_tensor(g["x"]), torch.as_tensor(g["y"])
+    with torch.no_grad():
+        for salt, name in enumerate(names):
+            p = dict(m.net.named_parameters())[name]
+            p.copy_(_lpips_formula_weights(tuple(p.shape), salt))
+        val, per = m(x, y, per_layer=True)
+        val_raw, per_raw = m(x, y, normalize=False, per_layer=True)
+    assert np.allclose(val.numpy(), g["val"], rtol=2e-5, atol=1e-7) and np.allclose(val_raw.numpy(), g["val_raw"], rtol=2e-5, atol=1e-7)
+    for k in range(5):
+        assert np.allclose(per[k].numpy(), g["per"][k], rtol=2e-5, atol=1e-8) and np.allclose(per_raw[k].numpy(), g["per_raw"][k], rtol=2e-5, atol=1e-8), k
+    with pytest.raises(ValueError, match="alex"):
+        LPIPS(net="squeeze")
+    with pytest.raises(KeyError, match="alex.pth"):
+        LPIPS(net="alex").load_lin_weights({})
+
+
 def test_ngp_loss_lpips_term_and_missing_weights():
     """NGPLoss with w_lpips > 0: refuses to run without weight files, and with a loaded module adds
     w_lpips * sum(LPIPS(pred[BGR], target[BGR])) on patch batches (loss.py:28-32)."""
