@@ -91,6 +91,31 @@ def build_model(args, device):
     return model, betas
 
 
+def render_sequence(model, seq, out_dir, gif="animation.gif"):
+    """animate.py:104-118 / novel_view.py:117-127: every batch of `seq` through render_image_fast (replayed from one captured
+    HIP graph), RGBA = [rgb, alpha] * 255 as 8-bit PNGs `<i>.png`, optionally a GIF of all frames.  Returns the frame count."""
+    os.makedirs(out_dir, exist_ok=True)
+    from PIL import Image
+    size = (seq.H, seq.W)
+    renderer = GraphedRenderer(model, seq.batch(0), size)
+    frames = []
+    with torch.inference_mode():
+        for i in range(len(seq)):
+            rgb, _, alpha, _ = renderer(seq.batch(i))
+            img = torch.cat([rgb, alpha[..., None]], dim=-1)[0]
+            frames.append((img.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())     # animate.py:109-113
+    renderer.finish()
+    for i in renderer.incomplete_calls:  # frames whose loop needed more iterations than the graph holds
+        rgb, _, alpha, _ = model.render_image_fast(seq.batch(i), size)
+        frames[i] = (torch.cat([rgb, alpha[..., None]], dim=-1)[0].clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
+    for i, f in enumerate(frames):
+        Image.fromarray(f, "RGBA").save(os.path.join(out_dir, "%d.png" % i))
+    if gif and frames:
+        ims = [Image.fromarray(f, "RGBA") for f in frames]
+        ims[0].save(os.path.join(out_dir, gif), save_all=True, append_images=ims[1:], duration=33, loop=0)
+    return len(frames)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--poses", help="npz with `poses` [n,>=72] and `trans` [n,3] (data/animation/aist_demo.npz)")
@@ -123,26 +148,8 @@ def main(argv=None):
     if args.max_frames:
         poses, trans = poses[:args.max_frames], trans[:args.max_frames]
     seq = AnimateSequence(poses, trans, betas, device, args.downscale)
-    os.makedirs(args.out, exist_ok=True)
-    from PIL import Image
-    size = (seq.H, seq.W)
-    renderer = GraphedRenderer(model, seq.batch(0), size)
-    frames = []
-    with torch.inference_mode():
-        for i in range(len(seq)):
-            rgb, _, alpha, _ = renderer(seq.batch(i))
-            img = torch.cat([rgb, alpha[..., None]], dim=-1)[0]
-            frames.append((img.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())     # animate.py:109-113
-    renderer.finish()
-    for i in renderer.incomplete_calls:  # frames whose loop needed more iterations than the graph holds
-        rgb, _, alpha, _ = model.render_image_fast(seq.batch(i), size)
-        frames[i] = (torch.cat([rgb, alpha[..., None]], dim=-1)[0].clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
-    for i, f in enumerate(frames):
-        Image.fromarray(f, "RGBA").save(os.path.join(args.out, "%d.png" % i))
-    if not args.no_gif and frames:
-        ims = [Image.fromarray(f, "RGBA") for f in frames]
-        ims[0].save(os.path.join(args.out, "animation.gif"), save_all=True, append_images=ims[1:], duration=33, loop=0)
-    print("wrote %d frames (%dx%d) to %s" % (len(frames), seq.W, seq.H, args.out))
+    n = render_sequence(model, seq, args.out, gif=None if args.no_gif else "animation.gif")
+    print("wrote %d frames (%dx%d) to %s" % (n, seq.W, seq.H, args.out))
     return 0
 
 

@@ -16,10 +16,12 @@ def save_checkpoint(model, path, optimizer=None, epoch=0, scheduler=None):
     return path
 
 
-def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, optimizer=None, scheduler=None):
+def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, optimizer=None, scheduler=None, skip_prefixes=()):
     """Returns (missing, unexpected).  The tcnn parameter vectors must have the tcnn-v1.6 layout this
     package restates ([MLP weights..., grid]); a size mismatch raises.  `optimizer` / `scheduler`: restored
-    from Lightning's `optimizer_states[0]` / `lr_schedulers[0]` when the checkpoint holds them (resume)."""
+    from Lightning's `optimizer_states[0]` / `lr_schedulers[0]` when the checkpoint holds them (resume).
+    `skip_prefixes`: entries whose key starts with one of them stay at the model's own values (eval.py:64-67 keeps the freshly
+    built `SMPL_param` tables of the test frames and takes everything else from the checkpoint)."""
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     net = getattr(model, "net_coarse", None)
@@ -32,6 +34,8 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
     take = {}
     unexpected = []
     for k, v in sd.items():
+        if any(k.startswith(p) for p in skip_prefixes):
+            continue
         if k in own:
             if tuple(own[k].shape) != tuple(v.shape):
                 hint = ""
@@ -46,7 +50,7 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
             take[k] = v
         else:
             unexpected.append(k)
-    missing = [k for k in own if k not in take]
+    missing = [k for k in own if k not in take and not any(k.startswith(p) for p in skip_prefixes)]
     on_path = [k for k in missing if k.startswith("net_coarse.") and k.endswith("params")]
     if strict_path_keys and on_path:
         raise KeyError("checkpoint lacks the field parameters: %s" % on_path)

@@ -23,6 +23,7 @@ class AvatarModel(torch.nn.Module):
         self.deformer = deformer
         self.renderer = renderer
         self.global_step = 0
+        self.is_refine = False      # opt.optimize_SMPL.is_refine (confs/SNARF_NGP_refine.yaml): render with the refined SMPL tables
 
     def forward(self, batch, eval_mode=True, noise=0):
         """DNeRF.py:61-70"""
@@ -33,7 +34,19 @@ class AvatarModel(torch.nn.Module):
 
     @torch.no_grad()
     def render_image_fast(self, batch, img_size, jitter=None):
-        """DNeRF.py:72-97: prepare deformer, rebuild the test occupancy grid, render."""
+        """DNeRF.py:72-97: (refinement: the frame's SMPL parameters come from the optimised tables, near / far follow the
+        refined translation -- :73-86), prepare deformer, rebuild the test occupancy grid, render."""
+        if getattr(self, "SMPL_param", None) is not None and self.is_refine:
+            idx = batch["idx_dev"] if torch.is_tensor(batch.get("idx_dev")) else batch["idx"].reshape(-1).long().to(batch["transl"].device)
+            body_params = self.SMPL_param(idx.reshape(-1).long())
+            for k in ("global_orient", "body_pose", "transl"):
+                assert batch[k].shape == body_params[k].shape, (k, batch[k].shape, body_params[k].shape)
+                batch[k] = body_params[k]
+            if type(self.deformer).__name__ == "SMPLDeformer":
+                batch["betas"] = body_params["betas"]
+            dist = torch.norm(batch["transl"], dim=-1, keepdim=True).detach()
+            batch["near"][:] = dist - 1
+            batch["far"][:] = dist + 1
         self.deformer.prepare_deformer(batch)
         self.renderer.density_grid_test.initialize(self.deformer, self.net_coarse, jitter=jitter)
         d = self.forward(batch, eval_mode=True)

@@ -801,6 +801,126 @@ def test_animate_sequence_matches_reference_animate_dataset_golden():
             assert np.array_equal(a, r) or np.abs(a - r).max() <= 1.2e-7 * max(1.0, np.abs(r).max()), (int(f), k, np.abs(a - r).max())
 
 
+def test_rotation_sequence_matches_reference_novel_view_dataset_golden():
+    """drivers.novel_view.RotationSequence (camera, the fixed pose, the turn about y composed with the body orientation and
+    converted back to a rotation vector) against the REFERENCE's novel_view.py AnimateDataset executing on the CPU
+    (tests/golden/make_novel_view_golden.py; its cv2.Rodrigues is a scipy stand-in).  Orientations are compared as rotation
+    matrices: every frame is a rotation by exactly pi, where +-pi k are the same rotation."""
+    from instantavatar_amd.drivers.novel_view import RotationSequence, rotvec_to_matrix
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "novel_view_golden.npz"))
+    n = int(g["n"])
+    seq = RotationSequence(n, g["betas"], "cpu", downscale=16)
+    assert (seq.H, seq.W) == (int(g["H"]), int(g["W"])) and len(seq) == n
+    b = seq.batch(0)
+    for k in ("rays_o", "rays_d", "betas", "body_pose", "transl", "near", "far"):
+        a, r = b[k][0].numpy(), g["f0_" + k]
+        assert a.shape == r.shape, (k, a.shape, r.shape)
+        assert np.array_equal(a, r) or np.abs(a - r).max() <= 1.2e-7 * max(1.0, np.abs(r).max()), (k, np.abs(a - r).max())
+    for f in range(n):
+        a, r = seq.batch(f)["global_orient"][0].numpy(), g["f%d_global_orient" % f]
+        assert a.shape == r.shape == (3,) and a.dtype == np.float32
+        assert abs(np.linalg.norm(a) - np.pi) < 1e-6                                        # R_y(angle) R_x(pi) always turns by pi
+        assert np.abs(rotvec_to_matrix(a) - rotvec_to_matrix(r)).max() < 2e-6, (f, a, r)
+
+
+def test_rodrigues_conversions_against_scipy():
+    """drivers.novel_view.rotvec_to_matrix / matrix_to_rotvec (the package's stand-in for cv2.Rodrigues) against
+    scipy.spatial.transform.Rotation over random rotations, small angles and the neighbourhood of pi."""
+    from scipy.spatial.transform import Rotation
+    from instantavatar_amd.drivers.novel_view import matrix_to_rotvec, rotvec_to_matrix
+    rs = np.random.RandomState(3)
+    for th in list(rs.uniform(0, np.pi, 200)) + [0.0, 1e-9, 1e-4, np.pi - 1e-4, np.pi - 1e-7, np.pi]:
+        k = rs.randn(3)
+        v = k / np.linalg.norm(k) * th
+        R = rotvec_to_matrix(v)
+        assert np.abs(R - Rotation.from_rotvec(v).as_matrix()).max() < 1e-12
+        w = matrix_to_rotvec(R)
+        assert np.abs(rotvec_to_matrix(w) - R).max() < 1e-7 and np.linalg.norm(w) <= np.pi + 1e-9
+        if th < np.pi - 1e-3:
+            assert np.abs(w - v).max() < 1e-7, (th, v, w)
+
+
+def test_eval_metrics_psnr_ssim_and_evaluator():
+    """utils.metrics (the figures of eval.py's Evaluator): PSNR against its definition, SSIM against an independent
+    scipy implementation of Wang et al. 2004 with the window torchmetrics uses (11 x 11 Gaussian, sigma 1.5, reflect
+    padding, border cropped), the Evaluator's clamp / layout handling, and LPIPS going in WITHOUT the [-1, 1] rescaling."""
+    from scipy.ndimage import correlate1d
+    from instantavatar_amd.utils.lpips import LPIPS
+    from instantavatar_amd.utils.metrics import Evaluator, psnr, ssim
+    rs = np.random.RandomState(0)
+    x = rs.rand(2, 3, 40, 52)
+    y = np.clip(x + 0.1 * rs.randn(2, 3, 40, 52), 0, 1)
+
+    def ssim_np(x, y):
+        d = np.arange(-5, 6)
+        g = np.exp(-(d / 1.5) ** 2 / 2)
+        g /= g.sum()
+        f = lambda a: correlate1d(correlate1d(a, g, axis=-1, mode="mirror"), g, axis=-2, mode="mirror")
+        mx, my = f(x), f(y)
+        sxx, syy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        m = ((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))
+        return m[..., 5:-5, 5:-5].reshape(len(x), -1).mean(-1).mean()
+    assert abs(float(ssim(torch.tensor(x), torch.tensor(y))) - ssim_np(x, y)) < 1e-12
+    assert abs(float(ssim(torch.tensor(x, dtype=torch.float32), torch.tensor(y, dtype=torch.float32))) - ssim_np(x, y)) < 2e-6
+    assert float(ssim(torch.tensor(x), torch.tensor(x))) == 1.0
+    assert abs(float(psnr(torch.tensor(x), torch.tensor(y))) - 10 * np.log10(1.0 / ((x - y) ** 2).mean())) < 1e-9
+    assert abs(float(psnr(torch.tensor(x) * 255, torch.tensor(y) * 255, data_range=255.0)) - float(psnr(torch.tensor(x), torch.tensor(y)))) < 1e-9
+    with pytest.raises(ValueError, match="NCHW"):
+        ssim(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8))
+    # Evaluator: NHWC in, prediction clamped to <= 1, no LPIPS entry without a loaded network, a network without weights refused
+    pred = torch.tensor(np.transpose(y, (0, 2, 3, 1)), dtype=torch.float32) * 1.2
+    gt = torch.tensor(np.transpose(x, (0, 2, 3, 1)), dtype=torch.float32)
+    out = Evaluator()(pred, gt)
+    assert set(out) == {"psnr", "ssim"}
+    pc = pred.clamp(max=1.0).permute(0, 3, 1, 2)
+    assert abs(float(out["psnr"]) - float(psnr(pc, gt.permute(0, 3, 1, 2)))) < 1e-5 and abs(float(out["ssim"]) - float(ssim(pc, gt.permute(0, 3, 1, 2)))) < 1e-6
+    with pytest.raises(ValueError, match="pretrained"):
+        Evaluator(lpips=LPIPS(net="alex"))
+    lp = LPIPS(net="alex")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_alex_golden.npz"))
+    lp.load_lin_weights({k.replace("__", "."): torch.as_tensor(g[k]) for k in g.files if k.startswith("lin")})
+    with torch.no_grad():
+        for salt, name in enumerate(sorted(n for n, _ in lp.net.named_parameters())):
+            p = dict(lp.net.named_parameters())[name]
+            p.copy_(_lpips_formula_weights(tuple(p.shape), salt))
+    lp.weights_loaded["trunk"] = True
+    gx, gy = torch.as_tensor(g["x"]).permute(0, 2, 3, 1), torch.as_tensor(g["y"]).permute(0, 2, 3, 1)
+    out = Evaluator(lpips=lp)(gx, gy)
+    assert abs(float(out["lpips"]) - float(g["val_raw"].mean())) < 2e-6            # normalize=False, mean over the batch
+
+
+def test_test_image_round_trip_is_cv2_imwrite_then_imread_bgr2rgb(tmp_path):
+    """evaluation.write_png_bgr / read_png_as_rgb / evaluate_folder: the file holds the panel's channels reversed and rounded
+    half-to-even (cv2.imwrite of a float image), reading it back returns the reversed 8-bit array / 255 (cv2.imread +
+    BGR2RGB), and the folder's metrics are prediction (middle third) against ground truth (left third); the JET table has
+    OpenCV's end points and ramps."""
+    from PIL import Image
+    from instantavatar_amd import evaluation as ev
+    from instantavatar_amd.utils.metrics import Evaluator, psnr
+    rs = np.random.RandomState(5)
+    H, W = 24, 20
+    gt, pred = rs.rand(H, W, 3).astype(np.float32), rs.rand(H, W, 3).astype(np.float32)
+    err = rs.rand(H, W, 3).astype(np.float32)
+    panel = torch.tensor(np.concatenate([gt, pred, err], 1))
+    ev.write_png_bgr(str(tmp_path / "0.png"), panel)
+    raw = np.asarray(Image.open(str(tmp_path / "0.png")))
+    want = np.clip(np.rint(panel.numpy() * np.float32(255)), 0, 255).astype(np.uint8)          # fp32 product, as the reference forms it
+    assert raw.shape == (H, 3 * W, 3) and np.array_equal(raw, want[..., ::-1])
+    assert ev.to_u8(torch.tensor([0.5, 1.5, 2.5, 254.5, 255.5, -0.5, 300.0])).tolist() == [0, 2, 2, 254, 255, 0, 255]   # ties to even, saturation
+    back = ev.read_png_as_rgb(str(tmp_path / "0.png"))
+    assert np.array_equal(back.numpy(), want[..., ::-1].astype(np.float32) / 255)
+    ev.write_png_bgr(str(tmp_path / "1.png"), panel.flip(0))
+    res, n = ev.evaluate_folder(str(tmp_path), Evaluator(), "cpu")
+    q = lambda a: torch.tensor(np.rint(a * np.float32(255)) / 255)
+    assert n == 2 and abs(res["psnr"] - float(psnr(q(pred), q(gt)))) < 1e-4
+    ev.write_results(str(tmp_path / "results.txt"), res)
+    assert open(str(tmp_path / "results.txt")).read().splitlines() == ["PSNR: %.2f" % res["psnr"], "SSIM: %.4f" % res["ssim"]]
+    lut = ev.jet_bgr(torch.arange(256, dtype=torch.uint8)).numpy()
+    assert list(lut[0]) == [128, 0, 0] and list(lut[255]) == [0, 0, 128]                  # dark blue ... dark red, B G R order
+    assert list(lut[51]) == [255, 77, 0] and list(lut[204]) == [0, 76, 255] and lut[:, 1].max() == 255 and int(lut[:, 1].argmax()) in range(96, 160)
+
+
 def test_losses_match_reference_loss_py_golden():
     """training.NeRFLoss / NGPLoss (torch formulation, fused=False: what the fused HIP kernel is tested against on the GPU)
     against the REFERENCE's utils/loss.py executing on the CPU (tests/golden/make_loss_golden.py): every reported value and
