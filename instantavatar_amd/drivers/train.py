@@ -1,8 +1,8 @@
 """`train.py` without Lightning / Hydra, for the part of it that lies on the hot path: the optimisation
 loop of DNeRFModel.training_step (DNeRF.py:112-161) over per-frame ray batches, with Lightning-layout
-checkpoints.  Real datasets (image loading, patch / edge samplers: SURVEY.md 8f rank 4) are not part
-of this package; the loop takes any iterable of batches with the reference's keys (`rays_o`, `rays_d`,
-`near`, `far`, `rgb`, `alpha`, `bg_color`, SMPL parameters).  `--synthetic` supplies one: targets rendered
+checkpoints, followed by one validation_step (DNeRF.py:171-188).  Image files are not read by this package (the samplers
+and `__getitem__` run on device-resident frames: datasets.DeviceFrames); the loop takes any iterable of batches with the
+reference's keys (`rays_o`, `rays_d`, `near`, `far`, `rgb`, `alpha`, `bg_color`, SMPL parameters).  `--synthetic` supplies one: targets rendered
 from the synthetic field, 4 096 random rays of a random frame per step (what bench.py times).
 
     python -m instantavatar_amd.drivers.train --synthetic --steps 200 --ckpt /tmp/avatar/last.ckpt
@@ -41,6 +41,16 @@ def synthetic_batches(device, teacher, res=256, n_frames=8, n_rays=4096, seed=12
         batch["bg_color"] = torch.ones_like(batch["rgb"])
         yield batch
         i += 1
+
+
+def synthetic_val_batch(device, teacher, res=256, frame=0):
+    """A whole frame with its target image: what the "val" split's __getitem__ yields (peoplesnapshot.py:112-125)."""
+    poses, tr = synthetic.procedural_pose_track(8)
+    b = make_batch(device, res, poses[frame], tr[frame])
+    with torch.no_grad():
+        rgb, _, alpha, _ = teacher.render_image_fast(dict(b), (res, res))
+    b["rgb"], b["alpha"] = rgb.reshape(1, -1, 3), alpha.reshape(1, -1)
+    return b
 
 
 def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout, scheduler=None,
@@ -96,6 +106,10 @@ def main(argv=None):
         print("resumed from %s at step %d (lr %.2e)" % (args.ckpt, model.global_step, float(opt.param_groups[0]["lr"])))
     losses, opt, sched = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps, optimizer=opt, scheduler=sched,
                              steps_per_epoch=args.steps_per_epoch, max_epochs=args.max_epochs)
+    from ..evaluation import validation_step
+    model.eval()
+    val = validation_step(model, synthetic_val_batch(device, teacher, res=args.res), (args.res, args.res))     # DNeRF.py:171-188
+    print("val/rgb_loss %.6f  val/counter_avg %.2f  val/counter_max %.0f" % (float(val["rgb_loss"]), float(val["counter_avg"]), float(val["counter_max"])))
     os.makedirs(os.path.dirname(os.path.abspath(args.ckpt)), exist_ok=True)
     ckpt_io.save_checkpoint(model, args.ckpt, optimizer=opt, scheduler=sched, epoch=sched.last_epoch)
     print("saved %s (step %d, mse %.5f)" % (args.ckpt, model.global_step, float(losses["mse_loss"])))
