@@ -86,8 +86,11 @@ class _FieldFn(torch.autograd.Function):
             state = net._grad_scale_state = torch.zeros(2, dtype=torch.int32, device=xc.device)
         _lib.check(L.ia_field_grad_scale(_lib.ptr(rgb), _lib.ptr(d_rgb), _lib.ptr(d_sigma), V, _lib.ptr(ctx.n_dev), _lib.ptr(state),
                                          _lib.ptr(S), _lib.stream()), "ia_field_grad_scale")
-        g_enc = _grad_buffer(net.encoder.params)
-        g_col = _grad_buffer(net.color_net.params)
+        # a frozen parameter vector (requires_grad False: eval.py:70-73 freezes the field and optimises the SMPL tables only)
+        # keeps `.grad` None, as autograd would leave it -- the kernels still need somewhere to accumulate: a scratch buffer
+        enc_live, col_live = net.encoder.params.requires_grad, net.color_net.params.requires_grad
+        g_enc = _grad_buffer(net.encoder.params) if enc_live else _scratch_grad(net, "enc", net.encoder.params)
+        g_col = _grad_buffer(net.color_net.params) if col_live else _scratch_grad(net, "col", net.color_net.params)
         n1 = net.sig_w1_size
         if FUSED_MLP_BACKWARD:
             dfeat = torch.empty((V, nf), device=xc.device)
@@ -105,7 +108,7 @@ class _FieldFn(torch.autograd.Function):
         from . import parallel
         red = parallel.current_reducer()
         last = red is not None and red.active and red.field_backward_done()  # last field call of this step's graph?
-        if last and dx is None and not FLAT_ALLREDUCE:
+        if last and dx is None and not FLAT_ALLREDUCE and enc_live and col_live:
             # level groups, finest first; each finished slice of the table gradient goes to RCCL while the next
             # group is scattered.  The MLP weight gradients travel with the last (small, dense-level) bucket.
             red.reduce_async(g_col)
@@ -119,6 +122,16 @@ class _FieldFn(torch.autograd.Function):
                                          _lib.ptr(dfeat), dtable.data_ptr(), _lib.ptr(dx), _lib.stream()),
                        "ia_hashgrid_bwd")
         return dx, None, None, None, None
+
+
+def _scratch_grad(net, tag, p):
+    """Where the backward kernels accumulate for a FROZEN parameter vector: one persistent buffer per network (its address
+    is part of a captured graph), never read."""
+    buf = getattr(net, "_frozen_grad_" + tag, None)
+    if buf is None or buf.shape != p.shape or buf.device != p.device:
+        buf = torch.zeros_like(p, dtype=torch.float32)
+        setattr(net, "_frozen_grad_" + tag, buf)
+    return buf
 
 
 def _grad_buffer(p):
