@@ -49,9 +49,10 @@ def synthetic_test_set(device, teacher, res, n_frames, pose_noise, transl_noise,
     return frames, true, start
 
 
-def refine_test_frames(model, frames, epochs, smpl_lr=1e-5, seed=42, log=None):
+def refine_test_frames(model, frames, epochs, smpl_lr=1e-5, seed=42, log=None, check_val_every_n_epoch=10):
     """eval.py:70-91 (`trainer.fit` on the test split with only `SMPL_param` trainable): `epochs` passes over the frames,
-    training_step with is_refine, the LR schedule stepped once per epoch.  Returns the number of steps taken."""
+    training_step with is_refine; every `check_val_every_n_epoch` epochs a validation_step on the first frame and ONE step of
+    the LR schedule (DNeRF.py:163-188; training.configure_scheduler).  Returns the number of steps taken."""
     n_train = ev.freeze_all_but_smpl(model)
     if n_train == 0:
         raise ValueError("refine_test_frames: the model has no SMPL_param tables")
@@ -67,7 +68,15 @@ def refine_test_frames(model, frames, epochs, smpl_lr=1e-5, seed=42, log=None):
         for i in torch.randperm(len(frames)).tolist():                  # DataLoader(shuffle=True) of the train split
             out = stepper(frames.batch(i, generator=g, out=stepper.inputs))
             steps += 1
-        sched.step()
+        if (epoch + 1) % check_val_every_n_epoch == 0:
+            model.eval()
+            b = frames.frame(0)
+            b["idx"] = b["idx"].to(frames.images.device)
+            val = ev.validation_step(model, b, (frames.H, frames.W))
+            model.train()
+            sched.step()
+            if log is not None:
+                print("epoch %d  val/rgb_loss %.6f  val/counter_avg %.2f" % (epoch, float(val["rgb_loss"]), float(val["counter_avg"])), file=log)
         if log is not None:
             print("epoch %d  loss %.5f  lr(SMPL) %.2e" % (epoch, float(out["loss"].detach()), float(opt.param_groups[2]["lr"])), file=log)
     model.eval()

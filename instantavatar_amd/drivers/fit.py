@@ -42,9 +42,10 @@ def build_fit_model(frames, body_model, device, threshold=0.05, n_levels=16):
 
 
 def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, loss_opt=None, log_every=50, out=sys.stdout,
-                 generator=None):
-    """The optimisation loop of fit.py (trainer.fit with SNARF_NGP_fitting.yaml: Adam lr 1e-3, SMPL tables lr 1e-4,
-    LambdaLR per epoch, one frame per step).  Returns the last losses."""
+                 generator=None, check_val_every_n_epoch=10):
+    """The optimisation loop of fit.py (trainer.fit with SNARF_NGP_fitting.yaml: Adam lr 1e-3, SMPL tables lr 1e-4, one frame
+    per step; the LambdaLR steps once per validation run = every `check_val_every_n_epoch` epochs, DNeRF.py:163-166 -- see
+    training.configure_scheduler).  Returns the last losses."""
     opt = configure_optimizer(model, lr=lr, smpl_lr=smpl_lr)
     sched = configure_scheduler(opt, max_epochs)
     loss_fn = NGPLoss(loss_opt or dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
@@ -55,7 +56,8 @@ def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, lo
     losses = None
     for it in range(steps):
         if it % n == 0 and it > 0:
-            sched.step()
+            if (it // n) % check_val_every_n_epoch == 0:
+                sched.step()
             order = torch.randperm(n, generator=generator).tolist()   # DataLoader(shuffle=True)
         losses = training_step(model, frames.batch(order[it % n]), opt, loss_fn)
         if log_every and (it + 1) % log_every == 0:

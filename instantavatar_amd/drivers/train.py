@@ -54,10 +54,12 @@ def synthetic_val_batch(device, teacher, res=256, frame=0):
 
 
 def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=sys.stdout, scheduler=None,
-        steps_per_epoch=None, max_epochs=None, world_size=1, graphed=True):
+        steps_per_epoch=None, max_epochs=None, world_size=1, graphed=True, check_val_every_n_epoch=10, on_validation=None):
     """`steps` iterations of training_step; returns (last losses (device tensors), optimizer, scheduler).
-    The reference steps its LambdaLR `(1 - epoch / max_epochs) ** 1.5` once per epoch (DNeRF.py:52-55, Lightning's
-    default interval): pass `steps_per_epoch` (= frames of the sequence) and `max_epochs` to get the same decay.
+    The reference steps its LambdaLR `(1 - k / max_epochs) ** 1.5` in `on_validation_epoch_end` (DNeRF.py:163-166; manual
+    optimisation, so Lightning does not step it): once per validation run, every `check_val_every_n_epoch` epochs.  Pass
+    `steps_per_epoch` (= frames of the sequence) and `max_epochs` to get the same decay; `on_validation(model)` is called at
+    those epochs before the scheduler steps (validation_step, DNeRF.py:171-188).
     graphed: on one rank the step is replayed from a captured HIP graph (training.GraphedTrainStep; it runs the
     occupancy-update steps eagerly and falls back to eager steps altogether when capture is not possible)."""
     optimizer = optimizer or configure_optimizer(model)
@@ -70,8 +72,12 @@ def fit(model, batches, steps, optimizer=None, loss_fn=None, log_every=50, out=s
     step = GraphedTrainStep(model, optimizer, loss_fn, world_size=world_size, enabled=graphed)
     for it, batch in zip(range(steps), batches):
         losses = step(batch)
-        if scheduler is not None and steps_per_epoch and model.global_step % steps_per_epoch == 0:
-            scheduler.step()
+        if steps_per_epoch and model.global_step % steps_per_epoch == 0 and (model.global_step // steps_per_epoch) % check_val_every_n_epoch == 0:
+            if on_validation is not None:
+                on_validation(model)
+                model.train()
+            if scheduler is not None:
+                scheduler.step()
         if log_every and (it + 1) % log_every == 0:
             torch.cuda.synchronize()
             print("step %d  loss %.5f  mse %.5f  lr %.2e  %.0f it/s" % (
@@ -88,8 +94,10 @@ def main(argv=None):
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--ckpt", default="checkpoints/last.ckpt")
     ap.add_argument("--resume", action="store_true")
-    ap.add_argument("--steps-per-epoch", type=int, default=8, help="frames per epoch (LR decays once per epoch)")
-    ap.add_argument("--max-epochs", type=int, default=200, help="confs/SNARF_NGP.yaml scheduler.max_epochs")
+    ap.add_argument("--steps-per-epoch", type=int, default=8, help="frames per epoch")
+    ap.add_argument("--max-epochs", type=int, default=30, help="confs/SNARF_NGP.yaml train.max_epochs (= scheduler.max_epochs)")
+    ap.add_argument("--check-val-every-n-epoch", type=int, default=10,
+                    help="confs/SNARF_NGP.yaml train.check_val_every_n_epoch: a validation_step and ONE step of the LR schedule every that many epochs")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("train: needs a GPU (the product path has no CPU fallback)")
@@ -104,12 +112,18 @@ def main(argv=None):
         # continues the interrupted one instead of restarting Adam from zero moments
         ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, optimizer=opt, scheduler=sched)
         print("resumed from %s at step %d (lr %.2e)" % (args.ckpt, model.global_step, float(opt.param_groups[0]["lr"])))
-    losses, opt, sched = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps, optimizer=opt, scheduler=sched,
-                             steps_per_epoch=args.steps_per_epoch, max_epochs=args.max_epochs)
     from ..evaluation import validation_step
-    model.eval()
-    val = validation_step(model, synthetic_val_batch(device, teacher, res=args.res), (args.res, args.res))     # DNeRF.py:171-188
-    print("val/rgb_loss %.6f  val/counter_avg %.2f  val/counter_max %.0f" % (float(val["rgb_loss"]), float(val["counter_avg"]), float(val["counter_max"])))
+    val_batch = synthetic_val_batch(device, teacher, res=args.res)
+
+    def validate(m):
+        m.eval()
+        val = validation_step(m, dict(val_batch), (args.res, args.res))                                    # DNeRF.py:171-188
+        print("step %d  val/rgb_loss %.6f  val/counter_avg %.2f  val/counter_max %.0f" % (m.global_step, float(val["rgb_loss"]), float(val["counter_avg"]),
+                                                                                        float(val["counter_max"])))
+    losses, opt, sched = fit(model, synthetic_batches(device, teacher, res=args.res), args.steps, optimizer=opt, scheduler=sched,
+                             steps_per_epoch=args.steps_per_epoch, max_epochs=args.max_epochs,
+                             check_val_every_n_epoch=args.check_val_every_n_epoch, on_validation=validate)
+    validate(model)
     os.makedirs(os.path.dirname(os.path.abspath(args.ckpt)), exist_ok=True)
     ckpt_io.save_checkpoint(model, args.ckpt, optimizer=opt, scheduler=sched, epoch=sched.last_epoch)
     print("saved %s (step %d, mse %.5f)" % (args.ckpt, model.global_step, float(losses["mse_loss"])))

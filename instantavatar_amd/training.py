@@ -341,8 +341,12 @@ def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=5e
 
 
 def configure_scheduler(optimizer, max_epochs):
-    """DNeRF.py:52-55: LambdaLR(lambda epoch: (1 - epoch / max_epochs) ** 1.5), stepped once per EPOCH
-    (Lightning's default interval); `fit` in drivers/train.py calls `.step()` every `steps_per_epoch`."""
+    """DNeRF.py:52-55: LambdaLR(lambda k: (1 - k / max_epochs) ** 1.5).  WHEN it is stepped: the reference optimises manually
+    (`automatic_optimization = False`, DNeRF.py:20), so Lightning never steps the scheduler itself; the only call is
+    `on_validation_epoch_end` (DNeRF.py:163-166) -- once per VALIDATION run, i.e. every `check_val_every_n_epoch` (10 in every
+    shipped config) epochs, and k counts validation runs, not epochs.  With SNARF_NGP.yaml (30 epochs) the learning rate ends
+    at (1 - 3/30)^1.5 = 0.85 of its start.  The drivers (`drivers/train.fit`, `drivers/fit.fit_sequence`, `drivers/eval`) step
+    it at exactly those epochs."""
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda epoch: (1 - min(epoch, max_epochs) / max_epochs) ** 1.5)
 
 

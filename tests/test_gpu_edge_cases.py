@@ -235,7 +235,8 @@ def test_train_driver_checkpoint_feeds_animate_driver(tmp_path):
     st = sd["optimizer_states"][0]["state"]
     assert all(float(v["step"]) == 60 for v in st.values()) and "lr_schedulers" in sd
     m0 = {k: v["exp_avg"].clone() for k, v in st.items()}
-    assert train.main(["--synthetic", "--steps", "8", "--res", "128", "--ckpt", ckpt, "--resume", "--steps-per-epoch", "4"]) == 0
+    assert train.main(["--synthetic", "--steps", "8", "--res", "128", "--ckpt", ckpt, "--resume", "--steps-per-epoch", "4",
+                       "--check-val-every-n-epoch", "1"]) == 0      # a validation run (and with it ONE scheduler step) after each of the 2 epochs
     sd2 = torch.load(ckpt, weights_only=False)
     assert sd2["global_step"] == 68
     st2 = sd2["optimizer_states"][0]["state"]
