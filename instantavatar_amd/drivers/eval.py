@@ -102,6 +102,7 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--epochs", type=int, default=20, help="confs/SNARF_NGP_refine.yaml train.max_epochs")
+    ap.add_argument("--check-val-every-n-epoch", type=int, default=10, help="confs/SNARF_NGP_refine.yaml train.check_val_every_n_epoch")
     ap.add_argument("--smpl-lr", type=float, default=1e-5, help="optimize_SMPL.lr")
     ap.add_argument("--pose-noise", type=float, default=0.03)
     ap.add_argument("--transl-noise", type=float, default=0.01)
@@ -122,7 +123,7 @@ def main(argv=None):
     from ..models.structures.body_model_param import SMPLParamEmbedding
     model.SMPL_param = SMPLParamEmbedding(**{k: torch.as_tensor(v.copy()) for k, v in start.items()}).to(device)
     field_before = [p.detach().clone() for n, p in model.named_parameters() if not n.startswith("SMPL_param")]
-    steps = refine_test_frames(model, frames, args.epochs, smpl_lr=args.smpl_lr, log=sys.stdout)
+    steps = refine_test_frames(model, frames, args.epochs, smpl_lr=args.smpl_lr, log=sys.stdout, check_val_every_n_epoch=args.check_val_every_n_epoch)
     frozen = all(torch.equal(a, p.detach()) for a, (n, p) in zip(field_before, ((n, p) for n, p in model.named_parameters() if not n.startswith("SMPL_param"))))
     if not frozen:
         raise RuntimeError("eval: a parameter outside SMPL_param changed during the refinement (eval.py:70-73 freezes them)")

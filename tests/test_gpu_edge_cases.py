@@ -170,8 +170,9 @@ def test_eval_driver_refines_renders_and_measures(tmp_path, capsys):
     from instantavatar_amd.drivers import eval as eval_driver
     from instantavatar_amd.utils.metrics import psnr, ssim
     out = str(tmp_path / "eval")
-    assert eval_driver.main(["--synthetic", "--frames", "3", "--res", "96", "--epochs", "2", "--out", out]) == 0
+    assert eval_driver.main(["--synthetic", "--frames", "3", "--res", "96", "--epochs", "2", "--check-val-every-n-epoch", "2", "--out", out]) == 0
     text = capsys.readouterr().out
+    assert text.count("val/rgb_loss") == 1 and "epoch 1  val/rgb_loss" in text          # one validation run (and scheduler step), after the 2nd epoch
     assert "refined 3 frames in 6 steps (field parameters untouched)" in text and "LPIPS: --" in text     # (the driver raises if the tables stay put)
     files = sorted(os.listdir(os.path.join(out, "test")))
     assert files == ["0.png", "1.png", "2.png"]
