@@ -607,6 +607,9 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
 #ifndef IA_QUAD_LDS_DELIVER
 #define IA_QUAD_LDS_DELIVER 2
 #endif
+#ifndef IA_QUAD_HALF_ROUNDS
+#define IA_QUAD_HALF_ROUNDS 0
+#endif
 #if IA_QUAD_LDS_DELIVER >= 2
 // Round R, lane k serves pair 4R + k = (target (4R + k) / 3, row (4R + k) % 3): the source lane of every DPP read is a per-lane
 // constant of the round -- quad_perm [0,0,0,1], [1,1,2,2], [2,3,3,3] -- and the row lands in float4 number 4R + k of the quad's
@@ -623,12 +626,38 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
   constexpr int PERM = R == 0 ? 0x40 : (R == 1 ? 0xA5 : 0xFE);
   const uint32_t load = quad_perm<PERM>(p.load);
   if (__ballot(load != 0) == 0) return;
+  const uint32_t koff = (uint32_t)(((threadIdx.x & 3) + R) % 3) * 16u;   // row (4R + k) % 3 = (k + R) % 3
+#if IA_QUAD_HALF_ROUNDS
+  // (four loads in flight per half round, offsets and weights broadcast just in time: 92 VGPRs, a fifth wave per SIMD without
+  // spills -- MEASURED 202.8 us against 196.5 us for whole rounds at four waves: occupancy is not what this kernel lacks.  OFF.)
+  typedef float f2h __attribute__((ext_vector_type(2)));
+  f2h h0 = (f2h){0.f, 0.f}, h1 = (f2h){0.f, 0.f};
+#pragma unroll
+  for (int c0 = 0; c0 < 8; c0 += 4) {
+    uint32_t off4[4];
+    float w4[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { off4[c] = quad_perm<PERM>(p.off[c0 + c]); w4[c] = quad_perm<PERM>(p.w[c0 + c]); }
+    if (load != 0) {
+      float4 v4[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) v4[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(off4[c] + koff));
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const f2h w2 = (f2h){w4[c], w4[c]};
+        h0 = __builtin_elementwise_fma((f2h){v4[c].x, v4[c].y}, w2, h0);
+        h1 = __builtin_elementwise_fma((f2h){v4[c].z, v4[c].w}, w2, h1);
+      }
+    }
+  }
+  if (load != 0) s_quad_k[4 * R] = make_float4(h0.x, h0.y, h1.x, h1.y);
+  return;
+#endif
   // (all DPP reads before the divergent part: a source lane that sits out this round must still be enabled when it is read)
   uint32_t off[8];
   float w[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) { off[c] = quad_perm<PERM>(p.off[c]); w[c] = quad_perm<PERM>(p.w[c]); }
-  const uint32_t koff = (uint32_t)(((threadIdx.x & 3) + R) % 3) * 16u;   // row (4R + k) % 3 = (k + R) % 3
   if (load != 0) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 v[8];
