@@ -563,16 +563,32 @@ struct FetchPlan {
   float w[8];
   uint32_t load;   // 1: the lane is active and at least one corner lies inside the grid
 };
+#ifndef IA_PLAN_FACTOR_ZERO
+#define IA_PLAN_FACTOR_ZERO 0
+#endif
 __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, float gy, float gz, bool active, FetchPlan &p) {
   const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
   const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
   const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
   const float fx1 = x1 - ix, fx0 = ix - x0, fy1 = y1 - iy, fy0 = iy - y0, fz1 = z1 - iz, fz0 = iz - z0;
+#if IA_PLAN_FACTOR_ZERO
+  // (prepared for round 4, NOT measured and not yet run through the parity tests: validity folded into the six 1-D factors --
+  // one unsigned compare and one select per axis end instead of two compares per end, three-way ANDs and eight selects on the
+  // products.  A zeroed factor makes its four products exactly +0: the factors are finite and non-negative (src_index maps
+  // NaN / huge coordinates to -100), and the multiplication order of the products is unchanged.)
+  const bool bx0 = (uint32_t)x0 < (uint32_t)g.W, bx1 = (uint32_t)x1 < (uint32_t)g.W;
+  const bool by0 = (uint32_t)y0 < (uint32_t)g.H, by1 = (uint32_t)y1 < (uint32_t)g.H;
+  const bool bz0 = (uint32_t)z0 < (uint32_t)g.D, bz1 = (uint32_t)z1 < (uint32_t)g.D;
+  const float qx0 = bx0 ? fx1 : 0.f, qx1 = bx1 ? fx0 : 0.f, qy0 = by0 ? fy1 : 0.f, qy1 = by1 ? fy0 : 0.f, qz0 = bz0 ? fz1 : 0.f, qz1 = bz1 ? fz0 : 0.f;
+  const float wgt[8] = {qx0 * qy0 * qz0, qx1 * qy0 * qz0, qx0 * qy1 * qz0, qx1 * qy1 * qz0,
+                        qx0 * qy0 * qz1, qx1 * qy0 * qz1, qx0 * qy1 * qz1, qx1 * qy1 * qz1};
+#else
   const float wgt[8] = {fx1 * fy1 * fz1, fx0 * fy1 * fz1, fx1 * fy0 * fz1, fx0 * fy0 * fz1,
                         fx1 * fy1 * fz0, fx0 * fy1 * fz0, fx1 * fy0 * fz0, fx0 * fy0 * fz0};
   const bool bx0 = x0 >= 0 && x0 < g.W, bx1 = x1 >= 0 && x1 < g.W;
   const bool by0 = y0 >= 0 && y0 < g.H, by1 = y1 >= 0 && y1 < g.H;
   const bool bz0 = z0 >= 0 && z0 < g.D, bz1 = z1 >= 0 && z1 < g.D;
+#endif
   const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
   const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
   const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
@@ -585,9 +601,13 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
   const uint32_t zy[4] = {zo[0] + yo[0], zo[0] + yo[1], zo[1] + yo[0], zo[1] + yo[1]};
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
     p.off[k] = zy[k >> 1] + xo[k & 1];
+#if IA_PLAN_FACTOR_ZERO
+    p.w[k] = wgt[k];
+#else
+    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
     p.w[k] = in ? wgt[k] : 0.f;
+#endif
   }
   p.load = (active && (bx0 || bx1) && (by0 || by1) && (bz0 || bz1)) ? 1u : 0u;
 }
