@@ -601,11 +601,12 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
   const uint32_t zy[4] = {zo[0] + yo[0], zo[0] + yo[1], zo[1] + yo[0], zo[1] + yo[1]};
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    p.off[k] = zy[k >> 1] + xo[k & 1];
 #if IA_PLAN_FACTOR_ZERO
+    p.off[k] = zy[k >> 1] + xo[k & 1];
     p.w[k] = wgt[k];
 #else
     const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
+    p.off[k] = zy[k >> 1] + xo[k & 1];
     p.w[k] = in ? wgt[k] : 0.f;
 #endif
   }
