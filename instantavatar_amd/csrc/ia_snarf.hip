@@ -631,6 +631,9 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
 #ifndef IA_QUAD_HALF_ROUNDS
 #define IA_QUAD_HALF_ROUNDS 0
 #endif
+#ifndef IA_QUAD_ASM_DPP_ADD
+#define IA_QUAD_ASM_DPP_ADD 0
+#endif
 #if IA_QUAD_LDS_DELIVER >= 2
 // Round R, lane k serves pair 4R + k = (target (4R + k) / 3, row (4R + k) % 3): the source lane of every DPP read is a per-lane
 // constant of the round -- quad_perm [0,0,0,1], [1,1,2,2], [2,3,3,3] -- and the row lands in float4 number 4R + k of the quad's
@@ -677,13 +680,28 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
   // (all DPP reads before the divergent part: a source lane that sits out this round must still be enabled when it is read)
   uint32_t off[8];
   float w[8];
+#if IA_QUAD_ASM_DPP_ADD
+  // (prepared for round 4, NOT measured and not yet through the parity tests: offset broadcast and row-offset add as ONE
+  // v_add_u32_dpp -- the compiler emits v_mov_b32_dpp + v_add_u32 because it sinks the add to the predicated loads.  The two
+  // wait states a DPP read needs after a VALU write of its source are the s_nop: inline asm is opaque to the hazard recogniser.)
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=v"(off[c]) : "v"(p.off[c]), "v"(koff), "i"(PERM & 3), "i"((PERM >> 2) & 3), "i"((PERM >> 4) & 3), "i"((PERM >> 6) & 3));
+    w[c] = quad_perm<PERM>(p.w[c]);
+  }
+  const uint32_t kadd = 0;
+#else
 #pragma unroll
   for (int c = 0; c < 8; c++) { off[c] = quad_perm<PERM>(p.off[c]); w[c] = quad_perm<PERM>(p.w[c]); }
+  const uint32_t kadd = koff;
+#endif
   if (load != 0) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 v[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(off[c] + koff));
+    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(off[c] + kadd));
     f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) {
