@@ -305,7 +305,7 @@ def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512)
                                 "what": "the same 2^20 random points sorted by Morton code first (the sort is not part of avg_launch_us)"}
     except Exception as e:
         out["morton_binned"] = {"error": repr(e)[:200]}
-    cj, src = _profile_json("r03_pmc_encode.json")
+    cj, src = _profile_json("pmc_encode", ("ia_field.hip",))
     out["counters_source"] = src
     if cj is not None:
         try:
@@ -392,23 +392,30 @@ def dry_run(args, rank, world_size):
         dist.destroy_process_group()
 
 
-def _so_sha256():
-    import hashlib
+def _device_code():
+    """{translation unit: hash of its gfx950 code objects} of the library this process RUNS (ia_source_manifest)"""
     from instantavatar_amd import _lib
-    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    m = _lib.lib().ia_source_manifest().decode()
+    return {kv.split("=")[0]: kv.split("=")[1].split(":")[-1] for kv in m.split(";") if "=" in kv}
 
 
-_SO_HASH = [None]
+_DEV_CODE = [None]
+PMC_ROUNDS = ("r04", "r03")
 
 
-def _profile_json(*names):
-    """A committed PMC summary under profiles/ (rocprofv3 --pmc passes, tools/pmc_all.sh) -- accepted ONLY when it was
-    collected on the library this process runs: the summaries carry the library's sha256 (tools/pmc_r3.py).
+def _profile_json(stem, tus):
+    """A committed PMC summary under profiles/ (rocprofv3 --pmc passes, tools/pmc_all.sh), newest round first -- accepted
+    ONLY when it was collected on the device code this process runs: a summary carries the per-translation-unit hashes of
+    the gfx950 code objects of the library it was collected on (instantavatar_amd/build.py: sha256 of `.hip_fatbin`), and
+    those of the translation units `tus` that hold the profiled kernels must equal the running library's.  A rebuild of
+    the same sources anywhere keeps the evidence, a changed kernel drops it.
     Returns (summary or None, source string saying which file was used or why none was)."""
-    if _SO_HASH[0] is None:
-        _SO_HASH[0] = _so_sha256()
+    if _DEV_CODE[0] is None:
+        _DEV_CODE[0] = _device_code()
+    mine = _DEV_CODE[0]
     why = "no PMC summary under profiles/ (tools/pmc_all.sh)"
-    for n in names:
+    for r in PMC_ROUNDS:
+        n = "%s_%s.json" % (r, stem)
         p = os.path.join(ROOT, "profiles", n)
         if not os.path.exists(p):
             continue
@@ -416,11 +423,15 @@ def _profile_json(*names):
             j = json.load(open(p))
         except Exception:
             continue
-        h = j.get("so_sha256")
-        if h == _SO_HASH[0]:
-            return j, "profiles/" + n
-        why = ("profiles/%s was collected on another build of the library (%s, this one is %s): not quoted" %
-               (n, (h or "no hash")[:12], _SO_HASH[0][:12]))
+        theirs = j.get("device_code")
+        if not isinstance(theirs, dict):
+            why = "profiles/%s carries no device-code hashes (collected before round 4): not quoted" % n
+            continue
+        bad = [t for t in tus if not mine.get(t) or mine.get(t) in ("?",) or theirs.get(t) != mine.get(t)]
+        if not bad:
+            return j, "profiles/%s (device code of %s = %s)" % (n, "+".join(tus), "+".join(mine[t] for t in tus))
+        why = ("profiles/%s was collected on other device code of %s (%s, this library: %s): not quoted" %
+               (n, bad[0], theirs.get(bad[0]), mine.get(bad[0])))
     return None, why
 
 
@@ -713,7 +724,7 @@ def main():
         # resident: the algorithmic bytes are served by the cache hierarchy, so the roof they are priced against
         # is the aggregate L2 bandwidth; the bytes that actually reached the fabric (PMC: FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/, accepted only when collected on THIS build) divided by the same launch time give the HBM fraction.
-        tj, tsrc = _profile_json("r03_pmc_traffic.json")
+        tj, tsrc = _profile_json("pmc_traffic", ("ia_snarf.hip",) if dom == "k_search" else ("ia_field.hip",))
         traffic = None
         if tj is not None:
             try:
@@ -743,7 +754,7 @@ def main():
         if L.ia_search_kernel_info(C.byref(vg), C.byref(lds), C.byref(thr), C.byref(wgs)) == 0:
             roof["kernel_resources"] = {"vgprs": vg.value, "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": thr.value,
                                         "workgroups_per_cu": wgs.value, "waves_per_simd": wgs.value * thr.value / 64 / 4.0}
-        cj, csrc = _profile_json("r03_pmc_search.json")
+        cj, csrc = _profile_json("pmc_search", ("ia_snarf.hip",))
         if cj is not None:
             # committed PMC passes of this kernel (tools/pmc_all.sh): what actually bounds k_search is the rate at which a
             # CU's vector L1 (TCP) looks up cache lines for divergent 16-byte gathers -- ~1 access per clock and CU
@@ -791,7 +802,7 @@ def main():
         result["roofline"] = roof
     if rank == 0 and prof:
         result["hashgrid_lookup"] = hashgrid_roofline(model, dev, frame_batch=batches[0])
-        mj, msrc = _profile_json("r03_pmc_mfma.json")
+        mj, msrc = _profile_json("pmc_mfma", ("ia_field.hip",))
         result["mfma"] = dict(mj, source=msrc) if mj is not None else {"source": msrc}
     if args.train_steps > 0:
         try:
@@ -809,7 +820,7 @@ def main():
                     result["train"]["refine"]["eager"] = {k: e[k] for k in ("it_per_sec", "launch_mode")}
             except Exception as e:
                 result["train"]["refine"] = {"error": repr(e)[:300]}
-            hj, hsrc = _profile_json("r03_pmc_hgbwd.json")
+            hj, hsrc = _profile_json("pmc_hgbwd", ("ia_field.hip",))
             # the training step's dominant kernel against the measured atomic-request ceiling (PMC pass on this build)
             result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc) if hj is not None else {"source": hsrc}
         except Exception as e:  # the headline line must survive a failure of the secondary workload

@@ -88,6 +88,11 @@ typedef struct ia_occ_grid {
 /* ---- library ------------------------------------------------------------- */
 int ia_version(void);
 const char *ia_last_error(void);
+/* "<translation unit>=<16 hex digits>;..." -- a hash per translation unit over (compiler flags, shared headers,
+ * source) of what this library was built from.  No counterpart in the reference (its extensions are JIT-built at
+ * import, deformer_torch.py:10-19): bench.py uses it to accept a committed counter summary only for the very
+ * kernel source it is running.                                                 */
+const char *ia_source_manifest(void);
 
 /* Level table as tcnn computes it on the host (grid.h: grid_scale /
  * grid_resolution / offset table; call site ngp.py:30-37).                   */

@@ -42,6 +42,7 @@ _VP = C.c_void_p
 _SIGS = {
     "ia_version": (C.c_int, []),
     "ia_last_error": (C.c_char_p, []),
+    "ia_source_manifest": (C.c_char_p, []),
     "ia_hash_desc_init": (C.c_int, [C.POINTER(HashDesc), C.c_int, C.c_int, C.c_int, C.c_float]),
     "ia_smpl_tfs": (C.c_int, [_VP] * 8 + [_VP]),
     "ia_smpl_tfs_bwd": (C.c_int, [_VP] * 9),

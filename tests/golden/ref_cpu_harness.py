@@ -11,6 +11,7 @@ reference executing, not to a reading of it.
 
 Test infrastructure only: imported by tests/golden/make_*.py, never by the product.
 """
+import os
 import sys
 import types
 
@@ -275,7 +276,16 @@ def install(oracle, field_holder, differentiable=False):
     import instant_avatar.models.networks.ngp as ngp
     import instant_avatar.renderers.raymarcher_acc as ray
     import instant_avatar.models.structures.density_grid as dgrid
-    import instant_avatar.models.DNeRF as dnerf
+    # DNeRF.py:15 opens logging.FileHandler("DNeRF.log") in the working directory at import time: import it from a
+    # temporary directory so that the harness leaves nothing behind in the repository
+    import tempfile
+    _cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as _tmp:
+        os.chdir(_tmp)
+        try:
+            import instant_avatar.models.DNeRF as dnerf
+        finally:
+            os.chdir(_cwd)
     from instant_avatar.deformers.smplx.body_models import SMPL
     from instant_avatar.deformers.smplx.utils import Struct
     return types.SimpleNamespace(snarf=snarf, ngp=ngp, ray=ray, dgrid=dgrid, dnerf=dnerf, SMPL=SMPL, Struct=Struct)

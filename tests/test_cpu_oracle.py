@@ -32,6 +32,62 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib().ia_version() >= 100
 
 
+def test_library_manifest_equals_checkout_and_names_device_code():
+    """The library says what it was built from (ia_source_manifest): the source hashes must be the checkout's (a stale
+    prebuilt .so is an error, build.py), and every translation unit with kernels carries a device-code hash."""
+    from instantavatar_amd import _lib, build as ia_build
+    assert ia_build.library_manifest() == ia_build.source_manifest(), "libinstantavatar_hip.so is stale: run __graft_entry__.build()"
+    assert not ia_build.needs_build()
+    dev = ia_build.device_manifest()
+    for tu in ("ia_snarf.hip", "ia_field.hip", "ia_render.hip"):
+        assert re.fullmatch(r"[0-9a-f]{16}", dev[tu]), dev
+    # the loaded library reports the same string the file carries
+    m = _lib.lib().ia_source_manifest().decode()
+    assert dict(kv.split("=") for kv in m.split(";")) == ia_build._raw_manifest()
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_rebuild_on_another_path_reproduces_the_device_code(tmp_path):
+    """the counter summaries under profiles/ are keyed on the device code, and a forced rebuild of
+    the same sources in ANOTHER directory must give the very same hashes (the .so bytes used to differ through the
+    path-derived __hip_cuid_*; build.py now names the cuid after the file)."""
+    import shutil
+    import subprocess
+    from instantavatar_amd import build as ia_build
+    os.makedirs(tmp_path / "elsewhere" / "instantavatar_amd")
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "elsewhere" / "include")
+    shutil.copytree(os.path.join(ROOT, "instantavatar_amd", "csrc"), tmp_path / "elsewhere" / "instantavatar_amd" / "csrc",
+                    ignore=shutil.ignore_patterns("*.o", ".stamps"))
+    shutil.copy(os.path.join(ROOT, "instantavatar_amd", "build.py"), tmp_path / "elsewhere" / "instantavatar_amd" / "build.py")
+    subprocess.check_call([sys.executable, "instantavatar_amd/build.py", "--force"], cwd=tmp_path / "elsewhere",
+                          stdout=subprocess.DEVNULL)
+    other = str(tmp_path / "elsewhere" / "instantavatar_amd" / "libinstantavatar_hip.so")
+    assert ia_build.device_manifest(other) == ia_build.device_manifest()
+    assert ia_build.library_manifest(other) == ia_build.library_manifest()
+
+
+def test_bench_quotes_a_counter_summary_only_for_the_device_code_it_runs(tmp_path, monkeypatch):
+    import json
+    import bench
+    from instantavatar_amd import build as ia_build
+    dev = ia_build.device_manifest()
+    os.makedirs(tmp_path / "profiles")
+    json.dump({"device_code": dev, "x": 1}, open(tmp_path / "profiles" / "r04_pmc_search.json", "w"))
+    json.dump({"device_code": dict(dev, **{"ia_field.hip": "0" * 16}), "x": 2}, open(tmp_path / "profiles" / "r04_pmc_encode.json", "w"))
+    json.dump({"so_sha256": "abc", "x": 3}, open(tmp_path / "profiles" / "r03_pmc_mfma.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    j, src = bench._profile_json("pmc_search", ("ia_snarf.hip",))
+    assert j["x"] == 1 and "r04_pmc_search.json" in src
+    j, src = bench._profile_json("pmc_encode", ("ia_field.hip",))
+    assert j is None and "other device code of ia_field.hip" in src
+    j, src = bench._profile_json("pmc_encode", ("ia_snarf.hip",))     # the changed unit is not the one this summary needs
+    assert j["x"] == 2
+    j, src = bench._profile_json("pmc_mfma", ("ia_field.hip",))
+    assert j is None and "no device-code hashes" in src
+    j, src = bench._profile_json("pmc_hgbwd", ("ia_field.hip",))
+    assert j is None and "no PMC summary" in src
+
+
 def test_no_cpu_fallback_fails_loudly():
     from instantavatar_amd import _lib
     from instantavatar_amd.models.networks.ngp import NeRFNGPNet

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 3: every PMC pass the bench line cites, on the library as it is NOW, summarised with its sha256 inside
-# (tools/pmc_r3.py -> gpurun_out/profiles_r03/r03_pmc_*.json; copy those to profiles/).
+# Every PMC pass the bench line cites, on the library as it is NOW, summarised with the hashes of its device code inside
+# (tools/pmc_r3.py -> gpurun_out/profiles_$RND/${RND}_pmc_*.json; copy those to profiles/).
 # One counter set per pass, --kernel-trace only (MI355X_MICROARCH.md; gpurun refuses --pmc combined with other traces).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RND=${IA_PMC_ROUND:-r04}; export IA_PMC_ROUND=$RND
 run() {  # run <dir> <counter set> -- <command...>
   local d=$1 c=$2; shift 3
   rm -rf $O/$d
@@ -26,14 +26,14 @@ done
 for c in "TCC_ATOMIC_sum TCC_REQ_sum" "TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum"; do
   run pmc3_$(echo $c | tr ' ' '+') "$c" -- python $R/bench.py --train-only --steps 30 --warmup 5 --no-graph
 done
-python $R/tools/pmc_r3.py $O $O/profiles_r03 > $O/pmc_all_summary.txt 2>&1; tail -5 $O/pmc_all_summary.txt
+python $R/tools/pmc_r3.py $O $O/profiles_$RND > $O/pmc_all_summary.txt 2>&1; tail -5 $O/pmc_all_summary.txt
 # the raw per-dispatch CSVs are tens of MB per pass (gpurun copies back at most 64 MiB): keep one condensed row per
 # (kernel, counter) of every pass next to the summaries and drop the raw files
-mkdir -p $O/profiles_r03/r03_pmc
+mkdir -p $O/profiles_$RND/${RND}_pmc
 for d in $O/pmc2_* $O/pmc_enc_* $O/pmc_encc_* $O/pmc3_*; do
   [ -d "$d" ] || continue
-  python $R/tools/pmc_condense.py $d $O/profiles_r03/r03_pmc/$(basename $d).csv 2>/dev/null
+  python $R/tools/pmc_condense.py $d $O/profiles_$RND/${RND}_pmc/$(basename $d).csv 2>/dev/null
   rm -rf $d
 done
 rm -rf $O/pmcq_* $O/pmc_s[0-9]* $O/prof_frame $O/prof_refine $O/pmc_records 2>/dev/null
-ls -la $O/profiles_r03 $O/profiles_r03/r03_pmc | head -40; du -sh $O
+ls -la $O/profiles_$RND $O/profiles_$RND/${RND}_pmc | head -40; du -sh $O

@@ -23,8 +23,18 @@ import pmc_r2  # noqa: E402
 SO = os.path.join(os.path.dirname(HERE), "instantavatar_amd", "libinstantavatar_hip.so")
 
 
+ROUND = os.environ.get("IA_PMC_ROUND", "r04")
+
+
 def so_hash():
     return hashlib.sha256(open(SO, "rb").read()).hexdigest()
+
+
+def device_code():
+    """{translation unit: hash of its gfx950 code objects} embedded in the library (instantavatar_amd/build.py)"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from instantavatar_amd import build as ia_build
+    return ia_build.device_manifest(SO)
 
 
 def per_kernel(pattern, match):
@@ -66,8 +76,8 @@ def per_kernel_tail(pattern, match, last_n):
 
 def main(root, out_dir):
     os.makedirs(out_dir, exist_ok=True)
-    meta = {"so_sha256": so_hash(), "collected_by": "tools/pmc_all.sh (rocprofv3 --pmc <one set per pass> --kernel-trace)"}
-    pmc_r2.main(root, out_dir, prefix="r03", meta=meta)
+    meta = {"so_sha256": so_hash(), "device_code": device_code(), "collected_by": "tools/pmc_all.sh (rocprofv3 --pmc <one set per pass> --kernel-trace)"}
+    pmc_r2.main(root, out_dir, prefix=ROUND, meta=meta)
     # ---- isolated encoder
     C, us, _ = per_kernel(os.path.join(root, "pmc_enc_*", "**", "*counter_collection.csv"), ("k_hashgrid<", "k_encode_xcd"))
     V = 1 << 20
@@ -110,7 +120,7 @@ def main(root, out_dir):
                     "Algorithmic bytes: 512 B/sample.  L2 request-rate ceiling: 8 XCD x 16 channels x 2.1 GHz = 269 G requests/s "
                     "(profiles/r02_ubench_l2gather.txt).  FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md)")
     enc.update(meta)
-    json.dump(enc, open(os.path.join(out_dir, "r03_pmc_encode.json"), "w"), indent=1)
+    json.dump(enc, open(os.path.join(out_dir, ROUND + "_pmc_encode.json"), "w"), indent=1)
     # ---- hash-grid backward atomics
     C, us, n = per_kernel(os.path.join(root, "pmc3_*", "**", "*counter_collection.csv"), ("k_hashgrid_bwd",))
     hg = {}
@@ -124,8 +134,8 @@ def main(root, out_dir):
     hg["_note"] = ("TCC_ATOMIC_sum / TCC_EA0_ATOMIC_sum over an eager `bench.py --train-only` run (PatchSampler workload); ceiling = "
                    "tools/ubench/atomics.hip (21.1 G requests/s, profiles/r02_ubench_atomics.txt)")
     hg.update(meta)
-    json.dump(hg, open(os.path.join(out_dir, "r03_pmc_hgbwd.json"), "w"), indent=1)
-    for n_ in ("r03_pmc_encode.json", "r03_pmc_hgbwd.json"):
+    json.dump(hg, open(os.path.join(out_dir, ROUND + "_pmc_hgbwd.json"), "w"), indent=1)
+    for n_ in (ROUND + "_pmc_encode.json", ROUND + "_pmc_hgbwd.json"):
         print("==", n_)
         print(open(os.path.join(out_dir, n_)).read()[:2500])
 
