@@ -51,15 +51,17 @@ _SIGS = {
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
     "ia_precompute_workspace_bytes": (C.c_size_t, [C.POINTER(SnarfGrid)]),
     "ia_precompute_ws": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP, C.c_size_t, _VP]),
+    "ia_snarf_search_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ia_search_set_impl": (C.c_int, [C.c_int]),
+    "ia_search_get_impl": (C.c_int, []),
     "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
-                                  C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
+                                  C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "ia_snarf_search_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                           C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, C.c_int32, _VP, _VP,
-                                          _VP, C.c_int, _VP]),
+                                          _VP, C.c_int, _VP, C.c_size_t, _VP]),
     "ia_snarf_search_compact_jinv": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                                C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, _VP, C.c_int32, _VP, _VP,
                                                _VP, C.c_int, _VP, C.c_size_t, _VP]),
-    "ia_snarf_search_jinv_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_field_fwd": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP]),
     "ia_field_act_stride": (C.c_int, [C.c_int]),
     "ia_field_fwd_train": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(Field), _VP, _VP, _VP, _VP]),
@@ -147,6 +149,8 @@ def lib():
             fn = getattr(l, name)  # AttributeError if a symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("IA_SEARCH_IMPL"):     # round-4 A/B switch: 0 = workgroup queues, 1 = persistent waves (default)
+            l.ia_search_set_impl(int(os.environ["IA_SEARCH_IMPL"]))
         _lib = l
     return _lib
 
@@ -167,6 +171,16 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "tensor must be contiguous"
     return t.data_ptr()
+
+
+def scratch(owner, name, nbytes, device):
+    """A byte buffer of at least `nbytes` cached on `owner` under `name` (grown, never shrunk): the caller-provided
+    workspaces of the C ABI.  Sized during the eager warm-up calls, so a captured graph replays with fixed pointers."""
+    t = getattr(owner, name, None)
+    if t is None or t.numel() < nbytes or t.device != torch.device(device):
+        t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        setattr(owner, name, t)
+    return t
 
 
 def stream():

@@ -22,7 +22,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libinstantavatar_hip.so")
-SOURCES = ["ia_error.cpp", "ia_snarf.hip", "ia_field.hip", "ia_render.hip", "ia_prof.hip", "ia_voxelise.hip", "ia_loss.hip", "ia_smpl_nn.hip", "ia_data.hip", "ia_mesh.hip"]
+SOURCES = ["ia_error.cpp", "ia_snarf.hip", "ia_search.hip", "ia_field.hip", "ia_render.hip", "ia_prof.hip", "ia_voxelise.hip", "ia_loss.hip", "ia_smpl_nn.hip", "ia_data.hip", "ia_mesh.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: fused multiply-adds appear only where the sources spell them
 # (IA_DOT3 / __builtin_fmaf), the same sequence the CPU checker uses
@@ -30,6 +30,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # named after the file instead, the objects (host AND device code) of the same sources are byte-identical whatever
 # directory they are built in, which is what lets a counter summary name the device code it was collected on
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# per-translation-unit flags.  ia_search.hip: the SLP vectoriser pairs scalar fp32 ops of the Broyden update into v_pk_* and
+# pays with register moves (static solver-loop count 614 -> 606 VALU, 51 -> 29 moves; per-lane arithmetic identical, the
+# parity tests are bit-exact with it): 193.4 -> 191.7 us on a frame's sample points (profiles/r04_ab_search_variants.txt)
+TU_FLAGS = {"ia_search.hip": ["-fno-slp-vectorize"]}
 OBJCOPY = os.environ.get("LLVM_OBJCOPY", "/opt/rocm/lib/llvm/bin/llvm-objcopy")
 SHARED_HEADERS = [os.path.join(CSRC, "ia_common.h"), os.path.join(HERE, "..", "include", "instantavatar_hip.h")]
 _MARK = b"IA_SOURCE_MANIFEST="
@@ -39,9 +43,19 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def extra_flags():
-    """experiment switches for A/B builds (tools/ab_build.sh): part of every hash, so a variant never passes for the default"""
-    return os.environ.get("IA_EXTRA_HIPCC_FLAGS", "").split()
+def extra_flags(src=None):
+    """experiment switches for A/B builds (tools/ab_*.sh): IA_EXTRA_HIPCC_FLAGS="[<file>:]<flags>" -- with a file prefix
+    (e.g. "ia_snarf.hip:-DIA_X=1") only that translation unit gets them.  Part of the unit's hashes, so a variant never
+    passes for the default build."""
+    own = list(TU_FLAGS.get(os.path.basename(src), [])) if src is not None else []
+    v = os.environ.get("IA_EXTRA_HIPCC_FLAGS", "").strip()
+    if not v:
+        return own
+    head = v.split()[0]
+    if ":" in head and head.split(":")[0].endswith((".hip", ".cpp")):
+        only, rest = v.split(":", 1)
+        return own + (rest.split() if src is not None and os.path.basename(src) == only else [])
+    return own + v.split()
 
 
 def cuid_flag(src):
@@ -63,7 +77,7 @@ def includes_of(src):
 
 def tu_hash(src):
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS + extra_flags() + [cuid_flag(src)]).encode())
+    h.update(" ".join(FLAGS + extra_flags(src) + [cuid_flag(src)]).encode())
     for f in SHARED_HEADERS + includes_of(src) + [src]:
         h.update(b"\0" + os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
@@ -155,7 +169,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj, stamp, h = job
-        cmd = [HIPCC] + FLAGS + extra_flags() + [cuid_flag(src), "-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra_flags(src) + [cuid_flag(src), "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -165,7 +179,7 @@ def build(force=False, verbose=False):
         list(ex.map(compile_one, jobs))
     err_src = os.path.join(CSRC, "ia_error.cpp")
     full = {k: "%s:%s" % (v, device_code_hash(os.path.join(CSRC, k + ".o")) if k != "ia_error.cpp" else "-") for k, v in want.items()}
-    cmd = [HIPCC] + FLAGS + extra_flags() + [cuid_flag(err_src), '-DIA_SOURCE_MANIFEST="%s"' % _manifest_string(full), "-x", "hip", "-c", err_src,
+    cmd = [HIPCC] + FLAGS + extra_flags(err_src) + [cuid_flag(err_src), '-DIA_SOURCE_MANIFEST="%s"' % _manifest_string(full), "-x", "hip", "-c", err_src,
                                               "-o", os.path.join(CSRC, "ia_error.cpp.o")]
     if verbose:
         print(" ".join(cmd), flush=True)

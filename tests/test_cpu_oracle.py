@@ -1077,7 +1077,11 @@ def test_round3_entry_points_validate_arguments_before_any_launch():
     tail = (C.c_float(1e-5), C.c_float(1e-1))
     # n_cand is required; P < 0 is rejected; P == 0 returns before touching anything; the J_inv output and the workspace are required
     big = 1 << 20
-    assert L.ia_snarf_search_jinv_workspace_bytes(4, 3) == 4 * 3 * 9 * 4
+    # workspace: work heads (8 x 128 B), one flag per (init, point of the 64-padded list), modes 1-2 the unfiltered roots, mode 2 their J_inv
+    w0, w1, w2 = (L.ia_snarf_search_workspace_bytes(4, 3, m) for m in (0, 1, 2))
+    assert w0 >= 8 * 128 + 3 * 64 and w1 >= w0 + 3 * 64 * 12 and w2 >= w1 + 4 * 3 * 9 * 4
+    assert L.ia_snarf_search_workspace_bytes(0, 3, 1) == 0 and L.ia_snarf_search_workspace_bytes(4, 99, 1) == 0 and L.ia_snarf_search_workspace_bytes(4, 3, 7) == 0
+    assert L.ia_search_get_impl() == 1 and L.ia_search_set_impl(5) != 0
     assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, None, 0, one, big, None) != 0
     assert b"n_cand" in L.ia_last_error()
     assert L.ia_snarf_search_compact_jinv(one, -1, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, one, big, None) != 0

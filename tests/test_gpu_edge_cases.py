@@ -39,7 +39,7 @@ def test_argument_errors_raise_and_report(gw):
     bones = _lib.bone_array([0, 1, 99])  # joint id out of range
     with pytest.raises(_lib.IAError):
         _lib.check(L.ia_snarf_search(_lib.ptr(t), 1, _lib.ptr(t), _lib.ptr(t), bones, 3, C.byref(model.deformer.deformer.grid_desc()),
-                                     1e-5, 1e-1, _lib.ptr(t), _lib.ptr(t), None, None, None), "ia_snarf_search")
+                                     1e-5, 1e-1, _lib.ptr(t), _lib.ptr(t), None, None, None, 0, None), "ia_snarf_search")
     ws = torch.empty(16, dtype=torch.uint8, device=DEV)  # workspace too small
     rc = L.ia_occupancy_from_density(_lib.ptr(torch.zeros(64 ** 3, device=DEV)), 64, _lib.ptr(torch.zeros(8193, dtype=torch.int32, device=DEV)),
                                      None, _lib.ptr(ws), 16, None)

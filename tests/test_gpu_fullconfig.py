@@ -56,69 +56,160 @@ def _check(rgb, alpha, counter, occ_g, ref, what):
     return info
 
 
-def test_bench_configuration_parity_512_eager_and_graph(oracle, bench_world):
-    """>= 2 procedural poses at 512x512 through `render_image_fast` (eager) AND the captured HIP graph
-    (`GraphedRenderer`, what bench.py times), both against `oracle.render_image_fast`."""
-    model, body, fp, init, poses, tr = bench_world
+def _eager_graph_pipelined(oracle, bench_world, frames, seed0, what):
+    """`frames`: list of (pose72, transl, betas or None).  Renders every frame at 512x512 through `render_image_fast`
+    (eager), the captured HIP graph (`GraphedRenderer`) and two frames in flight (`PipelinedRenderer`, what bench.py
+    times by default), each against `oracle.render_image_fast` on the same injected occupancy jitter."""
+    model, body, fp, init = bench_world[:4]
     res = 512
     ro, rd = syn.make_camera_rays(res)
     grid = model.renderer.density_grid_test
-    jits = {i: np.random.RandomState(500 + i).rand(5, G ** 3, 3).astype(np.float32) for i in (1, 5)}
-    refs = {}
-    for i in (1, 5):
-        ow = W.oracle_world(oracle, body, fp, init, poses[i], tr[i])
-        refs[i] = oracle.render_image_fast(ow, ro, rd, jits[i])
+    n = len(frames)
+    jits = [np.random.RandomState(seed0 + i).rand(5, G ** 3, 3).astype(np.float32) for i in range(n)]
+    refs, infos = [], []
+    for i, (pose, transl, betas) in enumerate(frames):
+        ow = W.oracle_world(oracle, body, fp, init, pose, transl, betas)
+        refs.append(oracle.render_image_fast(ow, ro, rd, jits[i]))
+    batch = lambda i: make_batch(DEV, res, frames[i][0], frames[i][1], betas=frames[i][2])
     # eager
-    for i in (1, 5):
-        rgb, depth, alpha, counter = model.render_image_fast(make_batch(DEV, res, poses[i], tr[i]), (res, res),
-                                                             jitter=torch.as_tensor(jits[i], device=DEV))
-        _check(rgb, alpha, counter, grid.density_field, refs[i], "512^2 eager pose %d" % i)
+    for i in range(n):
+        rgb, depth, alpha, counter = model.render_image_fast(batch(i), (res, res), jitter=torch.as_tensor(jits[i], device=DEV))
+        infos.append(_check(rgb, alpha, counter, grid.density_field, refs[i], "%s 512^2 eager frame %d" % (what, i)))
     # graph replay: the occupancy jitter is a static device buffer read by the captured launches
-    jit_dev = torch.as_tensor(jits[1], device=DEV).clone()
+    jit_dev = torch.as_tensor(jits[0], device=DEV).clone()
     orig = grid.initialize
     grid.initialize = lambda deformer, net, iters=5, jitter=None: orig(deformer, net, iters=iters, jitter=jit_dev)
     try:
-        g = GraphedRenderer(model, make_batch(DEV, res, poses[1], tr[1]), (res, res), sync_check=True)
-        for i in (1, 5):
+        g = GraphedRenderer(model, batch(0), (res, res), sync_check=True)
+        for i in range(n):
             jit_dev.copy_(torch.as_tensor(jits[i], device=DEV))
-            out = [t.clone() for t in g(make_batch(DEV, res, poses[i], tr[i]))]
-            _check(out[0], out[2], out[3], grid.density_field, refs[i], "512^2 graph pose %d" % i)
+            out = [t.clone() for t in g(batch(i))]
+            _check(out[0], out[2], out[3], grid.density_field, refs[i], "%s 512^2 graph frame %d" % (what, i))
         assert g.finish() == 0
     finally:
         grid.initialize = orig
-    # two frames in flight (what bench.py times by default): every replica's frames against the oracle as well
+    # two frames in flight: replica 0 renders the even calls, replica 1 the odd ones; each replica reads its own static
+    # jitter buffer, refreshed before the call that uses it
     import instantavatar_amd.pipeline as P
     from instantavatar_amd.pipeline import PipelinedRenderer
-    jit_a, jit_b = (torch.as_tensor(jits[i], device=DEV).clone() for i in (1, 5))
+    jit_rep = [torch.as_tensor(jits[0], device=DEV).clone(), torch.as_tensor(jits[min(1, n - 1)], device=DEV).clone()]
     patched, real_clone = [], P.clone_for_stream
 
-    def patch(m, jit_dev):
+    def patch(m, jd):
         gr = m.renderer.density_grid_test
         o = gr.initialize
-        gr.initialize = lambda deformer, net, iters=5, jitter=None, _o=o: _o(deformer, net, iters=iters, jitter=jit_dev)
+        gr.initialize = lambda deformer, net, iters=5, jitter=None, _o=o: _o(deformer, net, iters=iters, jitter=jd)
         patched.append((gr, o))
 
     def patched_clone(m):
         c = real_clone(m)
-        patch(c, jit_b)          # replica 1 always renders pose 5 below, replica 0 pose 1
+        patch(c, jit_rep[1])
         return c
-    patch(model, jit_a)
+    patch(model, jit_rep[0])
     P.clone_for_stream = patched_clone
     try:
-        pr = PipelinedRenderer(model, make_batch(DEV, res, poses[1], tr[1]), (res, res), n_in_flight=2)
+        pr = PipelinedRenderer(model, batch(0), (res, res), n_in_flight=2)
+        order = list(range(n)) + list(range(n))      # every frame passes through both replicas when n is odd
         got = []
-        keep = [make_batch(DEV, res, poses[i], tr[i]) for i in (1, 5, 1, 5)]
-        for b in keep:
-            pr(b, consume=lambda out, k: got.append(([t.clone() for t in out], pr.replicas[k].renderer.density_grid_test.density_field.clone())))
+        jits_dev = [torch.as_tensor(j, device=DEV) for j in jits]
+        torch.cuda.synchronize()
+        for call, i in enumerate(order):
+            k = call % 2
+            with torch.cuda.stream(pr.streams[k]):    # behind the replica's previous frame, ahead of its next replay; the
+                jit_rep[k].copy_(jits_dev[i])          # other replica's stream is not made to wait: two frames stay in flight
+            pr(batch(i), consume=lambda out, kk: got.append(([t.clone() for t in out], pr.replicas[kk].renderer.density_grid_test.density_field.clone())))
         pr.synchronize()
         assert pr.finish() == 0
-        for n, i in enumerate((1, 5, 1, 5)):
-            out, occ = got[n]
-            _check(out[0], out[2], out[3], occ, refs[i], "512^2 two in flight, call %d pose %d" % (n, i))
+        for call, i in enumerate(order):
+            out, occ = got[call]
+            _check(out[0], out[2], out[3], occ, refs[i], "%s 512^2 two in flight, call %d frame %d" % (what, call, i))
     finally:
         P.clone_for_stream = real_clone
         for gr, o in patched:
             gr.initialize = o
+    return infos
+
+
+def test_bench_configuration_parity_512_eager_and_graph(oracle, bench_world):
+    """>= 2 procedural poses at 512x512 through `render_image_fast` (eager), the captured HIP graph
+    (`GraphedRenderer`) and two frames in flight, all against `oracle.render_image_fast`."""
+    poses, tr = bench_world[4], bench_world[5]
+    _eager_graph_pipelined(oracle, bench_world, [(poses[1], tr[1], None), (poses[5], tr[5], None)], 500, "procedural")
+
+
+def test_bench_workload_parity_aist_demo_track(oracle, bench_world):
+    """The workload bench.py TIMES (BASELINE config 3, animate.py:48-50): frames 0, 100 and 199 of
+    `tests/golden/aist_demo_200.npz` = data/animation/aist_demo.npz[:200] with `trans - trans[0] + (0, 0.15, 5)`,
+    through the three launch modes of the bench (eager, graph, two frames in flight) against the oracle.  The track has
+    global-orient flips and a moving root that the procedural track does not."""
+    import os
+    poses, tr = syn.load_animation_track(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aist_demo_200.npz"))
+    assert poses.shape == (200, 72)
+    infos = _eager_graph_pipelined(oracle, bench_world, [(poses[i], tr[i], None) for i in (0, 100, 199)], 900, "aist_demo")
+    print("aist_demo frames 0/100/199:", [(round(x["cov"], 4), x["frac_rgb"], x["max_rgb"], x["occ_flips"]) for x in infos])
+
+
+def _pose_track(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_tracks.npz"))
+    return (np.concatenate([z[name + "_global_orient"], z[name + "_body_pose"]], 1).astype(np.float32), z[name + "_transl"].astype(np.float32),
+            z[name + "_betas"][0].astype(np.float32))
+
+
+@pytest.mark.parametrize("name,frame", [("male3", 0), ("male3", 57), ("seattle", 20)])
+def test_shipped_pose_tracks_frame_and_training_render(oracle, bench_world, name, frame):
+    """BASELINE configs 2 and 4 are quoted on the pose tracks the reference SHIPS
+    (data/PeopleSnapshot/male-3-casual/poses/anim_nerf_train.npz, data/custom/seattle/poses/train.npz; served by
+    peoplesnapshot.py:127-131 as betas / global_orient / body_pose / transl, near / far = |transl| -+ 1, :143-150):
+    one 512x512 frame and one training render (4 096 rays, jitter + sigma noise injected) of the bench model under those
+    SMPL parameters against the oracle.  Fixture: tests/golden/pose_tracks.npz (make_pose_tracks.py)."""
+    from instantavatar_amd.models.structures.utils import Rays
+    model, body, fp, init = bench_world[:4]
+    poses, tr, betas = _pose_track(name)
+    res = 512
+    ro, rd = syn.make_camera_rays(res)
+    jit = np.random.RandomState(1300 + frame).rand(5, G ** 3, 3).astype(np.float32)
+    ow = W.oracle_world(oracle, body, fp, init, poses[frame], tr[frame], betas)
+    ref = oracle.render_image_fast(ow, ro, rd, jit)
+    batch = make_batch(DEV, res, poses[frame], tr[frame], betas=betas)
+    rgb, depth, alpha, counter = model.render_image_fast(batch, (res, res), jitter=torch.as_tensor(jit, device=DEV))
+    info = _check(rgb, alpha, counter, model.renderer.density_grid_test.density_field, ref, "%s[%d] 512^2" % (name, frame))
+    # ---- training render of the same frame (row a15 / a8 under the shipped parameters)
+    n = 4096
+    grid = model.renderer.density_grid_train
+    model.deformer.prepare_deformer(batch)
+    coords = (grid.coords + 0.5 / G) * (grid.aabb[1] - grid.aabb[0]) + grid.aabb[0]
+    with torch.no_grad():
+        _, dens = model.deformer(coords.reshape(-1, 3), model.net_coarse, True)
+    grid._postprocess(dens.reshape(G, G, G))
+    hit = torch.nonzero(alpha.reshape(-1) > 0.5).reshape(-1)
+    gsel = torch.Generator(device=DEV).manual_seed(3)
+    # half of the rays on the body, half anywhere (the patch sampler's rays nearly all cross the body)
+    sel = torch.cat([hit[torch.randint(0, hit.numel(), (n // 2,), device=DEV, generator=gsel)],
+                     torch.randint(0, res * res, (n // 2,), device=DEV, generator=gsel)])
+    rays = Rays(o=batch["rays_o"][:, sel].clone(), d=batch["rays_d"][:, sel].clone(), near=batch["near"][:, sel].clone(),
+                far=batch["far"][:, sel].clone())
+    model.deformer.transform_rays_w2s(rays)
+    bg = torch.rand((1, n, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    c = lambda t: t.detach().reshape(-1, t.shape[-1]).cpu().numpy() if t.dim() > 2 else t.detach().reshape(-1).cpu().numpy()
+    torch.manual_seed(11)
+    jitter = torch.rand((n, 256), device=DEV)
+    noise = torch.randn((n, 256), device=DEV)
+    torch.manual_seed(11)
+    out = model.renderer.render_train_fused(rays, model.deformer, model.net_coarse, 1, bg)
+    tref = oracle.render_train(c(rays.o), c(rays.d), c(rays.near), c(rays.far), grid.density_field.cpu().numpy(),
+                               grid.aabb.cpu().numpy(), lambda p: oracle.deform_query(p, ow, eval_mode=False),
+                               jitter.cpu().numpy(), bg=c(bg), noise=noise.cpu().numpy())
+    trgb = out["rgb_coarse"].detach().reshape(-1, 3).cpu().numpy()
+    talpha = out["alpha_coarse"].detach().reshape(-1).cpu().numpy()
+    tw = out["weight_coarse"].detach().reshape(n, 256).cpu().numpy()
+    e_rgb, e_a, e_w = np.abs(trgb - tref["rgb"]).max(1), np.abs(talpha - tref["alpha"]), np.abs(tw - tref["weights"]).max(1)
+    tinfo = dict(hit=float((tref["alpha"] > 0.5).mean()), n_field=int(tref["n_field"]), frac_rgb=float((e_rgb > 1e-3).mean()),
+                 frac_alpha=float((e_a > 1e-3).mean()), frac_w=float((e_w > 1e-3).mean()), max_rgb=float(e_rgb.max()), median_rgb=float(np.median(e_rgb)))
+    print("%s[%d] training render" % (name, frame), tinfo)
+    assert tinfo["hit"] > 0.2 and tinfo["n_field"] > 10000, tinfo
+    assert tinfo["frac_rgb"] < 5e-3 and tinfo["frac_alpha"] < 5e-3 and tinfo["frac_w"] < 5e-3, tinfo
+    assert tinfo["median_rgb"] < 1e-4, tinfo
 
 
 def test_bench_configuration_parity_1024(oracle, bench_world):

@@ -22,8 +22,9 @@ def build(device, resolution=64, n_levels=16):
     return model, body, fp, init
 
 
-def oracle_world(orc, body, fp, init, pose72, transl):
-    return orc.make_world(body, init, fp, np.zeros(10, np.float32), pose72[3:], pose72[:3], transl, syn.INIT_BONES)
+def oracle_world(orc, body, fp, init, pose72, transl, betas=None):
+    return orc.make_world(body, init, fp, np.zeros(10, np.float32) if betas is None else np.asarray(betas, np.float32).reshape(10),
+                          pose72[3:], pose72[:3], transl, syn.INIT_BONES)
 
 
 def poses(n=4):

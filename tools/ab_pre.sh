@@ -1,7 +1,7 @@
 #!/bin/bash
+source "$(dirname "$0")/ab_lib.sh"
 # A/B helper (dev tool): rebuild with extra -D flags for ia_snarf.hip and time ia_precompute alone
 for flags in "$@"; do
-  ( cd instantavatar_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -x hip -c ia_snarf.hip -o ia_snarf.hip.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libinstantavatar_hip.so *.o )
+  ab_rebuild ia_snarf.hip "$flags" || { echo "build failed: [$flags]"; continue; }
   timeout 120 python tools/bench_precompute.py "$flags" 2>&1 | tail -1
 done
