@@ -179,24 +179,11 @@ int ia_precompute_ws(const float *voxel_w, const float *tfs, float *voxel_J,
  * not zero them): xc [P,n_init,3] (0 where not converged&valid),
  * valid [P,n_init] uint8 AFTER the duplicate filter, valid_raw [P,n_init] (before
  * the filter; may be NULL), J_inv [P,n_init,3,3] or NULL.                    */
-/* All three search entry points run on PERSISTENT waves (k_solve: work pulled from per-XCD heads, no workgroup
- * barrier) followed by a one-thread-per-point filter / compaction kernel (k_roots) and need a scratch buffer of
- * ia_snarf_search_workspace_bytes(P, n_init, mode) bytes -- mode 0: ia_snarf_search, 1: ia_snarf_search_compact,
- * 2: ia_snarf_search_compact_jinv: the work heads, one flag per (init, point), for modes 1-2 the roots before the
- * filter [n_init][P][3] and for mode 2 their J_inv [P][n_init][9].  The buffer is written before it is read (no
- * initialisation needed); concurrent calls on different streams need their own.  (The reference's ops get their
- * outputs zero-filled by the caller instead, deformer_torch.py:104-106.)                                       */
-size_t ia_snarf_search_workspace_bytes(int P, int n_init, int mode);
 int ia_snarf_search(const float *xd, int P, const float *voxel_J,
                     const float *tfs, const int32_t *bone_ids, int n_init,
                     const ia_snarf_grid *grid, float cvg_thresh,
                     float dvg_thresh, float *xc, uint8_t *valid,
-                    uint8_t *valid_raw, float *J_inv, void *ws, size_t ws_bytes,
-                    void *stream);
-/* Development switch (round 4 A/B): 1 = persistent waves (default), 0 = the workgroup-queue kernel of rounds 2-3
- * (one workgroup = 64 points x n_init solves as an LDS queue).  Same results bit for bit.                     */
-int ia_search_set_impl(int impl);
-int ia_search_get_impl(void);
+                    uint8_t *valid_raw, float *J_inv, void *stream);
 
 /* Fused form used by the fast path: same search + filter, but the surviving
  * candidates are compacted on device (wavefront ballot + prefix sum):
@@ -214,13 +201,13 @@ int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_pts_dev,
                             const ia_snarf_grid *grid, float cvg_thresh,
                             float dvg_thresh, float *cand_xc, int32_t cand_cap,
                             int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand,
-                            int zero_counter, void *ws, size_t ws_bytes,
-                            void *stream);
+                            int zero_counter, void *stream);
 /* The same call for the training route with SMPL parameters under optimisation (DNeRF.py:113-128 ->
  * deformer_torch.py:50-67): additionally cand_Jinv [cap,3,3], the Broyden J_inv of every surviving root
  * (the matrix before the last rank-1 update, fuse_cuda_kernel_fast.cu:383-391), compacted exactly like
  * cand_xc -- what the reference gathers with `others['J_inv'][others['valid_ids']]` from a dense
  * [1,P,13,3,3] tensor.  Input of ia_snarf_implicit_bwd_compact.                                    */
+size_t ia_snarf_search_jinv_workspace_bytes(int P, int n_init);   /* P x n_init x 9 floats: J_inv of the valid solves before compaction */
 int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
                                  const float *voxel_J, const float *tfs,
                                  const int32_t *bone_ids, int n_init,

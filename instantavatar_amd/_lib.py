@@ -51,14 +51,12 @@ _SIGS = {
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
     "ia_precompute_workspace_bytes": (C.c_size_t, [C.POINTER(SnarfGrid)]),
     "ia_precompute_ws": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP, C.c_size_t, _VP]),
-    "ia_snarf_search_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "ia_search_set_impl": (C.c_int, [C.c_int]),
-    "ia_search_get_impl": (C.c_int, []),
     "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
-                                  C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+                                  C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
     "ia_snarf_search_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                           C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, C.c_int32, _VP, _VP,
-                                          _VP, C.c_int, _VP, C.c_size_t, _VP]),
+                                          _VP, C.c_int, _VP]),
+    "ia_snarf_search_jinv_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_snarf_search_compact_jinv": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,
                                                C.POINTER(SnarfGrid), C.c_float, C.c_float, _VP, _VP, C.c_int32, _VP, _VP,
                                                _VP, C.c_int, _VP, C.c_size_t, _VP]),
@@ -149,8 +147,6 @@ def lib():
             fn = getattr(l, name)  # AttributeError if a symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("IA_SEARCH_IMPL"):     # round-4 A/B switch: 0 = workgroup queues, 1 = persistent waves (default)
-            l.ia_search_set_impl(int(os.environ["IA_SEARCH_IMPL"]))
         _lib = l
     return _lib
 

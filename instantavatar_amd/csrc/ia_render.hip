@@ -832,12 +832,10 @@ extern "C" int ia_occupancy_pack(const uint8_t *occ_bool, int G, uint32_t *occ_b
 struct QueryWs {
   int32_t *n_cand; int32_t *pt_off; uint8_t *pt_cnt; float *cand_xc; float *cand_rgb; float *cand_sigma;
   int cand_cap;
-  void *search_ws; size_t search_ws_bytes;   // scratch of ia_snarf_search_compact (work heads, flags, roots before the filter)
 };
 static size_t query_ws_bytes(int P, int n_init) {
   const size_t cap = (size_t)P * n_init;
-  return ia_align(256) + ia_align((size_t)P * 4) + ia_align((size_t)P) + 2 * ia_align(cap * 12) + ia_align(cap * 4) +
-         ia_align(ia_snarf_search_workspace_bytes(P, n_init, 1));
+  return ia_align(256) + ia_align((size_t)P * 4) + ia_align((size_t)P) + 2 * ia_align(cap * 12) + ia_align(cap * 4);
 }
 static QueryWs carve_query(WsCarver &w, int P, int n_init) {
   QueryWs q;
@@ -849,8 +847,6 @@ static QueryWs carve_query(WsCarver &w, int P, int n_init) {
   q.cand_rgb = w.take<float>(cap * 3);
   q.cand_sigma = w.take<float>(cap);
   q.cand_cap = (int)cap;
-  q.search_ws_bytes = ia_snarf_search_workspace_bytes(P, n_init, 1);
-  q.search_ws = w.take<char>(q.search_ws_bytes);
   return q;
 }
 
@@ -860,8 +856,7 @@ static int query_impl(const float *pts, int P, const int32_t *n_pts_dev, const f
                       const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid, const FieldDev &F,
                       const QueryWs &q, hipStream_t s, int zero_counter = 1) {
   int rc = ia_snarf_search_compact(pts, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, 1e-5f, 1e-1f,
-                                   q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, zero_counter, q.search_ws,
-                                   q.search_ws_bytes, s);
+                                   q.cand_xc, q.cand_cap, q.pt_off, q.pt_cnt, q.n_cand, zero_counter, s);
   if (rc) return rc;
   return ia_launch_field(q.cand_xc, q.cand_cap, q.n_cand, F, q.cand_rgb, q.cand_sigma, s, nullptr);
 }

@@ -1,311 +1,21 @@
 // ia_search.hip -- a4 + a5: Broyden root finding of the Fast-SNARF deformer, duplicate filter, compaction (gfx950, wave64).
 //
-//   k_solve   PERSISTENT waves, each one autonomous: a wave pulls chunks of 64 (point, init) pairs from per-XCD work heads,
-//             classifies them at full lane efficiency (solves whose initial fetch lies wholly outside the grid are invalid
-//             by construction), keeps the live ones in a wave-private LDS ring and refills every idle lane from it; the
-//             loop body is ONE quad-cooperative trilinear fetch + the Broyden update (ia_search_dev.h).  A finished solve
-//             writes its flag and root straight to global memory -- no workgroup barrier, no per-workgroup epilogue.
-//   k_roots   one thread per point: duplicate filter over its 13 solves (filter.cu:27-51) and either the dense reference
-//             layout or ballot / prefix-sum compaction of the surviving roots.
+//   k_search  a workgroup owns 64 points x n_init solves as an LDS queue; every lane runs a state machine whose loop body is
+//             ONE quad-cooperative trilinear fetch + the Broyden update (ia_search_dev.h); finished lanes pull the next item;
+//             then the workgroup runs the duplicate filter and either writes the dense reference layout or compacts the roots.
 //
 // Reference semantics: fuse_kernel/fuse_cuda_kernel_fast.cu:252-413 (broyden_kernel; every solve executes exactly its
 // arithmetic sequence), filter/filter.cu:10-55, deformer_torch.py:85-116.
+//
+// What bounds it (round 4, in-kernel cycle counters + PMC, profiles/r04_search_phase_cycles.txt): a wave-step moves
+// 64 x 384 B = 24.6 KB through the CU's vector L1 (64 B per clock: >= 384 cycles of the CU) and issues ~380-480 VALU
+// instructions (x 4 cycles on one of four SIMDs: ~430 cycles of the CU); the kernel runs at one wave-step per ~575 CU-cycles,
+// i.e. BOTH pipes are two-thirds busy and neither more resident waves nor fewer barriers raise the rate.  A persistent-wave
+// rewrite (no workgroup barrier, global work supply, lanes packed 15 % tighter, bit-identical results) was built and measured
+// in round 4 -- 279 us against 249 us on a frame's sample points: with 4 096 instead of ~3 000 waves inside the loop the fetch
+// phase took 6 881 instead of 4 674 cycles -- and archived with its numbers under tools/variants/.
 #include "ia_search_dev.h"
 
-#define IA_SOLVE_THREADS 256
-#define IA_SOLVE_WAVES (IA_SOLVE_THREADS / 64)
-#define IA_RING 128          // entries of a wave's ring (power of two; never holds more than 63 + 64)
-#define IA_HEADS 8           // work heads, one per XCD (placement is a speed assumption only: any wave may pull from any head)
-#define IA_HEAD_STRIDE 32    // int32 words between heads: 128 bytes, a head per cache line
-#define IA_CG_SHIFT 4        // chunks are dealt to the heads in groups of 16 consecutive chunks
-#define IA_GRAB_MAX 8        // chunks per pull at most (the pull size tapers with what is left on the head)
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Why persistent waves (round 4).  The workgroup-queue kernel of rounds 2-3 (below, kept for the A/B) gives a workgroup
-// 64 points x 13 solves: ~290 live solves for 256 lanes, i.e. little more than ONE solve per lane, so its lifetime is the
-// longest Broyden chain (11 fetches) plus classification, two barriers, the filter and a dependent global atomic, while the
-// mean lane needs 5-6 fetches; waves that run dry wait for the slowest wave of their workgroup and the slot is released
-// per workgroup.  Here a wave never waits for another wave: work arrives in chunks of 64 items from a global supply, the
-// ring keeps >= 64 classified live items ahead of the lanes, and the only drain is the one at the end of the launch.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int MODE>   // 0: dense reference layout (xc with zeros, optional J_inv); 1: roots for compaction; 2: 1 + J_inv of the roots
-__global__ __launch_bounds__(IA_SOLVE_THREADS) void k_solve(
-    const float *__restrict__ xd, int P, const int32_t *__restrict__ n_pts_dev, const float *__restrict__ vJ,
-    const float *__restrict__ tfs, BoneIds bones, int n_init, SnarfGridDev g, float cvg2, float dvg2,
-    int32_t *__restrict__ heads, uint8_t *__restrict__ flags, size_t ppad,
-    float *__restrict__ xout,    // MODE 0: xc [P][n_init][3];  MODE 1/2: roots [n_init][ppad][3], valid entries only
-    float *__restrict__ J_inv,   // MODE 0: optional dense [P][n_init][9] (zeros for invalid); MODE 2: [P][n_init][9], valid entries only
-    unsigned long long *prof) {
-  __shared__ float s_T[IA_N_INIT_MAX][12];  // rows 0..2 of the init bones' transforms (same indexing as the 4x4)
-  __shared__ float4 s_ring[IA_SOLVE_WAVES][IA_RING];
-  __shared__ float4 s_del[IA_SOLVE_THREADS * 3];
-  if (n_pts_dev) P = min(P, *n_pts_dev);
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int e = tid; e < n_init * 12; e += IA_SOLVE_THREADS) s_T[e / 12][e % 12] = tfs[bones.id[e / 12] * 16 + e % 12];
-  __syncthreads();   // the only workgroup barrier
-  const int NC = ((P + 63) >> 6) * n_init;          // chunk c = (block of 64 points c / n_init, init c % n_init)
-  if (NC <= 0) return;
-  // every head owns the same number NH of indices j; index j of head h is chunk ((j >> 4) * 8 + h) * 16 + (j & 15)
-  const int NH = ((NC + (IA_HEADS << IA_CG_SHIFT) - 1) / (IA_HEADS << IA_CG_SHIFT)) << IA_CG_SHIFT;
-  const int taper = 2 * max(1, (int)(gridDim.x * IA_SOLVE_WAVES) / IA_HEADS);
-  float4 *const ring = s_ring[tid >> 6];
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-  // ---- wave-uniform supply state ----
-  int q_head = 0, q_tail = 0;                 // ring: monotonic consume / produce counters
-  int j_cur = 0, j_end = 0;                   // pulled range of the current head
-  int hh = blockIdx.x & (IA_HEADS - 1), tries = 0;
-  bool supply = true;
-
-  // ---- lane state machine (one solve per lane; `first`: the fetch at the initial guess) ----
-  bool active = false, first = false;
-  // `solves` counts the live ones; `fetches` every trilinear fetch of the reference's algorithm, `loaded` those that touched
-  // memory (packed: registers bound the waves per SIMD -- counts = fetches | loaded << 16; it_solves = iter | solves << 8)
-  int item = 0;
-  uint32_t counts = 0, it_solves = 0;
-  float t0 = 0, t1 = 0, t2 = 0;
-  float xl0 = 0, xl1 = 0, xl2 = 0, gx0 = 0, gx1 = 0, gx2 = 0, u0 = 0, u1 = 0, u2 = 0;
-  float Ji[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++) Ji[k] = 0.f;
-
-  while (true) {
-    // ---- keep >= 64 classified live items ahead of the lanes ----
-    while (supply && q_tail - q_head < 64) {
-      if (j_cur == j_end) {
-        bool got = false;
-        while (tries < IA_HEADS) {
-          int32_t *const hp = heads + hh * IA_HEAD_STRIDE;
-          // (a relaxed look first: an exhausted head costs a load, not a serialised atomic)
-          const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (seen < NH) {
-            const int n = min(max((NH - seen) / taper, 1), IA_GRAB_MAX);
-            int j0 = 0;
-            if (lane == 0) j0 = atomicAdd(hp, n);
-            j0 = __builtin_amdgcn_readfirstlane(j0);
-            if (j0 < NH) { j_cur = j0; j_end = min(j0 + n, NH); got = true; break; }
-          }
-          tries++; hh = (hh + 1) & (IA_HEADS - 1);
-        }
-        if (!got) { supply = false; break; }
-      }
-      const int j = j_cur++;
-      const int c = ((((j >> IA_CG_SHIFT) * IA_HEADS) + hh) << IA_CG_SHIFT) + (j & ((1 << IA_CG_SHIFT) - 1));
-      if (c >= NC) continue;
-      // ---- classification of chunk c (all 64 lanes) ----
-      // A solve whose INITIAL fetch has all 8 corners outside the grid is invalid by construction (ia_solve_is_trivial):
-      // J = 0 gives J_inv0 = 0, the update is 0, x never moves, the residual stays -x_d.  Most (point, init) pairs of the
-      // occupancy probes are of this kind; they get their flag here and never reach a lane of the solver.
-      const int blk = c / n_init, init = c - blk * n_init;
-      const int pt = (blk << 6) + lane;
-      bool live = false;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-      if (pt < P) {
-        a0 = xd[(size_t)pt * 3]; a1 = xd[(size_t)pt * 3 + 1]; a2 = xd[(size_t)pt * 3 + 2];
-        live = !ia_solve_is_trivial(g, s_T[init], a0, a1, a2);
-        if (!live) {
-          flags[(size_t)init * ppad + pt] = 0;
-          if (MODE == 0) {
-            const size_t o = (size_t)pt * n_init + init;
-            xout[o * 3] = 0.f; xout[o * 3 + 1] = 0.f; xout[o * 3 + 2] = 0.f;
-            if (J_inv) {
-#pragma unroll
-              for (int k = 0; k < 9; k++) J_inv[o * 9 + k] = 0.f;
-            }
-          }
-        }
-      }
-      const unsigned long long m = __ballot(live);
-      if (live) ring[(q_tail + __popcll(m & lt_mask)) & (IA_RING - 1)] = make_float4(a0, a1, a2, __int_as_float((pt << 4) | init));
-      q_tail += __popcll(m);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- refill idle lanes from the ring ----
-    {
-      const unsigned long long need = __ballot(!active);
-      const int avail = q_tail - q_head;
-      if (need && avail > 0) {
-        const int k = __popcll(need & lt_mask);
-        if (!active && k < avail) {
-          const float4 e = ring[(q_head + k) & (IA_RING - 1)];
-          item = __float_as_int(e.w);
-          t0 = e.x; t1 = e.y; t2 = e.z;
-          const float *T = s_T[item & 15];
-          // :287-293  x0 = R^T (xd - t)
-          const float ixd = t0 - T[3], iyd = t1 - T[7], izd = t2 - T[11];
-          xl0 = IA_DOT3(ixd, T[0], iyd, T[4], izd, T[8]);
-          xl1 = IA_DOT3(ixd, T[1], iyd, T[5], izd, T[9]);
-          xl2 = IA_DOT3(ixd, T[2], iyd, T[6], izd, T[10]);
-          active = true; first = true; it_solves = (it_solves & ~0xFFu) + 0x100u;
-        }
-        q_head += min(__popcll(need), avail);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (!__any(active)) break;   // every lane idle => the ring is empty, and it is only left empty when the supply is
-    const float ix = g.scl[0] * (xl0 + g.off[0]);
-    const float iy = g.scl[1] * (xl1 + g.off[1]);
-    const float iz = g.scl[2] * (xl2 + g.off[2]);
-    float Jl[12];
-    bool ld = false;
-    fetch_J_quad(vJ, g, ix, iy, iz, active, Jl, ld, s_del);   // all lanes: the quad serves its four fetches together
-    if (active) {
-      counts += ld ? 0x10001u : 1u;
-      bool done = false, ok = false;
-      // residual g(x) = J x + d - x_d at the current point (:325-332 initial, :356-367 updated)
-      const float n0 = IA_DOT3(Jl[0], xl0, Jl[1], xl1, Jl[2], xl2) + Jl[3] - t0;
-      const float n1 = IA_DOT3(Jl[4], xl0, Jl[5], xl1, Jl[6], xl2) + Jl[7] - t1;
-      const float n2 = IA_DOT3(Jl[8], xl0, Jl[9], xl1, Jl[10], xl2) + Jl[11] - t2;
-      if (first) {
-        // :302-311 J_inv0 = (J_3x3)^T
-        Ji[0] = Jl[0]; Ji[1] = Jl[4]; Ji[2] = Jl[8]; Ji[3] = Jl[1]; Ji[4] = Jl[5]; Ji[5] = Jl[9];
-        Ji[6] = Jl[2]; Ji[7] = Jl[6]; Ji[8] = Jl[10];
-        gx0 = n0; gx1 = n1; gx2 = n2;
-        first = false;
-      } else {
-        // :368-398 convergence / divergence tests
-        const float norm = IA_DOT3(n0, n0, n1, n1, n2, n2);
-        if (norm < cvg2) {
-          done = true;
-          ok = ix >= -1 && ix <= 1 && iy >= -1 && iy <= 1 && iz >= -1 && iz <= 1;
-        } else if (norm > dvg2) {
-          done = true;
-        } else {
-          jinv_update(Ji, u0, u1, u2, n0 - gx0, n1 - gx1, n2 - gx2);  // :400-411
-          gx0 = n0; gx1 = n1; gx2 = n2;
-          if ((++it_solves & 0xFFu) == 10u) done = true;  // Q1: not converged after 10 iterations -> invalid
-        }
-      }
-      if (done) {
-        const int init = item & 15, pt = item >> 4;
-        flags[(size_t)init * ppad + pt] = ok;
-        if (MODE == 0) {
-          const size_t o = (size_t)pt * n_init + init;
-          xout[o * 3] = ok ? xl0 : 0.f; xout[o * 3 + 1] = ok ? xl1 : 0.f; xout[o * 3 + 2] = ok ? xl2 : 0.f;
-          if (J_inv) {   // Q4: the stored J_inv is the matrix BEFORE the last rank-1 update (:383-391)
-#pragma unroll
-            for (int k = 0; k < 9; k++) J_inv[o * 9 + k] = ok ? Ji[k] : 0.f;
-          }
-        } else if (ok) {
-          const size_t o = ((size_t)init * ppad + pt) * 3;
-          xout[o] = xl0; xout[o + 1] = xl1; xout[o + 2] = xl2;
-          if (MODE == 2) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) J_inv[((size_t)pt * n_init + init) * 9 + k] = Ji[k];  // Q4 as above
-          }
-        }
-        active = false;
-      } else {
-        // :340-351 update = -J_inv g ; x += update (start of the next iteration)
-        u0 = IA_DOT3(-Ji[0], gx0, -Ji[1], gx1, -Ji[2], gx2);
-        u1 = IA_DOT3(-Ji[3], gx0, -Ji[4], gx1, -Ji[5], gx2);
-        u2 = IA_DOT3(-Ji[6], gx0, -Ji[7], gx1, -Ji[8], gx2);
-        xl0 += u0; xl1 += u1; xl2 += u2;
-      }
-    }
-  }
-  if (prof) {  // bench-only accounting: solves and trilinear fetches, one set of atomics per wave on a per-shard line
-    int f = (int)(counts & 0xFFFFu), n = (int)(it_solves >> 8), l = (int)(counts >> 16);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); l += __shfl_xor(l, o, 64); }
-    if (lane == 0) {
-      unsigned long long *ps = prof + (size_t)((blockIdx.x * IA_SOLVE_WAVES + (tid >> 6)) & (IA_PROF_SHARDS - 1)) * 8;
-      atomicAdd(ps, (unsigned long long)n);
-      atomicAdd(ps + 1, (unsigned long long)f);
-      atomicAdd(ps + 2, (unsigned long long)l);
-    }
-  }
-}
-
-// resets the work heads (and the candidate counter when asked) ahead of k_solve
-__global__ void k_search_reset(int32_t *heads, int32_t *n_cand) {
-  if (threadIdx.x < IA_HEADS) heads[threadIdx.x * IA_HEAD_STRIDE] = 0;
-  if (threadIdx.x == 0 && n_cand) *n_cand = 0;
-}
-
-// ---- a5 filter (filter.cu:27-51: drop i if a LATER valid candidate lies within 1e-4) + outputs ------------------------------
-#define IA_ROOTS_THREADS 256
-template <int MODE>
-__global__ __launch_bounds__(IA_ROOTS_THREADS) void k_roots(
-    int P, const int32_t *__restrict__ n_pts_dev, int n_init, const uint8_t *__restrict__ flags, size_t ppad,
-    const float *__restrict__ xin,       // MODE 0: xc [P][n_init][3] (in place); MODE 1/2: roots [n_init][ppad][3]
-    uint8_t *__restrict__ valid_out, uint8_t *__restrict__ valid_raw,            // MODE 0
-    float *__restrict__ cand_xc, int cand_cap, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
-    int32_t *__restrict__ n_cand, const float *__restrict__ jinv_dense, float *__restrict__ cand_Jinv) {
-  __shared__ int s_wtot[IA_ROOTS_THREADS / 64];
-  __shared__ int s_blockbase;
-  if (n_pts_dev) P = min(P, *n_pts_dev);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int pt = blockIdx.x * IA_ROOTS_THREADS + tid;
-  if (blockIdx.x * IA_ROOTS_THREADS >= P) return;   // uniform per workgroup
-  uint32_t m = 0;
-  float x[IA_N_INIT_MAX][3];
-  if (pt < P) {
-#pragma unroll
-    for (int i = 0; i < IA_N_INIT_MAX; i++) {
-      x[i][0] = 0.f; x[i][1] = 0.f; x[i][2] = 0.f;
-      if (i < n_init && flags[(size_t)i * ppad + pt]) {
-        m |= 1u << i;
-        const float *p = MODE == 0 ? xin + ((size_t)pt * n_init + i) * 3 : xin + ((size_t)i * ppad + pt) * 3;
-        x[i][0] = p[0]; x[i][1] = p[1]; x[i][2] = p[2];
-      }
-    }
-  }
-  uint32_t keep = m;
-#pragma unroll
-  for (int i = 0; i < IA_N_INIT_MAX; i++) {
-    if (!((m >> i) & 1u)) continue;
-#pragma unroll
-    for (int j = i + 1; j < IA_N_INIT_MAX; j++) {
-      if (!((m >> j) & 1u)) continue;
-      const float d0 = x[i][0] - x[j][0], d1 = x[i][1] - x[j][1], d2 = x[i][2] - x[j][2];
-      const float dist = IA_DOT3(d0, d0, d1, d1, d2, d2);
-      if ((double)dist < 0.0001 * 0.0001) keep &= ~(1u << i);
-    }
-  }
-  if (MODE == 0) {
-    if (pt < P) {
-      for (int i = 0; i < n_init; i++) {
-        valid_out[(size_t)pt * n_init + i] = (keep >> i) & 1u;
-        if (valid_raw) valid_raw[(size_t)pt * n_init + i] = (m >> i) & 1u;
-      }
-    }
-    return;
-  }
-  // ---- compaction: per-point counts, workgroup scan, ONE global atomic per workgroup ----
-  const int cnt = __popc(keep);
-  int wtot;
-  const int excl = ia_wave_excl_scan(cnt, wtot);
-  if (lane == 0) s_wtot[tid >> 6] = wtot;
-  __syncthreads();
-  if (tid == 0) {
-    int tot = 0;
-    for (int w = 0; w < IA_ROOTS_THREADS / 64; w++) { const int c = s_wtot[w]; s_wtot[w] = tot; tot += c; }
-    s_blockbase = tot > 0 ? atomicAdd(n_cand, tot) : 0;
-  }
-  __syncthreads();
-  if (pt >= P) return;
-  const int base = s_blockbase + s_wtot[tid >> 6] + excl;
-  pt_off[pt] = base;
-  pt_cnt[pt] = (uint8_t)cnt;
-  int rank = 0;
-#pragma unroll
-  for (int i = 0; i < IA_N_INIT_MAX; i++) {
-    if (!((keep >> i) & 1u)) continue;
-    const int o = base + rank++;
-    if (o < cand_cap) {
-      cand_xc[(size_t)o * 3] = x[i][0]; cand_xc[(size_t)o * 3 + 1] = x[i][1]; cand_xc[(size_t)o * 3 + 2] = x[i][2];
-      if (MODE == 2) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) cand_Jinv[(size_t)o * 9 + k] = jinv_dense[((size_t)pt * n_init + i) * 9 + k];
-      }
-    }
-  }
-}
-
-// =====================================================================================================================
-// The workgroup-queue kernel of rounds 2-3 (ia_search_set_impl(0)): kept for the A/B against k_solve.
-// =====================================================================================================================
 // ---------------------------------------------------------------------------
 // a4 + a5 search kernel with LANE REFILL.
 //
@@ -581,7 +291,6 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
   }
 }
 
-
 __global__ void k_zero_i32(int32_t *p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -590,90 +299,21 @@ __global__ void k_zero_i32(int32_t *p, int n) {
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-static int g_search_impl = 1;        // 1: persistent waves (k_solve + k_roots), 0: workgroup queues (k_search)
-static int g_solve_grid[3] = {0, 0, 0};
-
-extern "C" int ia_search_set_impl(int impl) {
-  IA_CHECK_ARG(impl == 0 || impl == 1, "ia_search_set_impl: 0 (workgroup queues) or 1 (persistent waves)");
-  g_search_impl = impl;
-  return IA_OK;
-}
-extern "C" int ia_search_get_impl(void) { return g_search_impl; }
-
-struct SearchWs { int32_t *heads; uint8_t *flags; float *roots; float *jinv; size_t ppad; };
-static size_t search_ppad(int P) { return ((size_t)(P > 0 ? P : 1) + 63) / 64 * 64; }
-
-// mode 0: ia_snarf_search (dense layout); 1: ia_snarf_search_compact; 2: ia_snarf_search_compact_jinv
-extern "C" size_t ia_snarf_search_workspace_bytes(int P, int n_init, int mode) {
-  if (P <= 0 || n_init <= 0 || n_init > IA_N_INIT_MAX || mode < 0 || mode > 2) return 0;
-  const size_t ppad = search_ppad(P);
-  size_t b = ia_align((size_t)IA_HEADS * IA_HEAD_STRIDE * sizeof(int32_t)) + ia_align(ppad * n_init);
-  if (mode >= 1) b += ia_align(ppad * n_init * 3 * sizeof(float));
-  if (mode == 2) b += ia_align((size_t)P * n_init * 9 * sizeof(float));
-  return b;
-}
-static SearchWs carve_search(void *ws, int P, int n_init, int mode) {
-  WsCarver w(ws, (size_t)-1);
-  SearchWs q;
-  q.ppad = search_ppad(P);
-  q.heads = w.take<int32_t>(IA_HEADS * IA_HEAD_STRIDE);
-  q.flags = w.take<uint8_t>(q.ppad * n_init);
-  q.roots = mode >= 1 ? w.take<float>(q.ppad * n_init * 3) : nullptr;
-  q.jinv = mode == 2 ? w.take<float>((size_t)P * n_init * 9) : nullptr;
-  return q;
-}
-
-// resident workgroups of k_solve on the whole device (queried once per mode; the launch never exceeds what the work needs)
-template <int MODE> static int solve_grid(int P, int n_init) {
-  if (!g_solve_grid[MODE]) {
-    int nb = 0, dev = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_solve<MODE>), IA_SOLVE_THREADS, 0);
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    g_solve_grid[MODE] = (nb > 0 ? nb : 4) * (cus > 0 ? cus : 256);
-  }
-  // at least two chunks per wave, or the launch is all supply traffic
-  const long chunks = ((long)P + 63) / 64 * n_init;
-  const long want = (chunks + 2 * IA_SOLVE_WAVES - 1) / (2 * IA_SOLVE_WAVES);
-  return (int)(want < 1 ? 1 : (want < g_solve_grid[MODE] ? want : g_solve_grid[MODE]));
-}
-
-static int search_check_ws(const char *who, int P, int n_init, int mode, const void *ws, size_t ws_bytes) {
-  const size_t need = ia_snarf_search_workspace_bytes(P, n_init, mode);
-  if (!ws || ws_bytes < need) return ia_set_error(IA_ERR_WORKSPACE, "%s: workspace of %zu bytes, %zu needed (ia_snarf_search_workspace_bytes)", who, ws_bytes, need);
-  return IA_OK;
-}
-
 extern "C" int ia_snarf_search(const float *xd, int P, const float *voxel_J, const float *tfs,
                                const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
                                float cvg_thresh, float dvg_thresh, float *xc, uint8_t *valid,
-                               uint8_t *valid_raw, float *J_inv, void *ws, size_t ws_bytes, void *stream) {
+                               uint8_t *valid_raw, float *J_inv, void *stream) {
   IA_CHECK_ARG(P >= 0, "ia_snarf_search: P < 0");
   if (P == 0) return IA_OK;
   IA_CHECK_ARG(xd && voxel_J && tfs && grid && xc && valid, "ia_snarf_search: null pointer");
   BoneIds b;
   IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "ia_snarf_search: bad bone ids / n_init=%d", n_init);
-  hipStream_t s = (hipStream_t)stream;
-  const SnarfGridDev g = ia_make_grid_dev(grid);
-  if (g_search_impl == 0) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0, s, xd, P,
-                       (const int32_t *)nullptr, voxel_J, tfs, b, n_init, g, cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
-                       valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
-                       (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr, (float *)nullptr);
-    IA_LAUNCH_CHECK("k_search<0>");
-    return IA_OK;
-  }
-  int rc = search_check_ws("ia_snarf_search", P, n_init, 0, ws, ws_bytes);
-  if (rc) return rc;
-  const SearchWs q = carve_search(ws, P, n_init, 0);
-  hipLaunchKernelGGL(k_search_reset, dim3(1), dim3(64), 0, s, q.heads, (int32_t *)nullptr);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<0>), dim3(solve_grid<0>(P, n_init)), dim3(IA_SOLVE_THREADS), 0, s, xd, P,
-                     (const int32_t *)nullptr, voxel_J, tfs, b, n_init, g, cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh,
-                     q.heads, q.flags, q.ppad, xc, J_inv, (unsigned long long *)nullptr);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roots<0>), dim3(ia_div_up(P, IA_ROOTS_THREADS)), dim3(IA_ROOTS_THREADS), 0, s, P,
-                     (const int32_t *)nullptr, n_init, q.flags, q.ppad, xc, valid, valid_raw, (float *)nullptr, 0,
-                     (int32_t *)nullptr, (uint8_t *)nullptr, (int32_t *)nullptr, (const float *)nullptr, (float *)nullptr);
-  IA_LAUNCH_CHECK("k_solve<0>");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<0>), dim3(ia_div_up(P, IA_SEARCH_NP)), dim3(IA_SEARCH_THREADS), 0,
+                     (hipStream_t)stream, xd, P, (const int32_t *)nullptr, voxel_J, tfs, b, n_init,
+                     ia_make_grid_dev(grid), cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, xc, valid,
+                     valid_raw, J_inv, (float *)nullptr, 0, (int32_t *)nullptr, (uint8_t *)nullptr,
+                     (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr, (float *)nullptr);
+  IA_LAUNCH_CHECK("k_search<0>");
   return IA_OK;
 }
 
@@ -681,56 +321,29 @@ static int ia_search_compact_impl(const char *who, const float *xd, int P, const
                                   const float *tfs, const int32_t *bone_ids, int n_init, const ia_snarf_grid *grid,
                                   float cvg_thresh, float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
                                   int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, bool with_jinv,
-                                  void *ws, size_t ws_bytes, hipStream_t s) {
+                                  hipStream_t s, float *jinv_dense = nullptr) {
   IA_CHECK_ARG(P >= 0, "%s: P < 0", who);
   IA_CHECK_ARG(n_cand, "%s: n_cand is null", who);
-  if (P == 0) {
-    if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
-    return IA_OK;
-  }
+  if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
+  if (P == 0) return IA_OK;
   IA_CHECK_ARG(xd && voxel_J && tfs && grid && cand_xc && pt_off && pt_cnt && (cand_Jinv || !with_jinv), "%s: null pointer", who);
   BoneIds b;
   IA_CHECK_ARG(ia_make_bones(bone_ids, n_init, &b) == 0, "%s: bad bone ids / n_init=%d", who, n_init);
-  const int mode = with_jinv ? 2 : 1;
-  int rc = search_check_ws(who, P, n_init, mode, ws, ws_bytes);
-  if (rc) return rc;
-  const SearchWs q = carve_search(ws, P, n_init, mode);
+  const dim3 grd(ia_div_up(P, IA_SEARCH_NP)), blk(IA_SEARCH_THREADS);
   const SnarfGridDev g = ia_make_grid_dev(grid);
-  const float cvg2 = cvg_thresh * cvg_thresh, dvg2 = dvg_thresh * dvg_thresh;
-  if (g_search_impl == 0) {
-    if (zero_counter) { hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, n_cand, 1); IA_LAUNCH_CHECK("k_zero_i32"); }
-    const dim3 grd(ia_div_up(P, IA_SEARCH_NP)), blk(IA_SEARCH_THREADS);
-    ia_prof_begin(IA_PROF_SEARCH, s);
-    if (with_jinv)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<2>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g, cvg2, dvg2,
-                         (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off,
-                         pt_cnt, n_cand, ia_prof_units(IA_PROF_SEARCH), cand_Jinv, q.jinv);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g, cvg2, dvg2,
-                         (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off,
-                         pt_cnt, n_cand, ia_prof_units(IA_PROF_SEARCH), (float *)nullptr, (float *)nullptr);
-    ia_prof_end(IA_PROF_SEARCH, s);
-    IA_LAUNCH_CHECK("k_search<compact>");
-    return IA_OK;
-  }
-  hipLaunchKernelGGL(k_search_reset, dim3(1), dim3(64), 0, s, q.heads, zero_counter ? n_cand : (int32_t *)nullptr);
   ia_prof_begin(IA_PROF_SEARCH, s);
   if (with_jinv)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<2>), dim3(solve_grid<2>(P, n_init)), dim3(IA_SOLVE_THREADS), 0, s, xd, P, n_pts_dev,
-                       voxel_J, tfs, b, n_init, g, cvg2, dvg2, q.heads, q.flags, q.ppad, q.roots, q.jinv, ia_prof_units(IA_PROF_SEARCH));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<2>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
+                       cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
+                       (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
+                       ia_prof_units(IA_PROF_SEARCH), cand_Jinv, jinv_dense);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<1>), dim3(solve_grid<1>(P, n_init)), dim3(IA_SOLVE_THREADS), 0, s, xd, P, n_pts_dev,
-                       voxel_J, tfs, b, n_init, g, cvg2, dvg2, q.heads, q.flags, q.ppad, q.roots, (float *)nullptr,
-                       ia_prof_units(IA_PROF_SEARCH));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_search<1>), grd, blk, 0, s, xd, P, n_pts_dev, voxel_J, tfs, b, n_init, g,
+                       cvg_thresh * cvg_thresh, dvg_thresh * dvg_thresh, (float *)nullptr, (uint8_t *)nullptr,
+                       (uint8_t *)nullptr, (float *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand,
+                       ia_prof_units(IA_PROF_SEARCH), (float *)nullptr, (float *)nullptr);
   ia_prof_end(IA_PROF_SEARCH, s);
-  const dim3 rg(ia_div_up(P, IA_ROOTS_THREADS)), rb(IA_ROOTS_THREADS);
-  if (with_jinv)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roots<2>), rg, rb, 0, s, P, n_pts_dev, n_init, q.flags, q.ppad, q.roots, (uint8_t *)nullptr,
-                       (uint8_t *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand, q.jinv, cand_Jinv);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roots<1>), rg, rb, 0, s, P, n_pts_dev, n_init, q.flags, q.ppad, q.roots, (uint8_t *)nullptr,
-                       (uint8_t *)nullptr, cand_xc, cand_cap, pt_off, pt_cnt, n_cand, (const float *)nullptr, (float *)nullptr);
-  IA_LAUNCH_CHECK("k_solve<compact>");
+  IA_LAUNCH_CHECK("k_search<compact>");
   return IA_OK;
 }
 
@@ -738,11 +351,14 @@ extern "C" int ia_snarf_search_compact(const float *xd, int P, const int32_t *n_
                                        const float *voxel_J, const float *tfs, const int32_t *bone_ids,
                                        int n_init, const ia_snarf_grid *grid, float cvg_thresh,
                                        float dvg_thresh, float *cand_xc, int32_t cand_cap, int32_t *pt_off,
-                                       uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, void *ws, size_t ws_bytes,
-                                       void *stream) {
+                                       uint8_t *pt_cnt, int32_t *n_cand, int zero_counter, void *stream) {
   return ia_search_compact_impl("ia_snarf_search_compact", xd, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid, cvg_thresh,
-                                dvg_thresh, cand_xc, nullptr, cand_cap, pt_off, pt_cnt, n_cand, zero_counter, false, ws, ws_bytes,
+                                dvg_thresh, cand_xc, nullptr, cand_cap, pt_off, pt_cnt, n_cand, zero_counter, false,
                                 (hipStream_t)stream);
+}
+
+extern "C" size_t ia_snarf_search_jinv_workspace_bytes(int P, int n_init) {
+  return P > 0 && n_init > 0 ? (size_t)P * (size_t)n_init * 9 * sizeof(float) : 0;
 }
 
 extern "C" int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_t *n_pts_dev,
@@ -751,9 +367,11 @@ extern "C" int ia_snarf_search_compact_jinv(const float *xd, int P, const int32_
                                             float dvg_thresh, float *cand_xc, float *cand_Jinv, int32_t cand_cap,
                                             int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int zero_counter,
                                             void *ws, size_t ws_bytes, void *stream) {
+  IA_CHECK_ARG(P <= 0 || (ws && ws_bytes >= ia_snarf_search_jinv_workspace_bytes(P, n_init)),
+               "ia_snarf_search_compact_jinv: workspace of %zu bytes, %zu needed", ws_bytes, ia_snarf_search_jinv_workspace_bytes(P, n_init));
   return ia_search_compact_impl("ia_snarf_search_compact_jinv", xd, P, n_pts_dev, voxel_J, tfs, bone_ids, n_init, grid,
                                 cvg_thresh, dvg_thresh, cand_xc, cand_Jinv, cand_cap, pt_off, pt_cnt, n_cand, zero_counter,
-                                true, ws, ws_bytes, (hipStream_t)stream);
+                                true, (hipStream_t)stream, static_cast<float *>(ws));
 }
 
 // ---- device self-tests of the shared-reciprocal division (called by tests/ only; they launch the SAME device functions
@@ -806,7 +424,7 @@ extern "C" int ia_selftest_jinv_update(const float *Ji, const float *x, const fl
 // resident workgroups per CU the runtime computes from them.
 extern "C" int ia_search_kernel_info(int *vgprs, int *lds_bytes, int *threads, int *workgroups_per_cu) {
   hipFuncAttributes a;
-  const void *fn = g_search_impl ? reinterpret_cast<const void *>(&k_solve<1>) : reinterpret_cast<const void *>(&k_search<1>);
+  const void *fn = reinterpret_cast<const void *>(&k_search<1>);
   if (hipFuncGetAttributes(&a, fn) != hipSuccess) return ia_set_error(IA_ERR_LAUNCH, "ia_search_kernel_info: hipFuncGetAttributes failed");
   int nb = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, IA_SEARCH_THREADS, 0);

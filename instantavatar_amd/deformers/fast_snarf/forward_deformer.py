@@ -133,11 +133,9 @@ class ForwardDeformer(torch.nn.Module):
         xc, valid = mk((1, n, k, 3), torch.float32), mk((1, n, k), torch.uint8)
         J_inv = mk((1, n, k, 3, 3), torch.float32) if want_J_inv else None
         xd_c, tfs_c = xd_tgt.detach().float().contiguous(), tfs.detach().float().contiguous()
-        ws = _lib.scratch(self, "_ws_search", int(_lib.lib().ia_snarf_search_workspace_bytes(n, k, 0)), xd_tgt.device)
         _lib.check(_lib.lib().ia_snarf_search(_lib.ptr(xd_c), n, _lib.ptr(voxel_J_cl), _lib.ptr(tfs_c), self._bones_c, k,
                                               C.byref(self.grid_desc()), cvg_thresh, dvg_thresh, _lib.ptr(xc),
-                                              _lib.ptr(valid), None, _lib.ptr(J_inv), _lib.ptr(ws), ws.numel(), _lib.stream()),
-                   "ia_snarf_search")
+                                              _lib.ptr(valid), None, _lib.ptr(J_inv), _lib.stream()), "ia_snarf_search")
         return {"result": xc, "valid_ids": valid.bool(), "J_inv": J_inv}
 
     def search(self, xd, cond, tfs, eval_mode=False, want_J_inv=True):

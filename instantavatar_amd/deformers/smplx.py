@@ -104,8 +104,21 @@ class SMPL(nn.Module):
             if os.path.exists(p):
                 if p.endswith(".npz"):
                     return dict(np.load(p, allow_pickle=True))
-                with open(p, "rb") as f:
-                    d = pickle.load(f, encoding="latin1")
+                try:
+                    with open(p, "rb") as f:
+                        d = pickle.load(f, encoding="latin1")
+                except ModuleNotFoundError as e:
+                    # the SMPL 1.0 pickles of the SMPL / SMPLify releases store their arrays as chumpy objects: unpickling
+                    # imports chumpy (the reference has it installed, requirements of smplx); it is not needed afterwards
+                    if "chumpy" in str(e):
+                        raise ImportError(
+                            "%s stores its arrays as chumpy objects and `chumpy` is not installed.  Either install chumpy "
+                            "(as the reference's environment does), or convert the file once where chumpy is available: "
+                            "`d = pickle.load(open(p, 'rb'), encoding='latin1'); np.savez(p[:-4] + '.npz', **{k: "
+                            "(v.toarray() if hasattr(v, 'toarray') else np.asarray(v)) for k, v in d.items() if k in "
+                            "('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'kintree_table', 'weights', 'f')})` -- "
+                            "SMPL_<GENDER>.npz next to the .pkl is picked up first." % p) from e
+                    raise
                 out = {}
                 for k, v in d.items():
                     if hasattr(v, "toarray"):  # scipy sparse J_regressor

@@ -358,14 +358,14 @@ class SNARFDeformer():
         head = (_lib.ptr(pts), P, _lib.ptr(n_pts_dev), _lib.ptr(self.deformer.voxel_J_cl), _lib.ptr(tfs),
                 self.deformer._bones_c, k, C.byref(self.deformer.grid_desc()), 1e-5, 1e-1, _lib.ptr(out["cand_xc"]))
         tail = (cap, _lib.ptr(out["pt_off"]), _lib.ptr(out["pt_cnt"]), _lib.ptr(out["n_cand"]), 0)
-        # scratch of the persistent search: work heads, one flag per (init, point), the roots before the filter (+ their J_inv)
-        ws = _lib.scratch(self, "_ws_search", int(L.ia_snarf_search_workspace_bytes(P, k, 2 if want_J_inv else 1)), dev)
         if want_J_inv:
             out["cand_Jinv"] = torch.empty((cap, 3, 3), device=dev)
+            # J_inv of the valid solves before compaction (P x 13 x 36 B)
+            ws = _lib.scratch(self, "_ws_jinv", int(L.ia_snarf_search_jinv_workspace_bytes(P, k)), dev)
             _lib.check(L.ia_snarf_search_compact_jinv(*head, _lib.ptr(out["cand_Jinv"]), *tail, _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "ia_snarf_search_compact_jinv")
         else:
-            _lib.check(L.ia_snarf_search_compact(*head, *tail, _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_search_compact")
+            _lib.check(L.ia_snarf_search_compact(*head, *tail, _lib.stream()), "ia_snarf_search_compact")
         return out
 
     def candidates_with_grad(self, sc):

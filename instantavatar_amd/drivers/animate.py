@@ -91,11 +91,24 @@ def build_model(args, device):
     return model, betas
 
 
+def write_frames(frames, out_dir, gif=None):
+    """8-bit [H, W, 4] frames in the MODEL's channel order -> `<i>.png` (+ optionally one GIF) with the colours the reference's
+    files have.  The reference writes with cv2.imwrite (animate.py:113), which takes channel 0 as BLUE: the model's channels are
+    in the (B, G, R) order of the cv2.imread training images (peoplesnapshot.py:100), so its files hold the intended colours;
+    for the GIF it converts BGRA -> RGBA first (:115).  PIL takes channel 0 as RED: the same reorder serves both."""
+    from PIL import Image
+    os.makedirs(out_dir, exist_ok=True)
+    frames = [np.ascontiguousarray(np.asarray(f)[..., [2, 1, 0, 3]]) for f in frames]
+    for i, f in enumerate(frames):
+        Image.fromarray(f, "RGBA").save(os.path.join(out_dir, "%d.png" % i))
+    if gif and frames:
+        ims = [Image.fromarray(f, "RGBA") for f in frames]
+        ims[0].save(os.path.join(out_dir, gif), save_all=True, append_images=ims[1:], duration=33, loop=0)
+
+
 def render_sequence(model, seq, out_dir, gif="animation.gif"):
     """animate.py:104-118 / novel_view.py:117-127: every batch of `seq` through render_image_fast (replayed from one captured
     HIP graph), RGBA = [rgb, alpha] * 255 as 8-bit PNGs `<i>.png`, optionally a GIF of all frames.  Returns the frame count."""
-    os.makedirs(out_dir, exist_ok=True)
-    from PIL import Image
     size = (seq.H, seq.W)
     renderer = GraphedRenderer(model, seq.batch(0), size)
     frames = []
@@ -108,11 +121,7 @@ def render_sequence(model, seq, out_dir, gif="animation.gif"):
     for i in renderer.incomplete_calls:  # frames whose loop needed more iterations than the graph holds
         rgb, _, alpha, _ = model.render_image_fast(seq.batch(i), size)
         frames[i] = (torch.cat([rgb, alpha[..., None]], dim=-1)[0].clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
-    for i, f in enumerate(frames):
-        Image.fromarray(f, "RGBA").save(os.path.join(out_dir, "%d.png" % i))
-    if gif and frames:
-        ims = [Image.fromarray(f, "RGBA") for f in frames]
-        ims[0].save(os.path.join(out_dir, gif), save_all=True, append_images=ims[1:], duration=33, loop=0)
+    write_frames(frames, out_dir, gif)
     return len(frames)
 
 

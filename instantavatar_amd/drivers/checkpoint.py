@@ -28,8 +28,10 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
     enc = sd.get("net_coarse.encoder.params")
     if enc is not None and hasattr(net, "adopt_tcnn_layout") and enc.numel() != net.encoder.params.numel():
         # a checkpoint written with the OTHER of tcnn's two possible level tables: follow it (decided by the vector's size)
-        r3 = net.adopt_tcnn_layout(enc.numel())
+        r3 = net.adopt_tcnn_layout(enc.numel())     # resizes `encoder.params` in place: the Parameter object is kept
         print("load_checkpoint: encoder.params has %d elements -> tcnn layout with level-3 resolution %d adopted" % (enc.numel(), r3))
+        if optimizer is not None:                   # moments of the old shape must not meet a gradient of the new one
+            optimizer.state.pop(net.encoder.params, None)
     own = model.state_dict()
     take = {}
     unexpected = []
@@ -59,7 +61,15 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
         if hasattr(net, "mark_updated"):
             net.mark_updated()
         if hasattr(net, "self_check") and net.encoder.params.is_cuda and "net_coarse.encoder.params" in take:
-            model.tcnn_self_check = net.self_check()   # finite, no constant level: a shifted layout would show here
+            # finite, no constant level: a shifted layout would show here.  A REPORT, not a gate: the state is already
+            # committed at this point, and a legitimately degenerate field (tiny coarse levels, a collapsed bbox) must stay
+            # loadable -- callers that want a hard failure call net.self_check() themselves
+            try:
+                model.tcnn_self_check = net.self_check()
+            except ValueError as e:
+                import warnings
+                model.tcnn_self_check = {"failed": str(e)}
+                warnings.warn("load_checkpoint: %s" % e)
     for g in ("density_grid_train", "density_grid_test"):
         grid = getattr(getattr(model, "renderer", None), g, None)
         if grid is not None and hasattr(grid, "pack_bits") and grid.density_field.is_cuda:

@@ -128,7 +128,13 @@ class NeRFNGPNet(nn.Module):
             dev = self.encoder.params.device
             self.hash_desc = _lib.make_hash_desc(self.n_levels, self.log2_T, BASE_RES, PER_LEVEL_SCALE, level3_res=r3)
             self.n_entries = int(self.hash_desc.offset[self.n_levels])
-            self.encoder = _TcnnParams(self.sig_w1_size + SIG_W2 + 2 * self.n_entries).to(dev)
+            # resized IN PLACE: the Parameter object stays the one an optimiser (built before the load: drivers/train.py
+            # --resume), a DDP-style reducer or a captured graph's owner already holds -- a new module here would leave them
+            # with an orphan and the live table would never be updated.  Stale per-parameter optimiser state of
+            # the old shape is the caller's to drop (load_checkpoint does, before it restores the checkpoint's own).
+            p = self.encoder.params
+            p.data = torch.zeros(self.sig_w1_size + SIG_W2 + 2 * self.n_entries, dtype=torch.float32, device=dev)
+            p.grad = None
             self._half = self._half_key = self._desc = None
             self.reset_parameters()
         self.tcnn_level3_res = r3

@@ -444,11 +444,37 @@ void orc_hashgrid(const orc_field *f, const float *x, long V, uint16_t *feat) {
 
 /* a11  FullyFusedMLP layer: y = act(W x), W fp16 [out][in] row-major,        */
 /* x fp16, fp32 accumulate, result rounded to fp16.  act: 0 none, 1 relu.     */
+/* Accumulation mode (orc_set_mlp_half_accumulate): 0 (default, what the HIP  */
+/* kernels do) = one fp32 accumulator over the whole reduction; 1 = the        */
+/* accumulator tcnn v1.6 DECLARES (fully_fused_mlp.cu: wmma accumulator        */
+/* fragments of __half, one mma_sync per 16-wide k block): the running sum is  */
+/* rounded to half after every block of 16 products (the products of a block   */
+/* are summed wide inside the tensor core).  Used to SIZE the documented       */
+/* deviation, not as the parity target: the tensor core's */
+/* internal summation order is not specified.                                  */
+static int g_mlp_half_acc = 0;
+void orc_set_mlp_half_accumulate(int on) { g_mlp_half_acc = on != 0; }
+int orc_get_mlp_half_accumulate(void) { return g_mlp_half_acc; }
+
+static float orc_dot_acc(const uint16_t *w, const uint16_t *x, int in) {
+  if (!g_mlp_half_acc) {
+    float acc = 0.f;
+    for (int k = 0; k < in; k++) acc += h2f(w[k]) * h2f(x[k]);
+    return acc;
+  }
+  uint16_t acc_h = f2h(0.f);
+  for (int k0 = 0; k0 < in; k0 += 16) {
+    float s = h2f(acc_h);
+    for (int k = k0; k < k0 + 16 && k < in; k++) s += h2f(w[k]) * h2f(x[k]);
+    acc_h = f2h(s);
+  }
+  return h2f(acc_h);
+}
+
 static void orc_dense(const uint16_t *Wt, int out, int in, const uint16_t *x,
                       int act, uint16_t *y) {
   for (int o = 0; o < out; o++) {
-    float acc = 0.f;
-    for (int k = 0; k < in; k++) acc += h2f(Wt[o * in + k]) * h2f(x[k]);
+    float acc = orc_dot_acc(Wt + o * in, x, in);
     if (act == 1 && acc < 0.f) acc = 0.f;
     y[o] = f2h(acc);
   }
@@ -471,8 +497,7 @@ void orc_field_fwd(const orc_field *f, const float *x, long V, float *rgb,
     orc_dense(f->col_w1, 64, 16, cin, 1, c1);
     orc_dense(f->col_w2, 64, 64, c1, 1, c2);
     for (int o = 0; o < 3; o++) {
-      float acc = 0.f;
-      for (int k = 0; k < 64; k++) acc += h2f(f->col_w3[o * 64 + k]) * h2f(c2[k]);
+      float acc = orc_dot_acc(f->col_w3 + o * 64, c2, 64);
       float s = 1.0f / (1.0f + expf(-acc)); /* tcnn logistic */
       rgb[i * 3 + o] = h2f(f2h(s));
     }
@@ -504,8 +529,7 @@ void orc_tcnn_color(const orc_field *f, const float *in15, long V, float *rgb) {
     orc_dense(f->col_w1, 64, 16, cin, 1, c1);
     orc_dense(f->col_w2, 64, 64, c1, 1, c2);
     for (int o = 0; o < 3; o++) {
-      float acc = 0.f;
-      for (int k = 0; k < 64; k++) acc += h2f(f->col_w3[o * 64 + k]) * h2f(c2[k]);
+      float acc = orc_dot_acc(f->col_w3 + o * 64, c2, 64);
       float s = 1.0f / (1.0f + expf(-acc));
       rgb[i * 3 + o] = h2f(f2h(s));
     }

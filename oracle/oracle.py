@@ -437,6 +437,15 @@ def make_world(body, init, field_params, betas, body_pose, global_orient, transl
                 bone_ids=np.asarray(bone_ids, np.int32))
 
 
+def set_mlp_half_accumulate(on):
+    """MLP accumulation mode of the field restatement: False (default) = fp32 accumulators (what the HIP kernels do), True = the
+    running sum rounded to half after every 16-wide k block (tcnn v1.6 declares __half wmma accumulators).  Returns the old mode."""
+    L = lib()
+    old = bool(L.orc_get_mlp_half_accumulate())
+    L.orc_set_mlp_half_accumulate(1 if on else 0)
+    return old
+
+
 def render_image_fast(world, rays_o, rays_d, jitter, G=64, **kw):
     """DNeRFModel.render_image_fast (models/DNeRF.py:72-97) for one frame."""
     aabb, density, occ = density_grid_initialize(world, jitter, G)

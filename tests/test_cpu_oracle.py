@@ -185,6 +185,35 @@ def small_world(oracle):
     return body, init, fp, world
 
 
+def test_mlp_half_accumulate_mode_sizes_the_tcnn_deviation(oracle, small_world):
+    """DESIGN.md section 2's one documented deviation from tiny-cuda-nn v1.6: fp32 MLP accumulators here, __half wmma
+    accumulators there.  The oracle can run both (`set_mlp_half_accumulate`): the default mode is untouched, the half mode
+    rounds the running sum after every 16-wide k block, and on the synthetic field the two differ by a few half ulps of
+    the activations -- the per-sample size of the deviation (its per-RAY size on the 512^2 bench frame is measured by
+    tools/size_mlp_accumulation.py on the GPU box and quoted in DESIGN.md)."""
+    body, init, fp, world = small_world
+    rng = np.random.RandomState(3)
+    bb = init["bbox"]
+    x = (rng.rand(20000, 3).astype(np.float32) * (bb[1] - bb[0]) + bb[0]).astype(np.float32)
+    assert oracle.set_mlp_half_accumulate(False) is False
+    rgb0, sig0 = oracle.field_fwd(world["field"], x)
+    rgb0b, sig0b = oracle.field_fwd(world["field"], x)
+    assert np.array_equal(rgb0, rgb0b) and np.array_equal(sig0, sig0b)
+    try:
+        assert oracle.set_mlp_half_accumulate(True) is False
+        rgb1, sig1 = oracle.field_fwd(world["field"], x)
+    finally:
+        assert oracle.set_mlp_half_accumulate(False) is True
+    rgb2, sig2 = oracle.field_fwd(world["field"], x)
+    assert np.array_equal(rgb0, rgb2) and np.array_equal(sig0, sig2)        # the switch leaves nothing behind
+    d_rgb, d_sig = np.abs(rgb1 - rgb0).max(1), np.abs(sig1 - sig0)
+    rel_sig = d_sig / np.maximum(np.abs(sig0), 1.0)
+    print("half vs fp32 accumulate: rgb differs on %.3f of the samples (max %.2e, > 1e-3 on %.4f); sigma rel max %.2e, > 1e-3 on %.4f" % (
+        (d_rgb > 0).mean(), d_rgb.max(), (d_rgb > 1e-3).mean(), rel_sig.max(), (rel_sig > 1e-3).mean()))
+    assert (d_rgb > 0).any() or (d_sig > 0).any(), "the two modes must not be the same arithmetic"
+    assert d_rgb.max() < 2e-2 and rel_sig.max() < 5e-2      # a few half ulps (2^-11 relative) through three / two layers
+
+
 def test_weight_voxels_are_a_partition_of_unity(small_world):
     _, init, _, _ = small_world
     w = init["lbs_voxel"]
@@ -288,6 +317,133 @@ def test_smpl_deformer_oracle_properties(oracle):
     assert 0.2 < valid.mean() < 0.95
     ref = np.einsum("pij,pj->pi", prep["T_inv"][idx, :3, :3], pts) + prep["T_inv"][idx, :3, 3]
     assert np.abs(cano - ref).max() < 1e-5
+
+
+def test_animate_and_eval_writers_agree_on_the_channel_order(tmp_path):
+    """the model's channels are in cv2's (B, G, R) order; animate / novel_view frames (cv2.imwrite of BGRA in the
+    reference, animate.py:113) and eval's panels (cv2.imwrite of BGR, evaluation.write_png_bgr) must put the same colour
+    into the file."""
+    from PIL import Image
+    from instantavatar_amd import evaluation as ev
+    from instantavatar_amd.drivers import animate
+    frame = np.zeros((4, 6, 4), np.uint8)
+    frame[..., 0], frame[..., 1], frame[..., 2], frame[..., 3] = 10, 20, 30, 255     # B = 10, G = 20, R = 30
+    animate.write_frames([frame, frame], str(tmp_path / "a"), gif="x.gif")
+    a = np.asarray(Image.open(tmp_path / "a" / "0.png"))
+    assert a.shape == (4, 6, 4) and tuple(a[0, 0]) == (30, 20, 10, 255)           # what cv2.imwrite would have stored
+    ev.write_png_bgr(str(tmp_path / "e.png"), torch.as_tensor(frame[..., :3].astype(np.float32) / 255))
+    e = np.asarray(Image.open(tmp_path / "e.png"))
+    assert np.array_equal(e, a[..., :3])
+    g = Image.open(tmp_path / "a" / "x.gif")
+    assert g.n_frames == 2 or getattr(g, "n_frames", 1) >= 1                        # identical frames may be merged by the encoder
+    assert tuple(np.asarray(g.convert("RGB"))[0, 0]) == (30, 20, 10)
+
+
+def test_checkpoint_layout_switch_keeps_the_parameter_an_optimizer_holds(tmp_path):
+    """drivers/train.py --resume builds optimiser and scheduler BEFORE load_checkpoint; when the
+    checkpoint has the other tcnn level-3 layout the hash-table parameter must be resized IN PLACE (same Parameter object),
+    stale moments dropped, and the checkpoint's own optimiser state restored -- the optimiser then keeps training the live
+    table."""
+    from instantavatar_amd.drivers.checkpoint import load_checkpoint, save_checkpoint
+    from instantavatar_amd.models.networks.ngp import NeRFNGPNet
+
+    class M(torch.nn.Module):
+        def __init__(self, r3):
+            super().__init__()
+            self.net_coarse = NeRFNGPNet(dict(center=[0, 0, 0], scale=[1, 1, 1]), n_levels=5, log2_hashmap_size=19, level3_res=r3)
+    src, dst = M(55), M(54)
+    assert src.net_coarse.encoder.params.numel() != dst.net_coarse.encoder.params.numel()
+    so = torch.optim.Adam(src.parameters(), lr=1e-2)
+    for p in src.parameters():
+        p.grad = torch.full_like(p, 0.5)
+    so.step()
+    save_checkpoint(src, str(tmp_path / "c.ckpt"), optimizer=so)
+    p = dst.net_coarse.encoder.params
+    opt = torch.optim.Adam(dst.parameters(), lr=1e-2)
+    for q in dst.parameters():
+        q.grad = torch.ones_like(q)
+    opt.step()                                       # the optimiser now holds moments of the OLD shape
+    load_checkpoint(dst, str(tmp_path / "c.ckpt"), optimizer=opt)
+    assert dst.net_coarse.encoder.params is p and p.numel() == src.net_coarse.encoder.params.numel()
+    assert torch.equal(p.detach(), src.net_coarse.encoder.params.detach())
+    assert opt.state[p]["exp_avg"].shape == p.shape  # the checkpoint's moments, new shape
+    p.grad = torch.ones_like(p)
+    before = p.detach().clone()
+    opt.step()
+    assert (p.detach() != before).all()              # the LIVE table moves
+
+
+def _write_smpl_pickle(path, body, chumpy_key=None):
+    """the synthetic body in the key layout of the licensed SMPL_<GENDER>.pkl (smplx/body_models.py:108-154 reads
+    v_template, shapedirs [V,3,>=10], posedirs [V,3,207], a scipy-sparse J_regressor [24,V], kintree_table [2,24] with
+    uint32(-1) as the root's parent, weights [V,24], f [F,3])"""
+    import pickle
+    import scipy.sparse as sp
+    V = body["v_template"].shape[0]
+    posedirs = np.asarray(body["posedirs"], np.float64)
+    if posedirs.ndim == 2:                      # [207, V*3] -> the file's [V, 3, 207]
+        posedirs = posedirs.T.reshape(V, 3, -1)
+    parents = np.asarray(body["parents"]).astype(np.int64)
+    kt = np.stack([parents, np.arange(24)]).astype(np.uint32)      # kt[0, 0] = 4294967295
+    d = {"v_template": np.asarray(body["v_template"], np.float64), "shapedirs": np.asarray(body["shapedirs"], np.float64),
+         "posedirs": posedirs, "J_regressor": sp.csc_matrix(np.asarray(body["J_regressor"], np.float64)),
+         "kintree_table": kt, "weights": np.asarray(body["lbs_weights"], np.float64), "f": np.asarray(body["f"]).astype(np.uint32),
+         "bs_type": "lrotmin", "bs_style": "lbs", "J": np.zeros((24, 3)), "vert_sym_idxs": np.arange(V)}
+    if chumpy_key:
+        import sys
+        import types
+        mod = types.ModuleType("chumpy"); sub = types.ModuleType("chumpy.ch")
+        Ch = type("Ch", (), {"__module__": "chumpy.ch", "__init__": lambda self, x: setattr(self, "x", x)})
+        sub.Ch = Ch; mod.ch = sub
+        sys.modules["chumpy"], sys.modules["chumpy.ch"] = mod, sub
+        try:
+            d[chumpy_key] = Ch(d[chumpy_key])
+            with open(path, "wb") as f:
+                pickle.dump(d, f, protocol=2)
+        finally:
+            del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+        return
+    with open(path, "wb") as f:
+        pickle.dump(d, f, protocol=2)
+
+
+def test_smpl_loads_the_licensed_pickle_layout_and_names_chumpy(tmp_path):
+    """VERDICT r03 missing 4: the first real run goes through SMPL._load (model_path + gender -> SMPL_<GENDER>.pkl with
+    kintree_table / weights / posedirs [V,3,207] / sparse J_regressor), which no test executed.  A pickle written in that
+    layout from the synthetic body must give the same module as SMPL.from_dict(body); a pickle that needs chumpy to
+    unpickle gets an error that says so and how to convert it."""
+    from instantavatar_amd.deformers.smplx import SMPL
+    body = syn.make_body(42)
+    body = dict(body)
+    body.setdefault("f", np.stack([np.arange(0, 300), np.arange(1, 301), np.arange(2, 302)], 1))
+    d = tmp_path / "smpl"
+    d.mkdir()
+    _write_smpl_pickle(str(d / "SMPL_NEUTRAL.pkl"), body)
+    a = SMPL(str(d), "neutral")                      # directory + gender (confs/deformer/fast_snarf.yaml: model_path)
+    b = SMPL(str(d / "SMPL_NEUTRAL.pkl"), "neutral")  # or the file itself
+    ref = SMPL.from_dict(body)
+    for m in (a, b):
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "parents", "faces_tensor"):
+            assert torch.equal(getattr(m, k), getattr(ref, k)), k
+        assert m.parents_list[0] == -1 and m.posedirs.shape == (207, 6890 * 3)
+    betas = torch.zeros(1, 10)
+    pose = torch.as_tensor(syn.procedural_pose_track(4)[0][2][None])
+    oa, orf = a(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]), ref(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3])
+    assert torch.equal(oa.vertices, orf.vertices) and torch.equal(oa.A, orf.A)
+    with pytest.raises(FileNotFoundError):
+        SMPL(str(d), "female")
+    c = tmp_path / "ch"
+    c.mkdir()
+    _write_smpl_pickle(str(c / "SMPL_NEUTRAL.pkl"), body, chumpy_key="v_template")
+    with pytest.raises(ImportError) as e:
+        SMPL(str(c), "neutral")
+    assert "chumpy" in str(e.value) and "npz" in str(e.value)
+    # the conversion the message describes: an .npz next to the .pkl is picked up first
+    np.savez(str(c / "SMPL_NEUTRAL.npz"), v_template=body["v_template"], shapedirs=body["shapedirs"], posedirs=body["posedirs"],
+             J_regressor=body["J_regressor"], kintree_table=np.stack([np.asarray(body["parents"]), np.arange(24)]).astype(np.int64),
+             weights=body["lbs_weights"], f=body["f"])
+    n = SMPL(str(c), "neutral")
+    assert torch.equal(n.v_template, ref.v_template) and torch.equal(n.lbs_weights, ref.lbs_weights)
 
 
 def test_driver_config_and_checkpoint_io(tmp_path):
@@ -1077,11 +1233,7 @@ def test_round3_entry_points_validate_arguments_before_any_launch():
     tail = (C.c_float(1e-5), C.c_float(1e-1))
     # n_cand is required; P < 0 is rejected; P == 0 returns before touching anything; the J_inv output and the workspace are required
     big = 1 << 20
-    # workspace: work heads (8 x 128 B), one flag per (init, point of the 64-padded list), modes 1-2 the unfiltered roots, mode 2 their J_inv
-    w0, w1, w2 = (L.ia_snarf_search_workspace_bytes(4, 3, m) for m in (0, 1, 2))
-    assert w0 >= 8 * 128 + 3 * 64 and w1 >= w0 + 3 * 64 * 12 and w2 >= w1 + 4 * 3 * 9 * 4
-    assert L.ia_snarf_search_workspace_bytes(0, 3, 1) == 0 and L.ia_snarf_search_workspace_bytes(4, 99, 1) == 0 and L.ia_snarf_search_workspace_bytes(4, 3, 7) == 0
-    assert L.ia_search_get_impl() == 1 and L.ia_search_set_impl(5) != 0
+    assert L.ia_snarf_search_jinv_workspace_bytes(4, 3) == 4 * 3 * 9 * 4
     assert L.ia_snarf_search_compact_jinv(one, 4, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, None, 0, one, big, None) != 0
     assert b"n_cand" in L.ia_last_error()
     assert L.ia_snarf_search_compact_jinv(one, -1, None, one, one, bones, 3, C.byref(g), *tail, one, one, 16, one, one, one, 0, one, big, None) != 0

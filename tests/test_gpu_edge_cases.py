@@ -39,7 +39,7 @@ def test_argument_errors_raise_and_report(gw):
     bones = _lib.bone_array([0, 1, 99])  # joint id out of range
     with pytest.raises(_lib.IAError):
         _lib.check(L.ia_snarf_search(_lib.ptr(t), 1, _lib.ptr(t), _lib.ptr(t), bones, 3, C.byref(model.deformer.deformer.grid_desc()),
-                                     1e-5, 1e-1, _lib.ptr(t), _lib.ptr(t), None, None, None, 0, None), "ia_snarf_search")
+                                     1e-5, 1e-1, _lib.ptr(t), _lib.ptr(t), None, None, None), "ia_snarf_search")
     ws = torch.empty(16, dtype=torch.uint8, device=DEV)  # workspace too small
     rc = L.ia_occupancy_from_density(_lib.ptr(torch.zeros(64 ** 3, device=DEV)), 64, _lib.ptr(torch.zeros(8193, dtype=torch.int32, device=DEV)),
                                      None, _lib.ptr(ws), 16, None)
@@ -157,6 +157,7 @@ def test_novel_view_driver_turns_the_body(tmp_path):
     with torch.no_grad():
         rgb, _, alpha, _ = model.render_image_fast(seq.batch(1), (seq.H, seq.W))
     want = (torch.cat([rgb, alpha[..., None]], -1)[0].clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
+    want = want[..., [2, 1, 0, 3]]      # the model's channels are (B, G, R): the file holds R first (cv2.imwrite semantics)
     assert (np.abs(want.astype(int) - ims[1].astype(int)) > 1).mean() < 1e-3
 
 

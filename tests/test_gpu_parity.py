@@ -369,6 +369,49 @@ def test_render_frame_parity_full_pipeline(oracle, gpu_world):
         assert abs(counter.mean() - ref["counter"].mean()) < 0.02 * max(1.0, ref["counter"].mean())
 
 
+@pytest.mark.parametrize("which", ["own", "other"])
+def test_flat_tcnn_checkpoint_loads_and_renders_like_the_oracle(oracle, tmp_path, monkeypatch, which):
+    """VERDICT r03 missing 4 (second half): the first real checkpoint arrives as a Lightning dict whose field is two FLAT
+    tcnn vectors -- `net_coarse.encoder.params` = [W1 64x32 | W2 16x64 | grid] and `net_coarse.color_net.params` =
+    [64x16 | 64x64 | 16x64] (ngp.py:27-58, animate.py:92-95 loads it) -- in whichever of the two level-3 layouts that tcnn
+    build produced.  Written here from a synthetic field in BOTH layouts, loaded through drivers/checkpoint.load_checkpoint
+    into a model built for this host's default layout, rendered, and compared with the oracle evaluating the same field."""
+    import os
+    from instantavatar_amd.drivers.checkpoint import load_checkpoint
+    from instantavatar_amd.pipeline import build_synthetic_model
+    own = int(os.environ.get("IA_TCNN_LEVEL3_RES", "54"))
+    r3 = own if which == "own" else (55 if own == 54 else 54)
+    _, body, _, init = W.build(DEV, 64, 16)
+    model, _, _ = build_synthetic_model(DEV, resolution=64, n_levels=16)       # default layout; its own field is overwritten below
+    assert int(model.net_coarse.hash_desc.res[3]) == own
+    smpl = model.deformer.body_model
+    cano = smpl(betas=torch.zeros(1, 10, device=DEV), body_pose=torch.as_tensor(syn.cano_pose("A_pose"), device=DEV)[None],
+                return_verts=False).joints[0].cpu().numpy()
+    monkeypatch.setenv("IA_TCNN_LEVEL3_RES", str(r3))     # the generator and the oracle follow the environment
+    fp = syn.make_field(cano, model.deformer.bbox.cpu().numpy(), seed=7, n_levels=16)
+    assert int(fp["level_res"][3]) == r3
+    flat = lambda *ks: torch.from_numpy(np.concatenate([np.asarray(fp[k], np.float32).reshape(-1) for k in ks]))
+    sd = {"net_coarse.encoder.params": flat("sig_w1", "sig_w2", "table"), "net_coarse.color_net.params": flat("col_w1", "col_w2", "col_w3"),
+          "net_coarse.center": torch.as_tensor(fp["center"])[None], "net_coarse.scale": torch.as_tensor(fp["scale"])[None],
+          "loss_fn.lpips.net.slice1.0.weight": torch.zeros(3)}      # something a Lightning checkpoint carries that is not on the path
+    sd = {k: (v.reshape(model.state_dict()[k].shape) if k in model.state_dict() and v.numel() == model.state_dict()[k].numel() else v) for k, v in sd.items()}
+    path = str(tmp_path / "lightning.ckpt")
+    torch.save({"state_dict": sd, "global_step": 1234, "epoch": 3, "pytorch-lightning_version": "1.5.7"}, path)
+    missing, unexpected = load_checkpoint(model, path)
+    assert int(model.net_coarse.hash_desc.res[3]) == r3 and model.global_step == 1234
+    assert "loss_fn.lpips.net.slice1.0.weight" in unexpected
+    assert model.tcnn_self_check["level3_res"] == r3 and model.tcnn_self_check["finite"]
+    poses, tr = W.poses()
+    rgb, alpha, depth, counter, occ_g, ref = _frame_parity(oracle, model, body, fp, init, poses[2], tr[2], 64, 321)
+    err_rgb, err_a = np.abs(rgb - ref["rgb"]).max(1), np.abs(alpha - ref["alpha"])
+    print("flat tcnn checkpoint, level-3 resolution %d: cov %.3f, rays > 1e-3: rgb %.5f alpha %.5f, max %.2e, occupancy flips %.2e" % (
+        r3, (ref["alpha"] > 0.5).mean(), (err_rgb > 1e-3).mean(), (err_a > 1e-3).mean(), err_rgb.max(), (occ_g != ref["occ"].astype(bool)).mean()))
+    assert (ref["alpha"] > 0.5).mean() > 0.02
+    assert (occ_g != ref["occ"].astype(bool)).mean() < 2e-4
+    assert (err_rgb > 1e-3).mean() < 2e-3 and (err_a > 1e-3).mean() < 2e-3
+    assert np.median(err_rgb[ref["alpha"] > 0.5]) < 1e-4
+
+
 def test_render_closure_route_equals_fused_route(gpu_world):
     model, body, fp, init, poses, tr = gpu_world
     res = 64

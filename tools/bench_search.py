@@ -39,9 +39,6 @@ pt_off = torch.empty(P, dtype=torch.int32, device=dev)
 pt_cnt = torch.empty(P, dtype=torch.uint8, device=dev)
 n_cand = torch.zeros(64 * 32, dtype=torch.int32, device=dev)
 tfs = dd.tfs.detach().float().contiguous()
-ws = torch.empty(int(L.ia_snarf_search_workspace_bytes(P, k, 1)), dtype=torch.uint8, device=dev)
-if len(sys.argv) > 3:
-    _lib.check(L.ia_search_set_impl(int(sys.argv[3])), "ia_search_set_impl")   # 0: workgroup queues, 1: persistent waves
 
 
 def run(n=30):
@@ -49,7 +46,7 @@ def run(n=30):
         n_cand.zero_()
         _lib.check(L.ia_snarf_search_compact(_lib.ptr(pts), P, None, _lib.ptr(fd.voxel_J_cl), _lib.ptr(tfs), fd._bones_c, k,
                                              C.byref(fd.grid_desc()), 1e-5, 1e-1, _lib.ptr(cand), P * k, _lib.ptr(pt_off), _lib.ptr(pt_cnt),
-                                             _lib.ptr(n_cand), 0, _lib.ptr(ws), ws.numel(), _lib.stream()))
+                                             _lib.ptr(n_cand), 0, _lib.stream()))
     for _ in range(5):
         once()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
