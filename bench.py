@@ -319,6 +319,23 @@ def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512)
     return out
 
 
+def rank_report(rank, world_size, dev, extra):
+    """One record per rank, gathered on rank 0 and echoed by every rank on stderr: what each process really saw (device, RCCL
+    world size and backend, its own counts), so that a scaling run explains itself without the builder present."""
+    import torch.distributed as dist
+    rec = {"rank": rank, "device": (torch.cuda.get_device_name(dev) if dev is not None else "cpu (dry run)"), "device_index": (dev.index if dev is not None else None),
+           "world_size_seen": (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1),
+           "backend": (dist.get_backend() if dist.is_available() and dist.is_initialized() else None),
+           "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "pid": os.getpid()}
+    rec.update(extra)
+    print("[bench rank %d/%d] %s" % (rank, world_size, json.dumps(rec)), file=sys.stderr, flush=True)
+    if world_size > 1:
+        got = [None] * world_size
+        dist.all_gather_object(got, rec)
+        return got
+    return [rec]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -382,12 +399,13 @@ def dry_run(args, rank, world_size):
         dist.all_gather_object(gathered, (counts[0], checks))
         counts = [g[0] for g in gathered]
         assert all(abs(g[1][k] - checks[k]) < 1e-6 for g in gathered for k in range(3)), "replicas differ after the collectives"
+    ranks = rank_report(rank, world_size, None, {"frames_timed": len(my)})
     if rank == 0:
         print(json.dumps({"metric": "novel_pose_render_frames_per_sec_512x512", "value": sum(counts) / dt, "unit": "frames/s",
                           "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DRY RUN (no kernels; 1 ms sleep per frame)", "frames_sharded_over": world_size},
-                          "dry_run": True, "frames_per_rank": counts, "backend": "gloo"}))
+                          "dry_run": True, "frames_per_rank": counts, "backend": "gloo", "ranks": ranks}))
     if world_size > 1:
         dist.destroy_process_group()
 
@@ -489,9 +507,19 @@ def main():
                                   graphed=not args.no_graph)
         if not args.no_graph and (world_size > 1 or args.force_collectives):
             # the same N-rank step launched eagerly (~60 launches + the collectives from Python): the gap a captured step closes
+            from instantavatar_amd import parallel as par
+            par.EXPOSED_EVENTS = []
             e = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3), graphed=False)
+            torch.cuda.synchronize()
+            mean_ms, max_ms = par.exposed_allreduce_ms(par.EXPOSED_EVENTS)
+            par.EXPOSED_EVENTS = None
             tr_res["eager"] = {k: e[k] for k in ("it_per_sec", "rays_per_sec", "launch_mode")}
+            # how long the compute stream stood still per step for gradient transfers the backward did not hide (the last
+            # bucket: levels 0-3 + the MLP weights; the three 16.8 MB level groups travel under the scatter of the next one)
+            tr_res["eager"]["exposed_allreduce_ms_per_step"] = {"mean": mean_ms, "max": max_ms}
             tr_res["collectives"] = "RCCL, %d rank(s)%s" % (world_size, " (forced on one rank)" if args.force_collectives else "")
+        tr_res["ranks"] = rank_report(rank, world_size, dev, {"train_steps": int(tr_res["steps"]), "it_per_sec_local_clock": tr_res["it_per_sec"],
+                                                               "exposed_allreduce_ms_per_step": (tr_res.get("eager") or {}).get("exposed_allreduce_ms_per_step")})
         if rank == 0:
             print(json.dumps({"metric": "train_rays_per_sec", "value": tr_res["rays_per_sec"], "unit": "rays/s", "n_gpus": world_size,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / tr_res["it_per_sec"],
@@ -626,6 +654,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt                               # this rank's own clock around its K frames (the line reports the MAX over ranks)
     timed_frames = int(frames_done[0])          # what THIS rank rendered inside the timed region (the secondary runs below count on)
     main_samples_per_ray = float(cnt_sum.sum().item()) / args.steps
     main_alpha_coverage = float(cov_sum.sum().item()) / args.steps
@@ -798,6 +827,8 @@ def main():
         "frames_rerendered_eagerly": int(incomplete),
         "ms_per_step_instrumented": (dt_prof / args.steps * 1e3) if dt_prof else None,
     }
+    result["ranks"] = rank_report(rank, world_size, dev, {"frames_timed": int(timed_frames), "frames_per_s_local_clock": timed_frames / dt_local,
+                                                           "launch_mode": mode, "frames_in_flight": (args.in_flight if graphed is not None else 1)})
     if roof is not None:
         result["roofline"] = roof
     if rank == 0 and prof:

@@ -116,8 +116,10 @@ static inline int ia_make_bones(const int32_t *bone_ids, int n_init, BoneIds *b)
 // grid_sample un-normalisation, align_corners = true (fuse_cuda_kernel_fast.cu:62-91)
 __device__ __forceinline__ float src_index(float coord, int size) {
   coord = ((coord + 1.f) / 2) * (size - 1);
-  if (coord > (float)(INT_MAX - 1) || coord < (float)INT_MIN || !isfinite(coord)) return -100.0f;
-  return coord;
+  // reference (:84-91): coord > INT_MAX - 1 || coord < INT_MIN || !isfinite(coord) -> -100.  (float)(INT_MAX - 1) and
+  // (float)INT_MIN are +-2^31, so the three tests are ONE: NOT (|coord| <= 2^31) -- false for NaN and inf as well
+  // (one v_cmp with an abs modifier + one select instead of three compares, two ORs and a class test)
+  return __builtin_fabsf(coord) <= 2147483648.0f ? coord : -100.0f;
 }
 
 // true when none of the 8 trilinear corners of the fetch at normalised (gx,gy,gz) lies inside

@@ -75,6 +75,10 @@ def broadcast_module_state(module, world_size, src=0):
                 m.pack_bits()          # bit-packed occupancy follows density_field
 
 
+#: set to a list to collect, over all steps, the event pairs GradReducer.finish records around its waits (see there)
+EXPOSED_EVENTS = None
+
+
 class GradReducer:
     """Gradient averaging with the transfers started from inside the backward pass.
 
@@ -89,6 +93,10 @@ class GradReducer:
         self._works = []
         self._ranges = []   # (first byte, last byte) already handed in
         self._fields = 0    # field calls recorded in this step's autograd graph, not yet back-propagated
+        #: when set to a list, finish() appends one (event, event) pair per step around its waits on the collectives: the
+        #: time the COMPUTE stream stands still for transfers that the backward did not hide (bench.py --gpus N reports it).
+        #: Only meaningful for eagerly launched steps (events recorded during a graph capture cannot be timed).
+        self.exposed_events = EXPOSED_EVENTS
 
     @property
     def active(self):
@@ -157,11 +165,24 @@ class GradReducer:
             if p.grad is not None:
                 assert not self._covered(p.grad.view(-1)), "GradReducer: part of a gradient was not reduced"
         self.last_collectives = len(self._works)
+        timed = self.exposed_events is not None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w, t, scale in self._works:
             w.wait()
             if scale:
                 t.div_(self.world_size)
+        if timed:
+            e1.record()
+            self.exposed_events.append((e0, e1))
         self._works, self._ranges, self._fields = [], [], 0
+
+
+def exposed_allreduce_ms(pairs):
+    """mean and max over the steps of the time the compute stream waited for gradient transfers (after a synchronise)"""
+    ms = [a.elapsed_time(b) for a, b in pairs]
+    return (sum(ms) / len(ms), max(ms)) if ms else (None, None)
 
 
 #: the reducer of the training step in flight (set by training.training_step, read by the autograd

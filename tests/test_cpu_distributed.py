@@ -81,6 +81,10 @@ def test_bench_gpus2_dry_run_launches_two_ranks():
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["dry_run"] is True and r["frames_per_rank"] == [6, 6] and r["steps"] == 6
     assert r["metric"] == "novel_pose_render_frames_per_sec_512x512" and r["scaling"] == "weak"
+    # every rank reports what it saw: gathered into the line AND echoed on stderr by each process
+    assert [x["rank"] for x in r["ranks"]] == [0, 1] and all(x["world_size_seen"] == 2 and x["backend"] == "gloo" for x in r["ranks"])
+    assert len({x["pid"] for x in r["ranks"]}) == 2
+    assert "[bench rank 0/2]" in out.stderr and "[bench rank 1/2]" in out.stderr
     # a mismatch between --gpus and the launcher's world size must fail loudly
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
