@@ -314,6 +314,17 @@ def hashgrid_roofline(model, dev, n=1 << 20, reps=20, frame_batch=None, res=512)
             out.update(l2_hit_rate=c["l2_hit_rate"], l2_read_requests_per_sample=req,
                        l2_request_rate_frac=req * n / (us * 1e-6) / 269e9, l2_request_ceiling="8 XCD x 16 channels x 2.1 GHz = 269 G/s",
                        traffic=c["fabric_fetch_bytes_per_launch_x2_corrected"], traffic_source=src)
+            cc = cj.get("k_encode_xcd<16>/frame_coherent")
+            if cc and isinstance(out.get("frame_coherent"), dict) and "avg_launch_us" in out["frame_coherent"]:
+                fc = out["frame_coherent"]
+                # requests per sample from the counter pass (same sample set), rate from THIS run's launch time
+                fc.update(l2_read_requests_per_sample=cc.get("l2_read_requests_per_sample"), l1_accesses_per_sample=cc.get("l1_accesses_per_sample"),
+                          l2_hit_rate=cc.get("l2_hit_rate"),
+                          l2_request_rate_frac=(cc["l2_read_requests_per_sample"] * fc["samples"] / (fc["avg_launch_us"] * 1e-6) / 269e9
+                                                if cc.get("l2_read_requests_per_sample") else None),
+                          stall=("TCP_PENDING_STALL_CYCLES = 49 % of the vector L1's cycles, mean TCP->TCC round trip 198 clk, ~47 L2 requests in "
+                                 "flight per CU (Little): the L1's outstanding-miss capacity x the L2 latency bounds the request rate; 65 % of "
+                                 "the wave cycles wait for an issue slot behind it (profiles/r04_pmc_encode_stall/)"))
         except Exception:
             pass
     return out
@@ -528,7 +539,7 @@ def main():
                                                      "HBM), SNARF_NGP defaults, Adam, occupancy update every 20 steps, RCCL gradient "
                                                      "all-reduce" % (4096, res, res)},
                               "train": tr_res}))
-        if world_size > 1:
+        if world_size > 1 or args.force_collectives:
             torch.distributed.destroy_process_group()
         return
 
