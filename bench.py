@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true", help="with --gpus 1: start a 1-rank RCCL group and take the multi-rank "
                     "training path (bucketed all-reduce from inside the backward, density MAX-reduce) -- the eager-vs-graph gap of the "
                     "N-rank step measured on one GPU")
+    ap.add_argument("--tile-shard", action="store_true", help="latency mode (SURVEY 8e, optional): EVERY frame is split by image rows over "
+                    "the N ranks (parallel.render_frame_tiled: occupancy build duplicated, blocks all-gathered over RCCL); strong scaling")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises launch, frame sharding and the "
                     "collectives on the gloo backend (CPU test of the N > 1 plumbing)")
     ap.add_argument("--no-profile", action="store_true", help="disable the in-library event timing")
@@ -513,6 +515,41 @@ def main():
             return float(t.item())
         return x
 
+    if args.tile_shard:
+        # one frame at a time, all ranks on it: frames/s = 1 / latency.  Eager launches (the tiles' geometry differs per rank).
+        from instantavatar_amd.parallel import render_frame_tiled, shard_rows
+        gj = torch.Generator(device=dev)
+
+        def frame(i):
+            f = i % len(poses)
+            gj.manual_seed(1000 + i)            # the SAME occupancy jitter on every rank: the grids must agree
+            jit = torch.rand((5, 64 ** 3, 3), device=dev, generator=gj)
+            return render_frame_tiled(model, make_batch(dev, res, poses[f], tr[f]), (res, res), world_size, rank, jitter=jit)
+        for i in range(max(args.warmup, 2)):
+            out = frame(i)
+        torch.cuda.synchronize()
+        if world_size > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = frame(args.warmup + i)
+        torch.cuda.synchronize()
+        if world_size > 1:
+            torch.distributed.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        ranks = rank_report(rank, world_size, dev, {"rows": list(shard_rows(res, rank, world_size)), "alpha_coverage_whole_frame": float((out[2] > 0.5).float().mean())})
+        if rank == 0:
+            print(json.dumps({"metric": "novel_pose_frame_latency_frames_per_sec_%dx%d_row_sharded" % (res, res), "value": args.steps / dt, "unit": "frames/s",
+                              "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "render_image_fast %dx%d, ONE frame at a time split by image rows over %d rank(s) (occupancy build on "
+                                                     "every rank, row blocks all-gathered), eager launches, aist_demo.npz[:200]" % (res, res, world_size),
+                                         "rows_per_rank": [list(shard_rows(res, r, world_size)) for r in range(world_size)]},
+                              "ranks": ranks}))
+        if world_size > 1:
+            torch.distributed.destroy_process_group()
+        return
+
     if args.train_only:
         tr_res = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3),
                                   graphed=not args.no_graph)
@@ -764,7 +801,7 @@ def main():
         # resident: the algorithmic bytes are served by the cache hierarchy, so the roof they are priced against
         # is the aggregate L2 bandwidth; the bytes that actually reached the fabric (PMC: FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/, accepted only when collected on THIS build) divided by the same launch time give the HBM fraction.
-        tj, tsrc = _profile_json("pmc_traffic", ("ia_snarf.hip",) if dom == "k_search" else ("ia_field.hip",))
+        tj, tsrc = _profile_json("pmc_traffic", ("ia_search.hip",) if dom == "k_search" else ("ia_field.hip",))
         traffic = None
         if tj is not None:
             try:
@@ -794,7 +831,7 @@ def main():
         if L.ia_search_kernel_info(C.byref(vg), C.byref(lds), C.byref(thr), C.byref(wgs)) == 0:
             roof["kernel_resources"] = {"vgprs": vg.value, "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": thr.value,
                                         "workgroups_per_cu": wgs.value, "waves_per_simd": wgs.value * thr.value / 64 / 4.0}
-        cj, csrc = _profile_json("pmc_search", ("ia_snarf.hip",))
+        cj, csrc = _profile_json("pmc_search", ("ia_search.hip",))
         if cj is not None:
             # committed PMC passes of this kernel (tools/pmc_all.sh): what actually bounds k_search is the rate at which a
             # CU's vector L1 (TCP) looks up cache lines for divergent 16-byte gathers -- ~1 access per clock and CU

@@ -29,19 +29,16 @@ struct FetchPlan {
   uint32_t load;   // 1: the lane is active and at least one corner lies inside the grid
 };
 
-// IA_PLAN_FACTOR_ZERO: validity folded into the six 1-D interpolation factors -- one unsigned compare and one select per axis
-// end instead of two compares per end, three-way ANDs and eight selects on the products.  A zeroed factor makes its four
+// Validity is folded into the six 1-D interpolation factors -- one unsigned compare and one select per axis end instead of
+// two compares per end, three-way ANDs and eight selects on the products (round 3's form).  A zeroed factor makes its four
 // products exactly +0: the factors are finite and non-negative (src_index maps NaN / huge coordinates to -100), and the
-// multiplication order of the products is unchanged, so the weights are bit-identical to select-after-multiply.
-#ifndef IA_PLAN_FACTOR_ZERO
-#define IA_PLAN_FACTOR_ZERO 1
-#endif
+// multiplication order of the products is unchanged, so the weights are bit-identical to select-after-multiply
+// (test_broyden_search_and_filter, test_ref_pin.py; round 4: adopted, 196.3 -> 193.4 us together with the DPP add below).
 __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, float gy, float gz, bool active, FetchPlan &p) {
   const float ix = src_index(gx, g.W), iy = src_index(gy, g.H), iz = src_index(gz, g.D);
   const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
   const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
   const float fx1 = x1 - ix, fx0 = ix - x0, fy1 = y1 - iy, fy0 = iy - y0, fz1 = z1 - iz, fz0 = iz - z0;
-#if IA_PLAN_FACTOR_ZERO
   const bool bx0 = (uint32_t)x0 < (uint32_t)g.W, bx1 = (uint32_t)x1 < (uint32_t)g.W;
   const bool by0 = (uint32_t)y0 < (uint32_t)g.H, by1 = (uint32_t)y1 < (uint32_t)g.H;
   const bool bz0 = (uint32_t)z0 < (uint32_t)g.D, bz1 = (uint32_t)z1 < (uint32_t)g.D;
@@ -49,13 +46,6 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
   const float qx0 = bx0 ? fx1 : 0.f, qx1 = bx1 ? fx0 : 0.f, qy0 = by0 ? fy1 : 0.f, qy1 = by1 ? fy0 : 0.f, qz0 = bz0 ? fz1 : 0.f, qz1 = bz1 ? fz0 : 0.f;
   const float wgt[8] = {qx0 * qy0 * qz0, qx1 * qy0 * qz0, qx0 * qy1 * qz0, qx1 * qy1 * qz0,
                         qx0 * qy0 * qz1, qx1 * qy0 * qz1, qx0 * qy1 * qz1, qx1 * qy1 * qz1};
-#else
-  const float wgt[8] = {fx1 * fy1 * fz1, fx0 * fy1 * fz1, fx1 * fy0 * fz1, fx0 * fy0 * fz1,
-                        fx1 * fy1 * fz0, fx0 * fy1 * fz0, fx1 * fy0 * fz0, fx0 * fy0 * fz0};
-  const bool bx0 = x0 >= 0 && x0 < g.W, bx1 = x1 >= 0 && x1 < g.W;
-  const bool by0 = y0 >= 0 && y0 < g.H, by1 = y1 >= 0 && y1 < g.H;
-  const bool bz0 = z0 >= 0 && z0 < g.D, bz1 = z1 >= 0 && z1 < g.D;
-#endif
   const int cx0 = min(max(x0, 0), g.W - 1), cx1 = min(max(x1, 0), g.W - 1);
   const int cy0 = min(max(y0, 0), g.H - 1), cy1 = min(max(y1, 0), g.H - 1);
   const int cz0 = min(max(z0, 0), g.D - 1), cz1 = min(max(z1, 0), g.D - 1);
@@ -69,12 +59,7 @@ __device__ __forceinline__ void fetch_plan(const SnarfGridDev &g, float gx, floa
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     p.off[k] = zy[k >> 1] + xo[k & 1];
-#if IA_PLAN_FACTOR_ZERO
     p.w[k] = wgt[k];
-#else
-    const bool in = ((k & 1) ? bx1 : bx0) && ((k & 2) ? by1 : by0) && ((k & 4) ? bz1 : bz0);
-    p.w[k] = in ? wgt[k] : 0.f;
-#endif
   }
   p.load = (active && (bx0 || bx1) && (by0 || by1) && (bz0 || bz1)) ? 1u : 0u;
 }
@@ -88,12 +73,9 @@ template <int PERM> __device__ __forceinline__ float quad_perm(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), PERM, 0xF, 0xF, true));
 }
 
-// IA_QUAD_ASM_DPP_ADD: offset broadcast and row-offset add as ONE v_add_u32_dpp -- the compiler emits v_mov_b32_dpp +
-// v_add_u32 because it sinks the add to the predicated loads.  The two wait states a DPP read needs after a VALU write of its
-// source are the s_nop: inline asm is opaque to the hazard recogniser.
-#ifndef IA_QUAD_ASM_DPP_ADD
-#define IA_QUAD_ASM_DPP_ADD 1
-#endif
+// The offset broadcast and the row-offset add are ONE v_add_u32_dpp (inline asm: left to itself the compiler emits
+// v_mov_b32_dpp + v_add_u32, because it sinks the add to the predicated loads).  The two wait states a DPP read needs after a
+// VALU write of its source are the s_nop: inline asm is opaque to the hazard recogniser.
 template <int R>
 __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const FetchPlan &p, float4 *__restrict__ s_quad_k) {
   constexpr int PERM = R == 0 ? 0x40 : (R == 1 ? 0xA5 : 0xFE);
@@ -103,7 +85,6 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
   // (all DPP reads before the divergent part: a source lane that sits out this round must still be enabled when it is read)
   uint32_t off[8];
   float w[8];
-#if IA_QUAD_ASM_DPP_ADD
   asm volatile("s_nop 1");
 #pragma unroll
   for (int c = 0; c < 8; c++) {
@@ -111,17 +92,11 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
                  : "=v"(off[c]) : "v"(p.off[c]), "v"(koff), "i"(PERM & 3), "i"((PERM >> 2) & 3), "i"((PERM >> 4) & 3), "i"((PERM >> 6) & 3));
     w[c] = quad_perm<PERM>(p.w[c]);
   }
-  const uint32_t kadd = 0;
-#else
-#pragma unroll
-  for (int c = 0; c < 8; c++) { off[c] = quad_perm<PERM>(p.off[c]); w[c] = quad_perm<PERM>(p.w[c]); }
-  const uint32_t kadd = koff;
-#endif
   if (load != 0) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 v[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)(off[c] + kadd));
+    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)off[c]);
     f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) {

@@ -32,9 +32,52 @@ def shard_frames(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
+def shard_rows(n_rows, rank, world_size):
+    """Intra-frame sharding for latency (optional): rank r renders the contiguous block of image rows
+    [r0, r1) -- blocks differ by at most one row, empty when there are more ranks than rows."""
+    base, extra = divmod(int(n_rows), int(world_size))
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
 def _dist():
     import torch.distributed as dist
     return dist
+
+
+def render_frame_tiled(model, batch, img_size, world_size=1, rank=0, jitter=None, gather=True):
+    """ONE frame split over the ranks by image rows (config 5's 1024^2 frame is 7 ms on one GPU): every rank prepares the
+    deformer and rebuilds the per-frame occupancy grid itself (32 KB packed, deterministic given the same `jitter`: no
+    exchange), renders its block of rows through `model.render_image_fast`, and the blocks are all-gathered (RCCL; the only
+    collective, 4 x 4 bytes per ray + the sample counters).  A ray's march and compositing do not depend on which other rays
+    are alive -- only the per-ray SAMPLE COUNTER does (it follows the N_step schedule, raymarcher_acc.py:104, which depends
+    on the number of alive rays) -- so rgb / depth / alpha equal the single-GPU frame bit for bit (tests/test_gpu_fullconfig.py).
+    `jitter` must be the same on every rank (pass the tensor, or seed every rank's generator alike).
+    Returns (rgb, depth, alpha, counter) of the whole frame on every rank (gather=False: of this rank's rows only)."""
+    import torch
+    H, W = int(img_size[0]), int(img_size[1])
+    r0, r1 = shard_rows(H, rank, world_size)
+    sub = dict(batch)
+    for k in ("rays_o", "rays_d", "near", "far"):
+        sub[k] = batch[k][:, r0 * W:r1 * W].contiguous()
+    outs = model.render_image_fast(sub, (r1 - r0, W), jitter=jitter) if r1 > r0 else None
+    if not gather or not collectives_on(world_size):
+        return outs
+    dist = _dist()
+    dev = batch["rays_o"].device
+    full = []
+    shapes = [(3,), (), (), ()]
+    dtypes = [torch.float32, torch.float32, torch.float32, outs[3].dtype if outs is not None else torch.int32]
+    rows = [shard_rows(H, r, world_size) for r in range(world_size)]
+    pad = max(b - a for a, b in rows)          # the collective wants equal blocks: pad to the largest (they differ by <= 1 row)
+    for i, (sh, dt) in enumerate(zip(shapes, dtypes)):
+        parts = [torch.empty((1, pad, W) + sh, device=dev, dtype=dt) for _ in range(world_size)]
+        mine = torch.zeros((1, pad, W) + sh, device=dev, dtype=dt)
+        if outs is not None:
+            mine[:, :r1 - r0] = outs[i].reshape((1, r1 - r0, W) + sh).to(dt)
+        dist.all_gather(parts, mine)
+        full.append(torch.cat([p[:, :b - a] for p, (a, b) in zip(parts, rows)], dim=1))
+    return tuple(full)
 
 
 def reduce_density_cache(density_cached, world_size):

@@ -57,6 +57,50 @@ def test_gloo_world2_grad_average_density_max_and_sharding():
     assert f0 == [0, 2, 4, 6] and f1 == [1, 3, 5]
 
 
+def _tile_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from instantavatar_amd.parallel import render_frame_tiled, shard_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = 7, 5                      # 7 rows over 2 ranks: blocks of 4 and 3 rows
+
+    class Fake:                      # stands in for AvatarModel: "renders" a function of the ray it is given
+        def render_image_fast(self, batch, img_size, jitter=None):
+            o = batch["rays_o"]
+            assert o.shape[1] == img_size[0] * img_size[1]
+            rgb = o.reshape(1, *img_size, 3) * 2.0
+            dep = batch["near"].reshape(1, *img_size) + 1.0
+            return rgb, dep, dep * 0.5, (dep * 10).to(torch.int32)
+    idx = torch.arange(H * W, dtype=torch.float32)
+    batch = {"rays_o": torch.stack([idx, idx + 0.25, idx + 0.5], -1)[None], "rays_d": torch.zeros(1, H * W, 3),
+             "near": idx[None].clone(), "far": idx[None] + 2}
+    rgb, dep, alpha, cnt = render_frame_tiled(Fake(), batch, (H, W), world, rank)
+    ok = (rgb.shape == (1, H, W, 3) and torch.equal(rgb.reshape(-1, 3), batch["rays_o"][0] * 2) and torch.equal(dep.reshape(-1), idx + 1)
+          and torch.equal(alpha.reshape(-1), (idx + 1) * 0.5) and cnt.dtype == torch.int32 and torch.equal(cnt.reshape(-1), ((idx + 1) * 10).to(torch.int32)))
+    q.put((rank, bool(ok), shard_rows(H, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_intra_frame_row_sharding_gathers_the_whole_frame():
+    """one frame split by image rows over the ranks and all-gathered; ragged blocks (7 rows on 2 ranks)."""
+    from instantavatar_amd.parallel import shard_rows
+    assert [shard_rows(7, r, 2) for r in range(2)] == [(0, 4), (4, 7)]
+    assert [shard_rows(2, r, 3) for r in range(3)] == [(0, 1), (1, 2), (2, 2)]          # more ranks than rows: an empty block
+    assert [shard_rows(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and [r[2] for r in res] == [(0, 4), (4, 7)]
+
+
 def test_single_process_is_identity():
     from instantavatar_amd.parallel import shard_frames, reduce_density_cache
     assert shard_frames(5, 0, 1) == [0, 1, 2, 3, 4]

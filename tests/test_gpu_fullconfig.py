@@ -224,3 +224,30 @@ def test_bench_configuration_parity_1024(oracle, bench_world):
     rgb, depth, alpha, counter = model.render_image_fast(make_batch(DEV, res, poses[3], tr[3]), (res, res),
                                                          jitter=torch.as_tensor(jit, device=DEV))
     _check(rgb, alpha, counter, model.renderer.density_grid_test.density_field, ref, "1024^2")
+
+
+def test_intra_frame_row_sharding_equals_the_whole_frame(bench_world):
+    """SURVEY 8e (optional intra-frame sharding for latency; BASELINE config 5 renders 1024^2): the frame rendered as the row
+    blocks 8 ranks would take (`parallel.shard_rows`), one after the other on this GPU, against the whole frame.  A ray's march
+    and compositing do not depend on which other rays are alive: rgb / depth / alpha must be BIT-EQUAL; the per-ray sample
+    counter follows the N_step schedule (fewer alive rays -> more steps per iteration) and is only required to be >= the
+    samples the whole-frame render needed to reach the same result."""
+    from instantavatar_amd.parallel import render_frame_tiled, shard_rows
+    model, body, fp, init, poses, tr = bench_world
+    res, world = 512, 8
+    jit = torch.rand((5, G ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(77))
+    batch = make_batch(DEV, res, poses[2], tr[2])
+    full = [t.clone() for t in model.render_image_fast(batch, (res, res), jitter=jit)]
+    parts = []
+    for r in range(world):
+        out = render_frame_tiled(model, make_batch(DEV, res, poses[2], tr[2]), (res, res), world, r, jitter=jit, gather=False)
+        r0, r1 = shard_rows(res, r, world)
+        assert out[0].shape == (1, r1 - r0, res, 3)
+        parts.append([t.clone() for t in out])
+    for i, name in enumerate(("rgb", "depth", "alpha")):
+        got = torch.cat([p[i] for p in parts], dim=1)
+        assert torch.equal(got, full[i]), (name, float((got - full[i]).abs().max()))
+    cnt = torch.cat([p[3] for p in parts], dim=1)
+    assert (full[2] > 0.5).float().mean() > 0.02
+    hit = full[2] > 0.01
+    assert bool((cnt[hit] >= 1).all()) and float((cnt.float() - full[3].float()).abs().mean()) < 64

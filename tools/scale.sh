@@ -13,9 +13,9 @@ port=29500
 for n in 1 2 4 8; do
   [ $n -le $MAXN ] || break
   if [ $n -gt $HAVE ]; then echo "N=$n: only $HAVE device(s) here, skipped"; continue; fi
-  for mode in render train; do
+  for mode in render train tile; do
     port=$((port + 1))
-    extra=""; [ $mode = train ] && extra="--train-only"
+    extra=""; [ $mode = train ] && extra="--train-only"; [ $mode = tile ] && extra="--tile-shard"
     log=$OUT/${mode}_n$n
     timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
         $R/bench.py --gpus $n --steps $STEPS --warmup 5 --cpu-frames 0 --train-steps 0 $extra > $log.json 2> $log.err
