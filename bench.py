@@ -336,7 +336,8 @@ def rank_report(rank, world_size, dev, extra):
     """One record per rank, gathered on rank 0 and echoed by every rank on stderr: what each process really saw (device, RCCL
     world size and backend, its own counts), so that a scaling run explains itself without the builder present."""
     import torch.distributed as dist
-    rec = {"rank": rank, "device": (torch.cuda.get_device_name(dev) if dev is not None else "cpu (dry run)"), "device_index": (dev.index if dev is not None else None),
+    rec = {"rank": rank, "shared_device_dev_mode": os.environ.get("IA_BENCH_SHARE_DEVICE") == "1",
+           "device": (torch.cuda.get_device_name(dev) if dev is not None else "cpu (dry run)"), "device_index": (dev.index if dev is not None else None),
            "world_size_seen": (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1),
            "backend": (dist.get_backend() if dist.is_available() and dist.is_initialized() else None),
            "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "pid": os.getpid()}
@@ -360,7 +361,7 @@ def _free_port():
 def relaunch_distributed(args):
     """`python bench.py --gpus N` started directly (no WORLD_SIZE): run N ranks of this script on this
     node through torch.distributed.run, rendezvous on 127.0.0.1, and return their exit code."""
-    if not args.dry_run:
+    if not args.dry_run and os.environ.get("IA_BENCH_SHARE_DEVICE") != "1":
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if n_dev < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, n_dev))
@@ -481,13 +482,24 @@ def main():
         return dry_run(args, rank, world_size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # IA_BENCH_SHARE_DEVICE=1 (development / tests/test_gpu_collectives.py): all ranks of an N > 1 run share cuda:0 and talk
+    # over gloo -- RCCL refuses two ranks on one device.  Exercises the N-rank control flow of this file with the real kernels
+    # on a one-GPU box (sharding, gathers, barriers, per-rank reports, the eager N-rank training step); the numbers it prints
+    # are NOT scaling figures and the line says so.
+    share = os.environ.get("IA_BENCH_SHARE_DEVICE") == "1" and world_size > 1
+    if share:
+        local_rank = 0
+        os.environ["IA_GRAPH_COLLECTIVES"] = "0"     # gloo collectives cannot be captured into a HIP graph
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d needs GPU %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
     elif args.force_collectives:
         import torch.distributed as dist

