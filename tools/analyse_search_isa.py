@@ -3,7 +3,7 @@
     python tools/analyse_search_isa.py                 # the shipped configuration
     python tools/analyse_search_isa.py -DIA_QUAD_ASM_DPP_ADD=1 -DIA_PLAN_FACTOR_ZERO=1
 
-Compiles instantavatar_amd/csrc/ia_snarf.hip to assembly (device only), cuts out the lane state machine of k_search<1> (the
+Compiles instantavatar_amd/csrc/ia_search.hip to assembly (device only), cuts out the lane state machine of k_search<1> (the
 loop that holds the global_load_dwordx4 of the trilinear fetch) and counts its instructions by class.  The counts are STATIC
 (every path of the loop body once: refill, first iteration, update, done); the dynamic count per wave-step is lower (the
 refill and done paths are taken rarely) -- profiles/r03_pmc_issue/ has the executed totals."""
@@ -39,7 +39,7 @@ CLASSES = [
 
 
 def main(flags):
-    src = os.path.join(ROOT, "instantavatar_amd", "csrc", "ia_snarf.hip")
+    src = os.path.join(ROOT, "instantavatar_amd", "csrc", "ia_search.hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *flags, "-x", "hip",
