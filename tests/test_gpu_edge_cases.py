@@ -187,7 +187,11 @@ def test_eval_driver_refines_renders_and_measures(tmp_path, capsys):
         ss.append(float(ssim(pred.permute(2, 0, 1)[None], gt.permute(2, 0, 1)[None])))
     lines = open(os.path.join(out, "results.txt")).read().splitlines()
     assert lines == ["PSNR: %.2f" % np.mean(ps), "SSIM: %.4f" % np.mean(ss)]
-    assert np.mean(ps) > 15 and np.mean(ss) > 0.7                               # 0.03 rad off a pose the field knows: close, not equal
+    print("eval driver on the synthetic subject: PSNR %s -> %.2f, SSIM %s -> %.4f" % (np.round(ps, 2), np.mean(ps), np.round(ss, 4), np.mean(ss)))
+    # measured on the MI355X (round 4, three runs, identical): PSNR 25.09 / 25.45 / 24.24 -> 24.93, SSIM 0.9238 / 0.9265 / 0.9124 -> 0.9209
+    # (0.03 rad off a pose the field knows, two refinement epochs: close, not equal); round 3 had loosened these bounds to 15 / 0.7
+    # without a measurement
+    assert np.mean(ps) > 22 and np.mean(ss) > 0.88
 
 
 def test_render_image_fast_takes_the_refined_smpl_tables_when_is_refine():
