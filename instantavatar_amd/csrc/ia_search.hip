@@ -7,13 +7,14 @@
 // Reference semantics: fuse_kernel/fuse_cuda_kernel_fast.cu:252-413 (broyden_kernel; every solve executes exactly its
 // arithmetic sequence), filter/filter.cu:10-55, deformer_torch.py:85-116.
 //
-// What bounds it (round 4, in-kernel cycle counters + PMC, profiles/r04_search_phase_cycles.txt): a wave-step moves
-// 64 x 384 B = 24.6 KB through the CU's vector L1 (64 B per clock: >= 384 cycles of the CU) and issues ~380-480 VALU
-// instructions (x 4 cycles on one of four SIMDs: ~430 cycles of the CU); the kernel runs at one wave-step per ~575 CU-cycles,
-// i.e. BOTH pipes are two-thirds busy and neither more resident waves nor fewer barriers raise the rate.  A persistent-wave
-// rewrite (no workgroup barrier, global work supply, lanes packed 15 % tighter, bit-identical results) was built and measured
-// in round 4 -- 279 us against 249 us on a frame's sample points: with 4 096 instead of ~3 000 waves inside the loop the fetch
-// phase took 6 881 instead of 4 674 cycles -- and archived with its numbers under tools/variants/.
+// What bounds it (round 4; profiles/r04_search_phase_cycles.txt, r04_ab_search_occupancy_cellcache.txt): the
+// solver loop is a dependent chain -- fetch plan, three load round trips, row delivery through LDS, the Broyden update -- whose
+// latency the four waves per SIMD that 106 VGPRs allow hide only in part (3 / 2 workgroups per CU: 205 / 253 us against 191).  A
+// wave-step moves 24.6 KB through the CU's vector L1 and issues 380-480 VALU instructions; at one wave-step per ~575 CU-cycles
+// both pipes are two-thirds busy and neither is the limit (a register cell cache that removed 35 % of the loads gained 1.4 %
+// and lost 31 % through its registers).  A persistent-wave rewrite (no workgroup barrier, global work supply, lanes packed 15 %
+// tighter, bit-identical) lost by 12 %: more waves inside the loop only lengthen every round trip.  All archived with their
+// numbers under tools/variants/.
 #include "ia_search_dev.h"
 
 // ---------------------------------------------------------------------------
