@@ -851,6 +851,17 @@ def main():
                     "avg_launch_us_in_pass", "launches")
             roof["counters"] = {v: {k: cj[v][k] for k in keep if k in cj[v]} for v in ("k_search/probe", "k_search/render") if v in cj}
         roof["counters_source"] = csrc
+        if tj is not None:
+            # the streaming kernel of the path priced against HBM from the same counter passes (FETCH_SIZE x 2 + WRITE_SIZE and
+            # the launch time inside those passes): k_precompute reads the 50.3 MB skinning-weight volume and writes the 25.2 MB
+            # transform grid once per frame (81.8 MB algorithmic)
+            try:
+                pc = tj["k_precompute"]
+                roof["precompute_hbm"] = {"algorithmic_bytes": 81.8e6, "traffic": pc["hbm_bytes_per_launch"], "avg_launch_us_in_pass": pc["avg_launch_us_in_pass"],
+                                          "achieved": pc["hbm_bytes_per_launch"] / (pc["avg_launch_us_in_pass"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": pc["hbm_bytes_per_launch"] / (pc["avg_launch_us_in_pass"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": tsrc}
+            except Exception:
+                pass
 
     frames = args.steps * world_size
     fps = frames / dt
