@@ -531,6 +531,10 @@ int ia_profile_get(int kernel_id, double *total_ms, int64_t *launches,
 /* measurement helper: acc2[0] += mean(counter), acc2[1] += mean(alpha > 0.5) over the R rays of a rendered frame
  * (what a caller logging samples per ray / coverage of a sequence accumulates), one launch.                     */
 int ia_frame_stats(const float *counter, const float *alpha, int R, float *acc2, void *stream);
+/* 8-bit RGBA image of a rendered frame: rgba[4 i + c] = (uint8)(clamp(v, 0, 1) * 255), v = rgb[3 i + c] (c < 3) or
+ * alpha[i] (c = 3) -- replaces `torch.cat([rgb, alpha[..., None]], -1)` + `(img.cpu().numpy() * 255).astype(np.uint8)` of
+ * the frame loop (animate.py:107-113, novel_view.py:120-125).  rgba: R x 4 bytes, 4-byte aligned, channel order as given. */
+int ia_pack_rgba8(const float *rgb, const float *alpha, int R, uint8_t *rgba, void *stream);
 /* all n (<= 8) counters of a kernel: id 0 -> {solves, trilinear fetches of the algorithm (fuse_cuda_kernel_fast.cu:
  * one per Broyden evaluation), fetches that loaded memory (a fetch whose 8 corners all lie outside the grid is zero
  * without a load)}; id 1 -> {samples evaluated}.  Synchronises.                                                  */

@@ -128,6 +128,7 @@ _SIGS = {
     "ia_profile_get_units": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "ia_pack_rgba8": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "ia_selftest_shared_rcp": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ia_selftest_jinv_update": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
 }
@@ -142,6 +143,17 @@ def lib():
             raise ImportError(
                 "instantavatar_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        # a library built from other sources than this checkout is an error, not something to run silently (edit a kernel,
+        # forget to rebuild, and every number is the OLD kernel's).  The manifest is read from the file's bytes; variants
+        # built with IA_EXTRA_HIPCC_FLAGS carry the flags in their hashes, so the same variable must be set when they run.
+        if os.environ.get("IA_ALLOW_STALE_LIB", "0") != "1":
+            from . import build
+            have, want = build.library_manifest(LIB_PATH), build.source_manifest()
+            if have != want:
+                diff = sorted(k for k in set(have) | set(want) if have.get(k) != want.get(k))
+                raise ImportError(
+                    "instantavatar_amd: %s was built from other sources than this checkout (differs in: %s). Rebuild it "
+                    "(`python -m instantavatar_amd.build`), or set IA_ALLOW_STALE_LIB=1 to run it anyway." % (LIB_PATH, ", ".join(diff)))
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if a symbol is missing

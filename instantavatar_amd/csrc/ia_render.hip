@@ -1056,6 +1056,29 @@ extern "C" int ia_frame_stats(const float *counter, const float *alpha, int R, f
   return IA_OK;
 }
 
+// 8-bit RGBA frame of a rendered image, as animate.py:107-113 stores it: img = cat(rgb, alpha) ; (img * 255).astype(uint8)
+// -- the product in fp32, truncated towards zero; values outside [0, 1] (rgb = colour + T * bg can exceed 1 by an ulp) are
+// clamped first (numpy's out-of-range float -> uint8 cast is undefined).  One launch, one 32-bit store per ray: the frame leaves the
+// device as 4 bytes per ray instead of 16, and the caller's stream carries one kernel instead of cat / clamp / mul / cast.
+__global__ __launch_bounds__(256) void k_pack_rgba8(const float *__restrict__ rgb, const float *__restrict__ alpha, int R,
+                                                    uint32_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  auto q = [](float v) -> uint32_t { return (uint32_t)(fminf(fmaxf(v, 0.f), 1.f) * 255.f); };
+  out[i] = q(rgb[3 * i]) | (q(rgb[3 * i + 1]) << 8) | (q(rgb[3 * i + 2]) << 16) | (q(alpha[i]) << 24);
+}
+
+extern "C" int ia_pack_rgba8(const float *rgb, const float *alpha, int R, uint8_t *rgba, void *stream) {
+  IA_CHECK_ARG(R >= 0, "ia_pack_rgba8: R < 0");
+  if (R == 0) return IA_OK;
+  IA_CHECK_ARG(rgb && alpha && rgba, "ia_pack_rgba8: null pointer");
+  IA_CHECK_ARG((reinterpret_cast<uintptr_t>(rgba) & 3) == 0, "ia_pack_rgba8: rgba must be 4-byte aligned");
+  hipLaunchKernelGGL(k_pack_rgba8, dim3(ia_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, rgb, alpha, R,
+                     reinterpret_cast<uint32_t *>(rgba));
+  IA_LAUNCH_CHECK("k_pack_rgba8");
+  return IA_OK;
+}
+
 extern "C" int ia_transform_rays_w2s(const float *rays_o, const float *rays_d, const float *w2s, int R, float *o_out,
                                      float *d_out, float *near, float *far, void *stream) {
   IA_CHECK_ARG(R >= 0, "ia_transform_rays_w2s: R < 0");

@@ -110,9 +110,12 @@ def main(argv=None):
     ap.add_argument("--lpips-trunk", help="a saved torchvision alexnet().features.state_dict()")
     ap.add_argument("--out", default="eval_out")
     args = ap.parse_args(argv)
-    if not torch.cuda.is_available():
-        raise SystemExit("eval: needs a GPU (the product path has no CPU fallback)")
-    device = torch.device("cuda", 0)
+    from .launch import Launch
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the refinement steps ONE optimiser over the test frames in sequence (eval.py:70-97) and the metrics are means over
+        # all files: a few seconds of work that does not shard without changing Adam's step counts -- one process
+        raise SystemExit("eval: a single-process driver (start it without torch.distributed.run)")
+    device = Launch.from_env(who="eval").device     # cuda:LOCAL_RANK
     torch.manual_seed(42)
     teacher, _, _ = build_synthetic_model(device)
     model, _, _ = build_synthetic_model(device)

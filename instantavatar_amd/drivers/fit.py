@@ -42,24 +42,32 @@ def build_fit_model(frames, body_model, device, threshold=0.05, n_levels=16):
 
 
 def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, loss_opt=None, log_every=50, out=sys.stdout,
-                 generator=None, check_val_every_n_epoch=10):
+                 generator=None, check_val_every_n_epoch=10, rank=0, world_size=1):
     """The optimisation loop of fit.py (trainer.fit with SNARF_NGP_fitting.yaml: Adam lr 1e-3, SMPL tables lr 1e-4, one frame
     per step; the LambdaLR steps once per validation run = every `check_val_every_n_epoch` epochs, DNeRF.py:163-166 -- see
-    training.configure_scheduler).  Returns the last losses."""
+    training.configure_scheduler).  Returns the last losses.
+    world_size > 1: every rank calls this; replicas start from rank 0's state, rank r takes positions r, r + W, ... of the
+    epoch's (shared) shuffle -- a frame's SMPL rows receive a gradient from the rank that drew the frame only, the average
+    over ranks scales it by 1 / W, which Adam's normalisation absorbs -- and an epoch is ceil(frames / W) steps."""
+    from ..parallel import broadcast_module_state
+    broadcast_module_state(model, world_size)
     opt = configure_optimizer(model, lr=lr, smpl_lr=smpl_lr)
     sched = configure_scheduler(opt, max_epochs)
     loss_fn = NGPLoss(loss_opt or dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
     model.train()
     n = len(frames)
+    if generator is None and world_size > 1:
+        generator = torch.Generator().manual_seed(42)      # the ranks must shuffle alike (pl.seed_everything(42) in the reference)
+    per_epoch = -(-n // world_size)
     order = torch.randperm(n, generator=generator).tolist()
     t0 = time.perf_counter()
     losses = None
     for it in range(steps):
-        if it % n == 0 and it > 0:
-            if (it // n) % check_val_every_n_epoch == 0:
+        if it % per_epoch == 0 and it > 0:
+            if (it // per_epoch) % check_val_every_n_epoch == 0:
                 sched.step()
             order = torch.randperm(n, generator=generator).tolist()   # DataLoader(shuffle=True)
-        losses = training_step(model, frames.batch(order[it % n]), opt, loss_fn)
+        losses = training_step(model, frames.batch(order[((it % per_epoch) * world_size + rank) % n]), opt, loss_fn, world_size=world_size)
         if log_every and (it + 1) % log_every == 0:
             torch.cuda.synchronize()
             print("fit step %d  loss %.5f  mse %.5f  %.1f it/s" % (it + 1, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),
@@ -104,14 +112,19 @@ def main(argv=None):
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--out", default="outputs/fit")
     args = ap.parse_args(argv)
-    if not torch.cuda.is_available():
-        raise SystemExit("fit: needs a GPU (the product path has no CPU fallback)")
-    device = torch.device("cuda", 0)
-    frames, body_model, _ = synthetic_frames(device, res=args.res)
-    model = build_fit_model(frames, body_model, device)
-    losses = fit_sequence(model, frames, args.steps)
-    path = export_params(model, args.out)
-    print("saved %s (mse %.5f)" % (path, float(losses["mse_loss"])))
+    from .launch import Launch
+    launch = Launch.from_env(who="fit")
+    try:
+        device = launch.device
+        frames, body_model, _ = synthetic_frames(device, res=args.res)
+        model = build_fit_model(frames, body_model, device)
+        losses = fit_sequence(model, frames, args.steps, rank=launch.rank, world_size=launch.world_size, log_every=50 if launch.is_main else 0)
+        if launch.is_main:     # replicas are identical: rank 0 exports
+            path = export_params(model, args.out)
+            print("saved %s (mse %.5f, %d rank(s))" % (path, float(losses["mse_loss"]), launch.world_size))
+        launch.barrier()
+    finally:
+        launch.close()
     return 0
 
 

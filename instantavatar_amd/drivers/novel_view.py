@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import torch
 
-from .animate import build_model, make_rays, render_sequence
+from .animate import add_launch_args, build_model, fixed_jitter, make_rays, render_sequence
 
 
 def rotvec_to_matrix(v):
@@ -80,11 +80,13 @@ class RotationSequence:
     def __len__(self):
         return self.num_frames
 
-    def batch(self, idx):
+    def batch(self, idx, rays=True):
+        """rays=False: the SMPL parameters only (see animate.AnimateSequence.batch)"""
+        pose = {"betas": self.betas, "global_orient": self.global_orient[idx:idx + 1], "body_pose": self.body_pose, "transl": self.transl}
+        if not rays:
+            return pose
         ones = torch.ones(1, self.rays_d.shape[1], device=self.rays_d.device)
-        return {"rays_o": self.rays_o, "rays_d": self.rays_d, "betas": self.betas,
-                "global_orient": self.global_orient[idx:idx + 1], "body_pose": self.body_pose, "transl": self.transl,
-                "near": ones * 0, "far": ones * 10}
+        return {"rays_o": self.rays_o, "rays_d": self.rays_d, **pose, "near": ones * 0, "far": ones * 10}
 
 
 def main(argv=None):
@@ -102,17 +104,24 @@ def main(argv=None):
     ap.add_argument("--downscale", type=int, default=2)
     ap.add_argument("--out", default="animation/rotation")
     ap.add_argument("--no-gif", action="store_true")
+    add_launch_args(ap)
     args = ap.parse_args(argv)
-    if not torch.cuda.is_available():
-        raise SystemExit("novel_view: needs a GPU (the product path has no CPU fallback)")
     if not args.synthetic and not args.ckpt:
         ap.error("--ckpt is required unless --synthetic is given")
-    device = torch.device("cuda", 0)
-    model, betas = build_model(args, device)
-    model.eval()
-    seq = RotationSequence(args.frames, betas, device, args.downscale)
-    n = render_sequence(model, seq, args.out, gif=None if args.no_gif else "rotation.gif")
-    print("wrote %d frames (%dx%d) to %s" % (n, seq.W, seq.H, args.out))
+    from .launch import Launch
+    launch = Launch.from_env(who="novel_view")
+    device = launch.device
+    try:
+        model, betas = build_model(args, device, quiet=not launch.is_main)
+        model.eval()
+        seq = RotationSequence(args.frames, betas, device, args.downscale)
+        jitter = None if args.jitter_seed is None else fixed_jitter(args.jitter_seed, device)
+        res = render_sequence(model, seq, args.out, gif=None if args.no_gif else "rotation.gif", launch=launch,
+                              in_flight=args.in_flight, jitter=jitter)
+        if launch.is_main:
+            print("wrote %d frames (%dx%d) to %s" % (res["frames"], seq.W, seq.H, args.out))
+    finally:
+        launch.close()
     return 0
 
 

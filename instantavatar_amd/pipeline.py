@@ -70,19 +70,21 @@ class GraphedRenderer:
     them; they must be re-rendered through `model.render_image_fast`).  `sync_check=True` checks
     before returning."""
 
-    def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False, probe_batches=()):
+    def __init__(self, model, batch, img_size, warmup=3, margin=4, sync_check=False, probe_batches=(), jitter=None):
         """probe_batches: further batches (other poses of the sequence) rendered once eagerly to measure
         how many wave-front iterations the sequence needs; with a representative sample a small
-        `margin` is enough (every idle iteration costs five empty launches per frame)."""
-        self.model, self.img_size, self.sync_check = model, img_size, sync_check
+        `margin` is enough (every idle iteration costs five empty launches per frame).
+        jitter: a fixed occupancy-probe jitter ([5, 64^3, 3] in [0, 1), DensityGrid.initialize) read by every replay
+        instead of a fresh draw -- frames then depend on their pose only, whichever rank / replica / replay renders them."""
+        self.model, self.img_size, self.sync_check, self.jitter = model, img_size, sync_check, jitter
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         r = model.renderer
         need = 0
         for b in probe_batches:
-            model.render_image_fast(b, img_size)
+            model.render_image_fast(b, img_size, jitter=jitter)
             need = max(need, r.iters_executed())
         for _ in range(warmup):  # settles workspace sizes, fp16 shadows and the iteration count
-            model.render_image_fast(self.static, img_size)
+            model.render_image_fast(self.static, img_size, jitter=jitter)
             need = max(need, r.iters_executed())
         r._iters_hint = need + margin   # (no parity constraint: the alive lists ping-pong on the absolute iteration index)
         torch.cuda.synchronize()
@@ -92,7 +94,7 @@ class GraphedRenderer:
             # thread_local: other threads of the process (e.g. the RCCL watchdog of a multi-GPU job)
             # may touch the runtime while this thread captures
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.out = model.render_image_fast(self.static, img_size)
+                self.out = model.render_image_fast(self.static, img_size, jitter=jitter)
         finally:
             r._graph_capture = False
         # deferred alive check: a ring of pinned slots, polled without blocking -- the host may run up
@@ -159,14 +161,14 @@ class PipelinedRenderer:
     runs in those gaps.  Measured on MI355X: 395 -> 483 frames/s with two frames in flight; per-frame latency rises from
     2.5 to ~4.1 ms.  Outputs of call i stay valid until call i + n_in_flight (same replica, same stream: no extra ordering needed)."""
 
-    def __init__(self, model, batch, img_size, n_in_flight=2, margin=1, probe_batches=()):
+    def __init__(self, model, batch, img_size, n_in_flight=2, margin=1, probe_batches=(), jitter=None):
         self.replicas = [model] + [clone_for_stream(model) for _ in range(n_in_flight - 1)]
         self.streams = [torch.cuda.Stream(device=batch["rays_o"].device) for _ in self.replicas]
         self.graphs = []
         for m, s in zip(self.replicas, self.streams):
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.graphs.append(GraphedRenderer(m, batch, img_size, margin=margin, probe_batches=probe_batches))
+                self.graphs.append(GraphedRenderer(m, batch, img_size, margin=margin, probe_batches=probe_batches, jitter=jitter))
             torch.cuda.current_stream().wait_stream(s)
         self.events = [torch.cuda.Event() for _ in self.replicas]
         self.calls = 0
