@@ -441,6 +441,32 @@ __global__ void k_fill_i32(int32_t *p, int32_t v, int n) {
 // Batched probes are laid out CELL-major: probe p is jitter set p % iters of cell p / iters, so the
 // `iters` jittered points of one cell are neighbours in the point list (same workgroup, adjacent
 // lanes): their solves start within one cell of each other and share transform-grid lines in L1.
+// Enumeration of the cells: probe p belongs to cell ia_probe_cell(p / iters) of the occupancy grid's own index [x][y][z] (z
+// fastest, raymarcher.cu:49-52).  IA_PROBE_ORDER_X = 0: in that order; 1: x fastest; 2: Morton.  The probe launch of the
+// search is bound by its vector-L1 miss path (hit rate 71 % against 92 % in the render launches, profiles/r04_pmc_search.json),
+// and which cells share a workgroup decides how many lines its lanes share.
+// Only the ORDER of the points changes: every cell keeps its jitter and its probes, the density is bit-identical.
+// Measured (profiles/r05_ab_probe.txt): x-fastest (1) +7 % on the probe launch, Morton (2) -2 %: a workgroup's 13 cells as a
+// compact block share the most 128-byte lines (simulated unique lines per live solve 2.37 -> 2.05).
+#ifndef IA_PROBE_ORDER_X
+#define IA_PROBE_ORDER_X 2
+#endif
+__device__ __forceinline__ int ia_probe_cell(int c, int G) {
+  if (IA_PROBE_ORDER_X == 0) return c;
+  if (IA_PROBE_ORDER_X == 2 && G == 64) {   // Morton: bits of c dealt to z, y, x in turn -> a workgroup's 13 cells form a compact block
+    int x = 0, y = 0, z = 0;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+      z |= ((c >> (3 * b)) & 1) << b;
+      y |= ((c >> (3 * b + 1)) & 1) << b;
+      x |= ((c >> (3 * b + 2)) & 1) << b;
+    }
+    return (x * G + y) * G + z;
+  }
+  const int x = c % G, y = c / G % G, z = c / (G * G);
+  return (x * G + y) * G + z;
+}
+
 __global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ jitter, int G, int iters,
                                                       const float *__restrict__ aabb,
                                                       float *__restrict__ pts, int32_t *__restrict__ n_cand) {
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(256) void k_probe_points(const float *__restrict__ 
   const int p = blockIdx.x * blockDim.x + threadIdx.x;  // jitter is [iters][n cells][3]
   if (p == 0) *n_cand = 0;  // candidate counter of the following search
   if (p >= n * iters) return;
-  const int i = p / iters, it = p - i * iters;
+  const int it = p % iters, i = ia_probe_cell(p / iters, G);
   const int idx[3] = {i / (G * G), i / G % G, i % G};
 #pragma unroll
   for (int d = 0; d < 3; d++) {
@@ -901,15 +927,16 @@ extern "C" size_t ia_density_init_workspace_bytes_batched(int G, int n_init, int
 __global__ __launch_bounds__(256) void k_probe_max(const float *__restrict__ cand_rgb,
                                                    const float *__restrict__ cand_sigma,
                                                    const int32_t *__restrict__ pt_off,
-                                                   const uint8_t *__restrict__ pt_cnt, int n, int iters, int n_init,
+                                                   const uint8_t *__restrict__ pt_cnt, int n, int G, int iters, int n_init,
                                                    float *__restrict__ density) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int i = ia_probe_cell(c, G);
   float m = 0.f;
   for (int it = 0; it < iters; it++) {
-    const size_t p = (size_t)i * iters + it;  // cell-major probe order (k_probe_points)
-    float sg, c[3];
-    cand_max(cand_rgb, cand_sigma, pt_off[p], pt_cnt[p], n_init, 0.f, true, sg, c);
+    const size_t p = (size_t)c * iters + it;  // cell-major probe order (k_probe_points)
+    float sg, col[3];
+    cand_max(cand_rgb, cand_sigma, pt_off[p], pt_cnt[p], n_init, 0.f, true, sg, col);
     m = fmaxf(m, sg);
   }
   density[i] = m;
@@ -940,7 +967,7 @@ extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const
     hipLaunchKernelGGL(k_probe_points, dim3(ia_div_up(n_all, 256)), blk, 0, s, jitter, G, iters, aabb, pts, q.n_cand);
     rc = query_impl(pts, n_all, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, iters, n_init, density);
+    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, G, iters, n_init, density);
     IA_LAUNCH_CHECK("density_grid_init");
     return ia_occupancy_from_density(density, G, occ_bits, occ_bool, occ_ws, ia_occupancy_workspace_bytes(G), s);
   }

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
         const int init = item >> 7, pt = item & (NP - 1);
         s_x[init][pt][0] = ok ? xl0 : 0.f; s_x[init][pt][1] = ok ? xl1 : 0.f; s_x[init][pt][2] = ok ? xl2 : 0.f;
         s_valid[init][pt] = ok;
+        if (ok) it_solves |= 0x80000000u;   // this lane found a root (bit 31: `solves` stays below 2^16)
         if (MODE == 0 && J_inv) {
           // Q4: the stored J_inv is the matrix BEFORE the last rank-1 update (:383-391)
           const size_t o = ((size_t)(p0 + pt) * n_init + init) * 9;
@@ -215,17 +216,32 @@ __global__ __launch_bounds__(IA_SEARCH_THREADS) IA_SEARCH_ATTR void k_search(
     }
   }
   if (prof) {  // bench-only accounting: solves and trilinear fetches
-    int f = (int)(counts & 0xFFFFu), n = (int)(it_solves >> 8), l = (int)(counts >> 16);
+    int f = (int)(counts & 0xFFFFu), n = (int)((it_solves >> 8) & 0xFFFFu), l = (int)(counts >> 16);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); n += __shfl_xor(n, o, 64); l += __shfl_xor(l, o, 64); }
     if (lane == 0) { atomicAdd(&s_prof[0], n); atomicAdd(&s_prof[1], f); atomicAdd(&s_prof[2], l); }
   }
-  __syncthreads();
+  const int any_root = __syncthreads_or((int)(it_solves >> 31));
   if (prof && tid == 0) {  // one pair of global atomics per workgroup, on a per-shard line
     unsigned long long *ps = prof + (size_t)(blockIdx.x & (IA_PROF_SHARDS - 1)) * 8;
     atomicAdd(ps, (unsigned long long)s_prof[0]);
     atomicAdd(ps + 1, (unsigned long long)s_prof[1]);
     atomicAdd(ps + 2, (unsigned long long)s_prof[2]);
+  }
+  // No root in the whole workgroup (most workgroups of the occupancy probes, whose points lie in empty space around the
+  // body): nothing to filter, nothing to compact -- every point gets count 0 at offset 0, which is what the compaction
+  // below writes for a workgroup without candidates (s_blockbase = 0, all prefix sums 0).  Four barriers and the filter's
+  // and the compaction's LDS sweeps less; measured neutral on the launch time (profiles/r05_ab_probe.txt: those cycles are
+  // waves waiting, not a resource the solver loops of the other waves compete for).
+#ifndef IA_SEARCH_EARLY_OUT
+#define IA_SEARCH_EARLY_OUT 1
+#endif
+  if (IA_SEARCH_EARLY_OUT && MODE != 0 && !any_root) {
+    if (tid < np) {
+      pt_off[p0 + tid] = 0;
+      pt_cnt[p0 + tid] = 0;
+    }
+    return;
   }
   // ---- a5 filter (filter.cu:27-51): drop i if a LATER valid candidate lies within 1e-4 ----
   for (int init0 = 0; init0 < n_init; init0 += IA_SEARCH_THREADS / NP) {

@@ -85,13 +85,19 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
   // (all DPP reads before the divergent part: a source lane that sits out this round must still be enabled when it is read)
   uint32_t off[8];
   float w[8];
-  asm volatile("s_nop 1");
+  // ONE asm statement: the s_nop and the eight DPP adds cannot be separated -- volatile asm is ordered only against other
+  // volatile asm, so with separate statements the compiler was free to sink a VALU producer of p.off[c] between the s_nop
+  // and a DPP read (the build checked clean, nothing enforced it).  Early-clobber outputs: all eight are
+  // written before the last input is read.
+#define IA_DPP_ADD(o, i) "v_add_u32_dpp %" #o ", %" #i ", %16 quad_perm:[%17,%18,%19,%20] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm volatile("s_nop 1\n\t" IA_DPP_ADD(0, 8) IA_DPP_ADD(1, 9) IA_DPP_ADD(2, 10) IA_DPP_ADD(3, 11) IA_DPP_ADD(4, 12) IA_DPP_ADD(5, 13)
+               IA_DPP_ADD(6, 14) IA_DPP_ADD(7, 15)
+               : "=&v"(off[0]), "=&v"(off[1]), "=&v"(off[2]), "=&v"(off[3]), "=&v"(off[4]), "=&v"(off[5]), "=&v"(off[6]), "=&v"(off[7])
+               : "v"(p.off[0]), "v"(p.off[1]), "v"(p.off[2]), "v"(p.off[3]), "v"(p.off[4]), "v"(p.off[5]), "v"(p.off[6]), "v"(p.off[7]),
+                 "v"(koff), "i"(PERM & 3), "i"((PERM >> 2) & 3), "i"((PERM >> 4) & 3), "i"((PERM >> 6) & 3));
+#undef IA_DPP_ADD
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "=v"(off[c]) : "v"(p.off[c]), "v"(koff), "i"(PERM & 3), "i"((PERM >> 2) & 3), "i"((PERM >> 4) & 3), "i"((PERM >> 6) & 3));
-    w[c] = quad_perm<PERM>(p.w[c]);
-  }
+  for (int c = 0; c < 8; c++) w[c] = quad_perm<PERM>(p.w[c]);
   if (load != 0) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 v[8];
