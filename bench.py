@@ -97,7 +97,24 @@ def cpu_baseline(body, fp, model, poses, tr, res, n_frames):
             times.append(time.time() - t0)
     med = float(np.median(times))
     cores = os.cpu_count() or 1
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+    # BASELINE config 1 ("config 1 ... and one 512x512 frame"): a 128 x 128 frame of the body in its
+    # canonical pose -- the deformer's transforms are the identity up to the root frame -- with an 8-level hash grid
+    cano = orc.smpl_forward(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), want_verts=False)["joints"]
+    fp8 = syn.make_field(np.asarray(cano, np.float32), init["bbox"], seed=42, n_levels=8)
+    ro1, rd1 = syn.make_camera_rays(128)
+    w1 = orc.make_world(body, init, fp8, np.zeros(10, np.float32), syn.cano_pose("A_pose"), poses[0, :3], tr[0], syn.INIT_BONES)
+    t1 = []
+    for i in range(4):                     # 1 warm-up + 3
+        jit = rng.rand(5, 64 ** 3, 3).astype(np.float32)
+        t0 = time.time()
+        out1 = orc.render_image_fast(w1, ro1, rd1, jit)
+        if i > 0:
+            t1.append(time.time() - t0)
+    med1 = float(np.median(t1))
+    config1 = {"value": 1.0 / med1, "unit": "frames/s", "rays_per_sec": 128 * 128 / med1, "frame_seconds": [round(t, 3) for t in t1],
+               "what": "BASELINE config 1: one 128x128 frame, canonical pose (identity deformer transforms), 8-level hash grid + 2x64 MLPs, "
+                       "occupancy build + render through oracle/ (C + OpenMP, fp32); 1 warm-up + median of 3"}
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port", "config1_128x128_identity_8_levels": config1,
             "sample": ("1 warm-up + %d full %dx%d frames of the bench's pose track (occupancy build + render) through oracle/ -- a C + OpenMP "
                        "restatement of the reference's algorithm (fp32), all host cores; median frame time.  The reference itself has no CPU "
                        "path (its kernels are CUDA-only), so this port stands in for the 'PyTorch-CPU path' of BASELINE.json" % (n_frames, res, res)),
@@ -183,6 +200,16 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             batch["bg_color"] = bg
             return stepper(batch)
 
+    from instantavatar_amd import parallel as _par
+    if graphed and stepper.enabled and _par.collectives_on(world_size):
+        # N ranks: three host-launched steps before anything is captured (step 0 is eager by rule; 1-2 are held back here):
+        # a mis-set-up communicator shows up as an ordinary RCCL error in an eager all-reduce, not inside a stream capture
+        stepper.enabled = False
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        stepper.enabled = True
     for i in range(max(warmup, 3)):
         step(i)
     torch.cuda.synchronize()
@@ -215,6 +242,7 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             "samples_candidates_last_step": list(getattr(r, "last_train_counts", ()) or ()),
             "launch_mode": ("hip_graph (%d replays, %d eager steps)" % (stepper.replays, stepper.eager_steps)) if stepper.replays
                            else "eager", "graph_capture_error": stepper.capture_error,
+            "graph_collectives": bool(stepper.replays) and _par.collectives_on(world_size),
             "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
@@ -382,6 +410,24 @@ def dry_run(args, rank, world_size):
     if world_size > 1:
         dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    if os.environ.get("IA_BENCH_CHILD") == "1":
+        # the child job of supervised_train, without kernels: its own group came up (on its own port), one collective, one line
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "train_rays_per_sec", "dry_run": True,
+                              "train": {"it_per_sec": 1.0, "rays_per_sec": 4096.0 * world_size, "ranks_in_child_group": int(t.item()),
+                                        "graph_collectives": os.environ.get("IA_GRAPH_COLLECTIVES", "1") != "0"}}))
+        dist.destroy_process_group()
+        return
+    if args.train_only and world_size > 1:
+        tr_res, sup = supervised_train(args, rank, world_size, max(args.steps, 1), dry=True)
+        if rank == 0:
+            print(json.dumps({"metric": "train_rays_per_sec", "value": (tr_res or {}).get("rays_per_sec"), "n_gpus": world_size, "dry_run": True,
+                              "train": dict(tr_res or {}, supervised=sup)}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     n_total = args.steps + args.warmup
     my = shard_frames(n_total * world_size, rank, world_size)
     assert len(my) == n_total
@@ -424,6 +470,52 @@ def dry_run(args, rank, world_size):
         dist.destroy_process_group()
 
 
+def supervised_train(args, rank, world_size, train_steps, dry=False):
+    """N > 1: the training measurement runs in a CHILD job -- every rank starts `bench.py --train-only` again as its own
+    child (same RANK / LOCAL_RANK / WORLD_SIZE, the next rendezvous port), the children form their own RCCL group and
+    rank 0's child prints the line this rank parses.  The parents only watch: a child that does not finish within
+    IA_BENCH_CHILD_TIMEOUT seconds (default 300; a hung stream capture of the RCCL collectives is the case this is for --
+    GraphedTrainStep has replayed captured collectives with a 1-rank group only) is killed BY PID, the parents agree (MIN
+    over ranks) that the attempt failed, and the phase is executed again with IA_GRAPH_COLLECTIVES=0 (eager N-rank steps).
+    A capture that merely FAILS is handled inside the child (GraphedTrainStep: the ranks agree and all launch eagerly).
+    Returns (the child's `train` dict on rank 0 / None elsewhere, report dict)."""
+    import torch.distributed as dist
+    timeout = float(os.environ.get("IA_BENCH_CHILD_TIMEOUT", "300"))
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    report = {"attempts": [], "timeout_s": timeout}
+    for attempt, graph_coll in enumerate(("1", "0")):
+        if attempt == 0 and os.environ.get("IA_GRAPH_COLLECTIVES", "1") == "0" and "IA_TEST_CHILD_HANG_RANK" not in os.environ:
+            continue      # already asked for eager collectives: a single attempt
+        # (without torchrun's TORCHELASTIC_* variables: with TORCHELASTIC_USE_AGENT_STORE the ranks would look for the AGENT's
+        # store on the new port, where nobody listens -- the children rendezvous on their own, rank 0's child hosts the store)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(IA_BENCH_CHILD="1", IA_BENCH_ATTEMPT=str(attempt), IA_GRAPH_COLLECTIVES=graph_coll, MASTER_PORT=str(base_port + 101 + attempt))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world_size), "--train-only", "--steps", str(train_steps),
+               "--warmup", str(max(args.warmup, 3)), "--res", str(args.res)] + (["--no-graph"] if args.no_graph else []) + (["--dry-run"] if dry else [])
+        t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+        out, state = "", "ok"
+        try:
+            out, _ = proc.communicate(timeout=timeout)
+            if proc.returncode != 0:
+                state = "exit code %d" % proc.returncode
+        except subprocess.TimeoutExpired:
+            proc.kill()           # the exact process this rank started
+            out, _ = proc.communicate()
+            state = "no result after %.0f s: killed" % timeout
+        ok = torch.tensor([1.0 if state == "ok" else 0.0], device=("cuda" if dist.get_backend() == "nccl" else "cpu"))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        report["attempts"].append({"IA_GRAPH_COLLECTIVES": graph_coll, "this_rank": state, "all_ranks_ok": bool(ok.item()),
+                                   "seconds": round(time.perf_counter() - t0, 1)})
+        if bool(ok.item()):
+            train = None
+            if rank == 0:
+                lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+                train = json.loads(lines[-1]).get("train") if lines else {"error": "the child printed no line"}
+            return train, report
+    return ({"error": "both attempts failed"} if rank == 0 else None), report
+
+
 def _device_code():
     """{translation unit: hash of its gfx950 code objects} of the library this process RUNS (ia_source_manifest)"""
     from instantavatar_amd import _lib
@@ -432,7 +524,7 @@ def _device_code():
 
 
 _DEV_CODE = [None]
-PMC_ROUNDS = ("r04", "r03")
+PMC_ROUNDS = ("r05", "r04", "r03")
 
 
 def _profile_json(stem, tus):
@@ -478,6 +570,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
+    if os.environ.get("IA_TEST_CHILD_HANG_RANK") == str(rank) and os.environ.get("IA_BENCH_CHILD") == "1" and os.environ.get("IA_BENCH_ATTEMPT") == "0":
+        time.sleep(10 ** 6)   # test hook: this rank's FIRST child never gets anywhere -- what a hung stream capture looks like from outside
     if args.dry_run:
         return dry_run(args, rank, world_size)
     if not torch.cuda.is_available():
@@ -562,6 +656,22 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
+    is_child = os.environ.get("IA_BENCH_CHILD") == "1"
+    if args.train_only and world_size > 1 and not is_child:
+        tr_res, sup = supervised_train(args, rank, world_size, max(args.steps, 1))
+        if rank == 0:
+            tr_res = dict(tr_res or {}, supervised=sup)
+            it = tr_res.get("it_per_sec")
+            print(json.dumps({"metric": "train_rays_per_sec", "value": tr_res.get("rays_per_sec"), "unit": "rays/s", "n_gpus": world_size,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": (1e3 / it if it else None),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "training_step, 4096 rays per step and GPU (PatchSampler 4 x 32 x 32 on %dx%d frames resident in "
+                                                     "HBM), SNARF_NGP defaults, Adam, occupancy update every 20 steps, RCCL gradient "
+                                                     "all-reduce; measured in a supervised child job (bench.supervised_train)" % (args.res, args.res)},
+                              "train": tr_res}))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     if args.train_only:
         tr_res = train_throughput(model, dev, poses, tr, rank, world_size, max(args.steps, 1), res=res, warmup=max(args.warmup, 3),
                                   graphed=not args.no_graph)
@@ -813,7 +923,9 @@ def main():
         # resident: the algorithmic bytes are served by the cache hierarchy, so the roof they are priced against
         # is the aggregate L2 bandwidth; the bytes that actually reached the fabric (PMC: FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/, accepted only when collected on THIS build) divided by the same launch time give the HBM fraction.
-        tj, tsrc = _profile_json("pmc_traffic", ("ia_search.hip",) if dom == "k_search" else ("ia_field.hip",))
+        # (every kernel is keyed on ITS translation unit: a summary of another unit's kernel must not pass for this one's)
+        KERNEL_TU = {"k_search": "ia_search.hip", "k_field": "ia_field.hip", "k_precompute": "ia_snarf.hip"}
+        tj, tsrc = _profile_json("pmc_traffic", (KERNEL_TU[dom],))
         traffic = None
         if tj is not None:
             try:
@@ -851,15 +963,16 @@ def main():
                     "avg_launch_us_in_pass", "launches")
             roof["counters"] = {v: {k: cj[v][k] for k in keep if k in cj[v]} for v in ("k_search/probe", "k_search/render") if v in cj}
         roof["counters_source"] = csrc
-        if tj is not None:
+        pj, psrc = _profile_json("pmc_traffic", (KERNEL_TU["k_precompute"],))   # k_precompute lives in ia_snarf.hip
+        if pj is not None:
             # the streaming kernel of the path priced against HBM from the same counter passes (FETCH_SIZE x 2 + WRITE_SIZE and
             # the launch time inside those passes): k_precompute reads the 50.3 MB skinning-weight volume and writes the 25.2 MB
             # transform grid once per frame (81.8 MB algorithmic)
             try:
-                pc = tj["k_precompute"]
+                pc = pj["k_precompute"]
                 roof["precompute_hbm"] = {"algorithmic_bytes": 81.8e6, "traffic": pc["hbm_bytes_per_launch"], "avg_launch_us_in_pass": pc["avg_launch_us_in_pass"],
                                           "achieved": pc["hbm_bytes_per_launch"] / (pc["avg_launch_us_in_pass"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": pc["hbm_bytes_per_launch"] / (pc["avg_launch_us_in_pass"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": tsrc}
+                                          "frac": pc["hbm_bytes_per_launch"] / (pc["avg_launch_us_in_pass"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": psrc}
             except Exception:
                 pass
 
@@ -906,7 +1019,11 @@ def main():
         result["hashgrid_lookup"] = hashgrid_roofline(model, dev, frame_batch=batches[0])
         mj, msrc = _profile_json("pmc_mfma", ("ia_field.hip",))
         result["mfma"] = dict(mj, source=msrc) if mj is not None else {"source": msrc}
-    if args.train_steps > 0:
+    if args.train_steps > 0 and world_size > 1:
+        tr_res, sup = supervised_train(args, rank, world_size, args.train_steps)     # (collective over the parents: every rank calls it)
+        if rank == 0:
+            result["train"] = dict(tr_res or {}, supervised=sup)
+    elif args.train_steps > 0:
         try:
             result["train"] = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph)
             u = train_throughput(model, dev, poses, tr, rank, world_size, args.train_steps, res=res, graphed=not args.no_graph,

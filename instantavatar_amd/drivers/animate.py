@@ -77,7 +77,7 @@ def build_model(args, device, quiet=False):
     if args.synthetic:
         model, _, _ = build_synthetic_model(device)
         if args.ckpt:  # synthetic body, trained weights (e.g. written by drivers.train --synthetic)
-            missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device)
+            missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, strict_self_check=True)
             if not quiet:
                 print("checkpoint %s loaded (step %d)" % (args.ckpt, model.global_step))
         return model, np.zeros(10, np.float32)
@@ -88,7 +88,7 @@ def build_model(args, device, quiet=False):
     betas = np.zeros(10, np.float32)
     if args.betas:
         betas = np.load(args.betas)["betas"].reshape(-1)[:10].astype(np.float32)
-    missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device)
+    missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, strict_self_check=True)
     if not quiet:
         print("checkpoint %s: %d tensors not on the path ignored, %d own tensors kept at init" % (args.ckpt, len(unexpected), len(missing)))
     if not getattr(deformer, "initialized", False):

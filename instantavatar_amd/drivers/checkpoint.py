@@ -16,12 +16,16 @@ def save_checkpoint(model, path, optimizer=None, epoch=0, scheduler=None):
     return path
 
 
-def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, optimizer=None, scheduler=None, skip_prefixes=()):
+def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, optimizer=None, scheduler=None, skip_prefixes=(),
+                    strict_self_check=False):
     """Returns (missing, unexpected).  The tcnn parameter vectors must have the tcnn-v1.6 layout this
     package restates ([MLP weights..., grid]); a size mismatch raises.  `optimizer` / `scheduler`: restored
     from Lightning's `optimizer_states[0]` / `lr_schedulers[0]` when the checkpoint holds them (resume).
     `skip_prefixes`: entries whose key starts with one of them stay at the model's own values (eval.py:64-67 keeps the freshly
-    built `SMPL_param` tables of the test frames and takes everything else from the checkpoint)."""
+    built `SMPL_param` tables of the test frames and takes everything else from the checkpoint).
+    `strict_self_check`: a loaded encoder that fails `NeRFNGPNet.self_check` (non-finite features or a constant level: what a
+    mis-laid-out table looks like) raises instead of warning.  The drivers that RENDER from a checkpoint (animate, novel_view,
+    eval) pass True -- garbage frames with exit code 0 are worse than a refusal; tooling that inspects checkpoints keeps False."""
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     net = getattr(model, "net_coarse", None)
@@ -69,6 +73,8 @@ def load_checkpoint(model, path, map_location="cpu", strict_path_keys=True, opti
             except ValueError as e:
                 import warnings
                 model.tcnn_self_check = {"failed": str(e)}
+                if strict_self_check:
+                    raise
                 warnings.warn("load_checkpoint: %s" % e)
     for g in ("density_grid_train", "density_grid_test"):
         grid = getattr(getattr(model, "renderer", None), g, None)

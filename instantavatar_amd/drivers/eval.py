@@ -120,7 +120,7 @@ def main(argv=None):
     teacher, _, _ = build_synthetic_model(device)
     model, _, _ = build_synthetic_model(device)
     if args.ckpt:
-        missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, skip_prefixes=("SMPL_param",))
+        missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, skip_prefixes=("SMPL_param",), strict_self_check=True)
         print("checkpoint %s loaded (step %d), SMPL_param entries skipped" % (args.ckpt, model.global_step))
     frames, true, start = synthetic_test_set(device, teacher, args.res, args.frames, args.pose_noise, args.transl_noise)
     from ..models.structures.body_model_param import SMPLParamEmbedding

@@ -52,14 +52,22 @@ def render_frame_tiled(model, batch, img_size, world_size=1, rank=0, jitter=None
     collective, 4 x 4 bytes per ray + the sample counters).  A ray's march and compositing do not depend on which other rays
     are alive -- only the per-ray SAMPLE COUNTER does (it follows the N_step schedule, raymarcher_acc.py:104, which depends
     on the number of alive rays) -- so rgb / depth / alpha equal the single-GPU frame bit for bit (tests/test_gpu_fullconfig.py).
-    `jitter` must be the same on every rank (pass the tensor, or seed every rank's generator alike).
-    Returns (rgb, depth, alpha, counter) of the whole frame on every rank (gather=False: of this rank's rows only)."""
+    `jitter` must be the same on every rank: pass the tensor, or leave it None and rank 0's draw is broadcast.
+    Returns (rgb, depth, alpha, counter) of the whole frame on every rank (gather=False: of this rank's rows only); the
+    counter is float32 on every rank, like the renderer's."""
     import torch
     H, W = int(img_size[0]), int(img_size[1])
     r0, r1 = shard_rows(H, rank, world_size)
     sub = dict(batch)
     for k in ("rays_o", "rays_d", "near", "far"):
         sub[k] = batch[k][:, r0 * W:r1 * W].contiguous()
+    if collectives_on(world_size) and world_size > 1:
+        dist = _dist()
+        if jitter is None:
+            # every rank rebuilds the occupancy grid itself: with a private draw per rank the blocks would come from DIFFERENT
+            # grids and the gathered frame would be a patchwork, silently.  One draw, rank 0's, for all (3.9 MB, once per frame)
+            jitter = torch.rand((5, 64 ** 3, 3), device=batch["rays_o"].device)
+            dist.broadcast(jitter, src=0)
     outs = model.render_image_fast(sub, (r1 - r0, W), jitter=jitter) if r1 > r0 else None
     if not gather or not collectives_on(world_size):
         return outs
@@ -67,7 +75,9 @@ def render_frame_tiled(model, batch, img_size, world_size=1, rank=0, jitter=None
     dev = batch["rays_o"].device
     full = []
     shapes = [(3,), (), (), ()]
-    dtypes = [torch.float32, torch.float32, torch.float32, outs[3].dtype if outs is not None else torch.int32]
+    # one fixed dtype per output on EVERY rank -- the renderer's counter is float32 (raymarcher_acc.py:185); a rank with an empty
+    # row block (more ranks than rows) must not guess another one, or the all_gather mismatches
+    dtypes = [torch.float32, torch.float32, torch.float32, torch.float32]
     rows = [shard_rows(H, r, world_size) for r in range(world_size)]
     pad = max(b - a for a, b in rows)          # the collective wants equal blocks: pad to the largest (they differ by <= 1 row)
     for i, (sh, dt) in enumerate(zip(shapes, dtypes)):

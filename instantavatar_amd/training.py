@@ -552,6 +552,7 @@ class GraphedTrainStep:
         self.replays = 0
         self.eager_steps = 0
         self.capture_error = None
+        self._agreed = False   # the ranks have agreed on the outcome of the first capture (see __call__)
         self._warmed = False   # an eager step has run through this object (lazy initialisation done)
 
     # -- helpers ---------------------------------------------------------------------------------------
@@ -592,6 +593,8 @@ class GraphedTrainStep:
 
     # -- the step --------------------------------------------------------------------------------------
     def __call__(self, batch=None):
+        import os
+        from . import parallel
         m, r = self.model, self.model.renderer
         if batch is None:
             if self.inputs is None:
@@ -639,14 +642,34 @@ class GraphedTrainStep:
             return training_step(m, self.inputs, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         if entry is None:
             self.graphs = {k: e for k, e in self.graphs.items() if k[1] == r.train_cand_capacity}
+            err = None
             try:
+                if os.environ.get("IA_TEST_CAPTURE_FAIL_RANK") == os.environ.get("RANK", "0"):
+                    raise RuntimeError("capture failure injected by IA_TEST_CAPTURE_FAIL_RANK (test hook)")
                 entry = self._capture(key, use_noise)
             except Exception as e:  # capture not possible on this stack: stay eager (same kernels, host-launched)
-                self.capture_error = repr(e)[:300]
+                err = repr(e)[:300]
+            if not self._agreed and parallel.collectives_on(self.world_size):
+                # The FIRST capture happens at the same step on every rank (step 0 is an occupancy update, the warm-up rules
+                # do not depend on the rank): agree on its outcome, once, outside any capture.  One rank whose capture failed
+                # would otherwise launch its collectives eagerly against the other ranks' replays for the rest of the run --
+                # order-compatible by construction, but a mix nothing has exercised on 8 GPUs.  All ranks captured, or
+                # all ranks run eagerly.  (Later re-captures -- a candidate-capacity overflow is a per-rank event -- cannot
+                # be agreed on: the other ranks are inside a replay then; a failure there falls back on that rank alone.)
+                self._agreed = True
+                import torch.distributed as dist
+                flag = torch.tensor([0.0 if err else 1.0], device=next(m.parameters()).device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) == 0.0 and err is None:
+                    err = "HIP-graph capture failed on another rank: all ranks launch eagerly"
+                    self.graphs.pop(key, None)
+            if err is not None:
+                self.capture_error = err
                 self.enabled = False
                 import warnings
                 warnings.warn("GraphedTrainStep: HIP-graph capture failed, training continues with eager launches (slower): " + self.capture_error)
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 self.eager_steps += 1
                 return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         entry["graph"].replay()

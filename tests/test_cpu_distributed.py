@@ -66,18 +66,29 @@ def _tile_worker(rank, world, port, q):
     H, W = 7, 5                      # 7 rows over 2 ranks: blocks of 4 and 3 rows
 
     class Fake:                      # stands in for AvatarModel: "renders" a function of the ray it is given
+        jitters = []
+
         def render_image_fast(self, batch, img_size, jitter=None):
             o = batch["rays_o"]
             assert o.shape[1] == img_size[0] * img_size[1]
             rgb = o.reshape(1, *img_size, 3) * 2.0
             dep = batch["near"].reshape(1, *img_size) + 1.0
-            return rgb, dep, dep * 0.5, (dep * 10).to(torch.int32)
+            self.jitters.append(None if jitter is None else float(jitter.sum()))
+            return rgb, dep, dep * 0.5, dep * 10          # the renderer's counter is float32 (raymarcher_acc.py:185)
     idx = torch.arange(H * W, dtype=torch.float32)
     batch = {"rays_o": torch.stack([idx, idx + 0.25, idx + 0.5], -1)[None], "rays_d": torch.zeros(1, H * W, 3),
              "near": idx[None].clone(), "far": idx[None] + 2}
     rgb, dep, alpha, cnt = render_frame_tiled(Fake(), batch, (H, W), world, rank)
     ok = (rgb.shape == (1, H, W, 3) and torch.equal(rgb.reshape(-1, 3), batch["rays_o"][0] * 2) and torch.equal(dep.reshape(-1), idx + 1)
-          and torch.equal(alpha.reshape(-1), (idx + 1) * 0.5) and cnt.dtype == torch.int32 and torch.equal(cnt.reshape(-1), ((idx + 1) * 10).to(torch.int32)))
+          and torch.equal(alpha.reshape(-1), (idx + 1) * 0.5) and cnt.dtype == torch.float32 and torch.equal(cnt.reshape(-1), (idx + 1) * 10))
+    # no jitter given: rank 0's draw reaches every rank (private draws would give every block its own occupancy grid)
+    js = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(js, torch.tensor([Fake.jitters[-1]], dtype=torch.float64))
+    ok = ok and Fake.jitters[-1] is not None and all(float(j) == float(js[0]) for j in js)
+    # more ranks than rows: the rank with the empty block joins the gather with the same dtypes (it used to guess int32)
+    b1 = {k: v[:, :W].clone() for k, v in batch.items()}
+    rgb1, dep1, alpha1, cnt1 = render_frame_tiled(Fake(), b1, (1, W), world, rank)
+    ok = ok and rgb1.shape == (1, 1, W, 3) and cnt1.dtype == torch.float32 and torch.equal(cnt1.reshape(-1), (idx[:W] + 1) * 10)
     q.put((rank, bool(ok), shard_rows(H, rank, world)))
     dist.destroy_process_group()
 
@@ -134,6 +145,35 @@ def test_bench_gpus2_dry_run_launches_two_ranks():
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def _bench_dry(extra_env, extra_args=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--train-only"] + list(extra_args),
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_supervised_training_child_job_dry_run():
+    """bench.supervised_train without kernels (VERDICT r04 task 7): with N > 1 the training phase runs in a child job -- each
+    rank re-executes bench.py as its own child on the next rendezvous port (WITHOUT torchrun's TORCHELASTIC_* variables: the
+    children must host their own store), rank 0 parses its child's line.  Then the watchdog's case: rank 1's first child never
+    gets anywhere; both parents give up after IA_BENCH_CHILD_TIMEOUT, kill their children by PID, agree on the failure and run
+    the phase again with IA_GRAPH_COLLECTIVES=0 -- the line reports both attempts."""
+    r = _bench_dry({})
+    sup = r["train"]["supervised"]["attempts"]
+    assert len(sup) == 1 and sup[0]["all_ranks_ok"] and sup[0]["IA_GRAPH_COLLECTIVES"] == "1", sup
+    assert r["train"]["ranks_in_child_group"] == 2 and r["train"]["graph_collectives"] is True and r["value"] == 8192.0
+    r = _bench_dry({"IA_TEST_CHILD_HANG_RANK": "1", "IA_BENCH_CHILD_TIMEOUT": "12"})
+    sup = r["train"]["supervised"]["attempts"]
+    assert len(sup) == 2 and not sup[0]["all_ranks_ok"] and "killed" in sup[0]["this_rank"], sup
+    assert sup[1]["all_ranks_ok"] and sup[1]["IA_GRAPH_COLLECTIVES"] == "0" and r["train"]["graph_collectives"] is False, sup
 
 
 def test_bench_gpus_without_devices_fails_loudly():
@@ -446,3 +486,79 @@ def test_gloo_world2_animate_driver_shards_frames_and_gathers_the_gif(tmp_path):
     for i in range(7):                                       # the gathered frames are interleaved back into sequence order
         g1.seek(i), g2.seek(i)
         assert np.array_equal(np.asarray(g1.convert("RGBA")), np.asarray(g2.convert("RGBA"))), i
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# GraphedTrainStep at world size 2 (VERDICT r04 weak 6 / task 7): the ranks agree on the outcome of the FIRST capture -- one rank
+# whose capture failed must not launch its collectives eagerly against the other rank's replays.  The capture itself needs a
+# GPU; here `_capture` is replaced by a stand-in whose "graph" replays an eager step, everything around it is the real code.
+def _graph_agreement_worker(rank, world, port, fail_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank))
+    if fail_rank is not None:
+        os.environ["IA_TEST_CAPTURE_FAIL_RANK"] = str(fail_rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instantavatar_amd import parallel, training
+    from instantavatar_amd.models.structures.density_grid import DensityGrid
+    torch.manual_seed(7 + rank)
+    net = _MockNet()
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net_coarse, self.deformer, self.global_step = net, _MockDeformer(), 0
+            grid = DensityGrid(4, aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]))
+            grid._postprocess = lambda density: setattr(grid, "density_field", density > density.mean())
+            self.renderer = type("R", (), {"density_grid_train": grid, "idx": 0, "train_cand_capacity": 1,
+                                           "_train_counts_check": lambda self: None, "_train_counts_peek": lambda self, cap: None})()
+
+        def forward(self, batch, eval_mode=False, noise=0):
+            _, sigma = self.deformer(batch["pts"], self.net_coarse, eval_mode=False)
+            a = torch.sigmoid(sigma)
+            return {"rgb_coarse": a[:, None].expand(-1, 3), "alpha_coarse": a, "weight_coarse": a[:, None].expand(-1, 4)}
+    model = Model()
+    parallel.broadcast_module_state(model, world)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    loss_fn = training.NeRFLoss(fused=False)
+    stepper = training.GraphedTrainStep(model, opt, loss_fn, world_size=world, graph_collectives=True)
+    assert stepper.enabled
+
+    def fake_capture(key, use_noise):
+        class G:
+            def replay(self_inner):
+                entry["out"] = training.training_step(model, stepper.inputs, opt, loss_fn, world, _capturing=True)
+        params = [p for g in opt.param_groups for p in g["params"]]
+        entry = dict(graph=G(), out=None, grads=[p.grad for p in params], params=params, cap=1)
+        stepper.graphs[key] = entry
+        return entry
+    stepper._capture = fake_capture
+    for step in range(6):
+        stepper({"pts": torch.randn(16, 3), "rgb": torch.rand(16, 3), "alpha": torch.rand(16)})
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    q.put((rank, stepper.enabled, stepper.replays, stepper.eager_steps, stepper.capture_error, torch.equal(both[0], both[1]), model.global_step))
+    dist.destroy_process_group()
+
+
+def _run_graph_agreement(fail_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_agreement_worker, args=(r, 2, port, fail_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_gloo_world2_first_graph_capture_is_all_or_nothing():
+    ok = _run_graph_agreement(None)
+    for rank, enabled, replays, eager, err, identical, gstep in ok:
+        assert enabled and replays == 5 and eager == 1 and err is None and identical and gstep == 6
+    bad = _run_graph_agreement(1)                       # the capture fails on rank 1 ONLY
+    for rank, enabled, replays, eager, err, identical, gstep in bad:
+        assert not enabled and replays == 0 and eager == 6 and identical and gstep == 6, (rank, enabled, replays, eager, err)
+    assert "injected" in bad[1][4] and "another rank" in bad[0][4]

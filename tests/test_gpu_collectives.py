@@ -115,18 +115,24 @@ def test_training_step_over_rccl_with_one_rank():
     assert np.allclose(g["losses"], o["plain_losses"], rtol=5e-3, atol=1e-6) and g["params_rel_diff_vs_plain"] < 5e-3
 
 
-@pytest.mark.parametrize("mode", ["render", "train", "tile"])
+@pytest.mark.parametrize("mode", ["render", "train", "tile", "train-hang"])
 def test_bench_two_ranks_share_the_one_gpu(mode):
     """The N > 1 control flow of bench.py with the REAL kernels on a one-GPU box (VERDICT r03 missing 2: the scaling runs are
     the driver's and have never executed): two ranks started by bench.py's own launcher share cuda:0 and talk over gloo
     (`IA_BENCH_SHARE_DEVICE=1`; RCCL refuses two ranks on one device) -- round-robin frame sharding, the gathers and
     barriers, the per-rank reports, the eager two-rank training step with its bucketed gradient average and the MAX-reduce of
     the density cache, the row-sharded frame.  The numbers are not scaling figures; what is tested is that every rank reaches
-    every collective and the line comes out whole."""
+    every collective and the line comes out whole.
+    With N > 1 the training phase runs in a supervised child job (bench.supervised_train).  "train-hang": rank 1's first child
+    never gets anywhere (IA_TEST_CHILD_HANG_RANK -- what a hung stream capture of the RCCL collectives would look like from
+    outside): both parents must give up after IA_BENCH_CHILD_TIMEOUT, kill their children, agree, run the phase again with
+    IA_GRAPH_COLLECTIVES=0 and report both attempts instead of dying (VERDICT r04 task 7)."""
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["IA_BENCH_SHARE_DEVICE"] = "1"
-    extra = {"render": ["--train-steps", "12"], "train": ["--train-only"], "tile": ["--tile-shard"]}[mode]
+    extra = {"render": ["--train-steps", "12"], "train": ["--train-only"], "tile": ["--tile-shard"], "train-hang": ["--train-only"]}[mode]
+    if mode == "train-hang":
+        env.update(IA_TEST_CHILD_HANG_RANK="1", IA_BENCH_CHILD_TIMEOUT="45")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--cpu-frames", "0",
                           "--spinup-max-ms", "200"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -139,7 +145,13 @@ def test_bench_two_ranks_share_the_one_gpu(mode):
         assert r["frames_per_rank"] == [8, 8] and r["value"] > 0 and r["scaling"] == "weak"
         assert "error" not in r["train"], r["train"]
         assert r["train"]["it_per_sec"] > 0 and r["train"]["launch_mode"] == "eager"      # gloo collectives are not capturable
-    elif mode == "train":
+    elif mode in ("train", "train-hang"):
+        sup = r["train"]["supervised"]["attempts"]
+        if mode == "train-hang":
+            assert len(sup) == 2 and not sup[0]["all_ranks_ok"] and "killed" in sup[0]["this_rank"] and sup[0]["IA_GRAPH_COLLECTIVES"] == "1", sup
+            assert sup[1]["all_ranks_ok"] and sup[1]["IA_GRAPH_COLLECTIVES"] == "0" and r["train"]["graph_collectives"] is False, sup
+        else:
+            assert len(sup) == 1 and sup[0]["all_ranks_ok"], sup
         assert r["metric"] == "train_rays_per_sec" and r["value"] > 0
         assert r["train"]["rays_per_step_per_gpu"] == 4096 and abs(r["value"] - r["train"]["it_per_sec"] * 4096 * 2) < 1e-3 * r["value"]
     else:

@@ -9,10 +9,10 @@ encoding (calls >= 8192 samples) and the batched occupancy probes (5 x 64^3 x 13
 launch).  Reference: models/DNeRF.py:72-97, renderers/raymarcher_acc.py:83-138,
 models/structures/density_grid.py:95-110.
 
-Tolerances are those of tests/test_gpu_parity.py: rgb / alpha within 1e-3 absolute with at most
-0.2 % of the rays moved by the reference's own discontinuities (occupancy cell flips,
-alpha < 0.01 skips, T <= 1e-4 stops); occupancy cell flips < 2e-4; sample counters equal on
->= 99.8 % of the rays.
+Tolerances (tests/world.py: rays_within / cells_within, sized to what is measured): rgb / alpha within 1e-3
+absolute on all but 1e-4 of the rays (26 of 262 144; measured 0-3 -- the reference's own discontinuities:
+occupancy cell flips, alpha < 0.01 skips, T <= 1e-4 stops); occupancy cells differing <= 2e-5 (5; measured
+<= 1); sample counters equal on >= 99.95 % of the rays.
 """
 import numpy as np
 import pytest
@@ -47,11 +47,12 @@ def _check(rgb, alpha, counter, occ_g, ref, what):
                 median_rgb_on_body=float(np.median(err_rgb[ref["alpha"] > 0.5])), counter_mismatch=float((counter != ref["counter"]).mean()),
                 counter_mean=(float(counter.mean()), float(ref["counter"].mean())))
     print(what, info)
-    assert info["occ_flips"] < 2e-4, (what, info)
+    W.cells_within(occ_g.cpu().numpy(), ref["occ"].astype(bool), what + " occupancy")          # <= 5 of 262 144 cells (measured <= 1)
     assert info["cov"] > 0.02, (what, info)
-    assert info["frac_rgb"] < 2e-3 and info["frac_alpha"] < 2e-3, (what, info)
+    W.rays_within(err_rgb, what + " rgb")                                                        # <= 1e-4 of the rays (measured 0-3 of 262 144)
+    W.rays_within(err_a, what + " alpha")
     assert info["median_rgb_on_body"] < 1e-4, (what, info)
-    assert info["counter_mismatch"] < 2e-3, (what, info)
+    assert info["counter_mismatch"] < 5e-4, (what, info)
     assert abs(info["counter_mean"][0] - info["counter_mean"][1]) < 0.005 * max(1.0, info["counter_mean"][1]), (what, info)
     return info
 
@@ -208,7 +209,8 @@ def test_shipped_pose_tracks_frame_and_training_render(oracle, bench_world, name
                  frac_alpha=float((e_a > 1e-3).mean()), frac_w=float((e_w > 1e-3).mean()), max_rgb=float(e_rgb.max()), median_rgb=float(np.median(e_rgb)))
     print("%s[%d] training render" % (name, frame), tinfo)
     assert tinfo["hit"] > 0.2 and tinfo["n_field"] > 10000, tinfo
-    assert tinfo["frac_rgb"] < 5e-3 and tinfo["frac_alpha"] < 5e-3 and tinfo["frac_w"] < 5e-3, tinfo
+    for e, nm in ((e_rgb, "rgb"), (e_a, "alpha"), (e_w, "weights")):
+        W.rays_within(e, "%s[%d] training render %s" % (name, frame, nm), frac=5e-4)               # <= 2 of 4 096 rays (measured 0)
     assert tinfo["median_rgb"] < 1e-4, tinfo
 
 
@@ -230,8 +232,9 @@ def test_intra_frame_row_sharding_equals_the_whole_frame(bench_world):
     """SURVEY 8e (optional intra-frame sharding for latency; BASELINE config 5 renders 1024^2): the frame rendered as the row
     blocks 8 ranks would take (`parallel.shard_rows`), one after the other on this GPU, against the whole frame.  A ray's march
     and compositing do not depend on which other rays are alive: rgb / depth / alpha must be BIT-EQUAL; the per-ray sample
-    counter follows the N_step schedule (fewer alive rays -> more steps per iteration) and is only required to be >= the
-    samples the whole-frame render needed to reach the same result."""
+    counter follows the N_step schedule (fewer alive rays -> more samples marched per iteration, raymarcher_acc.py:104): a ray
+    that terminates mid-iteration has marched the rest of that iteration's samples too, so the two counts of a ray differ by
+    the schedules' overshoot in either direction.  What does not depend on the schedule: WHICH rays march any sample at all."""
     from instantavatar_amd.parallel import render_frame_tiled, shard_rows
     model, body, fp, init, poses, tr = bench_world
     res, world = 512, 8
@@ -250,4 +253,5 @@ def test_intra_frame_row_sharding_equals_the_whole_frame(bench_world):
     cnt = torch.cat([p[3] for p in parts], dim=1)
     assert (full[2] > 0.5).float().mean() > 0.02
     hit = full[2] > 0.01
+    assert torch.equal(cnt > 0, full[3] > 0), "the set of rays that meet an occupied cell depends on the row sharding"
     assert bool((cnt[hit] >= 1).all()) and float((cnt.float() - full[3].float()).abs().mean()) < 64

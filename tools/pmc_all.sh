@@ -1,9 +1,9 @@
 #!/bin/bash
 # Every PMC pass the bench line cites, on the library as it is NOW, summarised with the hashes of its device code inside
-# (tools/pmc_r3.py -> gpurun_out/profiles_$RND/${RND}_pmc_*.json; copy those to profiles/).
+# (tools/pmc_condense_all.py -> gpurun_out/profiles_$RND/${RND}_pmc_*.json; copy those to profiles/).
 # One counter set per pass, --kernel-trace only (MI355X_MICROARCH.md; gpurun refuses --pmc combined with other traces).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RND=${IA_PMC_ROUND:-r04}; export IA_PMC_ROUND=$RND
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RND=${IA_PMC_ROUND:-r05}; export IA_PMC_ROUND=$RND
 run() {  # run <dir> <counter set> -- <command...>
   local d=$1 c=$2; shift 3
   rm -rf $O/$d
@@ -26,7 +26,7 @@ done
 for c in "TCC_ATOMIC_sum TCC_REQ_sum" "TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum"; do
   run pmc3_$(echo $c | tr ' ' '+') "$c" -- python $R/bench.py --train-only --steps 30 --warmup 5 --no-graph
 done
-python $R/tools/pmc_r3.py $O $O/profiles_$RND > $O/pmc_all_summary.txt 2>&1; tail -5 $O/pmc_all_summary.txt
+python $R/tools/pmc_condense_all.py $O $O/profiles_$RND > $O/pmc_all_summary.txt 2>&1; tail -5 $O/pmc_all_summary.txt
 # the raw per-dispatch CSVs are tens of MB per pass (gpurun copies back at most 64 MiB): keep one condensed row per
 # (kernel, counter) of every pass next to the summaries and drop the raw files
 mkdir -p $O/profiles_$RND/${RND}_pmc

@@ -1,11 +1,11 @@
-"""Round 3: ONE summary of every PMC pass of tools/pmc_all.sh, stamped with the sha256 of the library the counters were
+"""ONE summary of every PMC pass of tools/pmc_all.sh, stamped with the hashes of the device code the counters were
 collected on (bench.py refuses a summary whose hash differs from the library it runs):
 
-  r03_pmc_traffic.json  r03_pmc_search.json  r03_pmc_mfma.json   (bench passes, tools/pmc_r2.py's summaries)
-  r03_pmc_encode.json   isolated hash-grid lookup (tools/pmc_encode.py): requests per sample, hit rates, fabric bytes
-  r03_pmc_hgbwd.json    hash-grid backward: L2 atomic requests per launch against the measured ceiling
+  <round>_pmc_traffic.json  <round>_pmc_search.json  <round>_pmc_mfma.json   (bench passes, tools/pmc_summarise_bench.py's summaries)
+  <round>_pmc_encode.json   isolated hash-grid lookup (tools/pmc_encode.py): requests per sample, hit rates, fabric bytes
+  <round>_pmc_hgbwd.json    hash-grid backward: L2 atomic requests per launch against the measured ceiling
 
-    python tools/pmc_r3.py <gpurun_out dir> <out dir>
+    python tools/pmc_condense_all.py <gpurun_out dir> <out dir>
 """
 import collections
 import csv
@@ -18,12 +18,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import pmc_r2  # noqa: E402
+import pmc_summarise_bench as pmc_bench  # noqa: E402
 
 SO = os.path.join(os.path.dirname(HERE), "instantavatar_amd", "libinstantavatar_hip.so")
 
 
-ROUND = os.environ.get("IA_PMC_ROUND", "r04")
+ROUND = os.environ.get("IA_PMC_ROUND", "r05")
 
 
 def so_hash():
@@ -77,7 +77,7 @@ def per_kernel_tail(pattern, match, last_n):
 def main(root, out_dir):
     os.makedirs(out_dir, exist_ok=True)
     meta = {"so_sha256": so_hash(), "device_code": device_code(), "collected_by": "tools/pmc_all.sh (rocprofv3 --pmc <one set per pass> --kernel-trace)"}
-    pmc_r2.main(root, out_dir, prefix=ROUND, meta=meta)
+    pmc_bench.main(root, out_dir, prefix=ROUND, meta=meta)
     # ---- isolated encoder
     C, us, _ = per_kernel(os.path.join(root, "pmc_enc_*", "**", "*counter_collection.csv"), ("k_hashgrid<", "k_encode_xcd"))
     V = 1 << 20

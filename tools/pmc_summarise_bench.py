@@ -1,13 +1,13 @@
-"""Summarises the rocprofv3 --pmc passes of tools/pmc_r2.sh (gpurun_out/pmc2_*/r_counter_collection.csv):
+"""Summarises the rocprofv3 --pmc passes of tools/pmc_all.sh (gpurun_out/pmc2_*/r_counter_collection.csv):
 per kernel family and launch -- counters averaged over the launches of a family, durations from the dispatch
 timestamps of the same pass.  Writes (to <out_dir>, copied to profiles/ by hand):
 
-  r02_pmc_traffic.json   HBM bytes per launch (FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
-  r02_pmc_search.json    k_search: L1 / L2 hit rates, requests, stall and issue counters, probe vs render launches
-  r02_pmc_mfma.json      MFMA busy cycles of k_field / k_field_bwd against the SIMD cycles of the launch
-  r02_pmc_encode.json    (only with pmc_encode passes) kept from tools/pmc_encode.py
+  <round>_pmc_traffic.json   HBM bytes per launch (FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
+  <round>_pmc_search.json    k_search: L1 / L2 hit rates, requests, stall and issue counters, probe vs render launches
+  <round>_pmc_mfma.json      MFMA busy cycles of k_field / k_field_bwd against the SIMD cycles of the launch
+  <round>_pmc_encode.json    (only with pmc_encode passes) kept from tools/pmc_encode.py
 
-    python tools/pmc_r2.py <gpurun_out dir> <out dir>
+    python tools/pmc_summarise_bench.py <gpurun_out dir> <out dir>
 """
 import collections
 import csv
