@@ -141,27 +141,13 @@ class SMPLDeformer():
         """smpl_deformer.py:122-131: invalid points -> rgb 0, sigma 0"""
         if self._native(model) and not torch.is_grad_enabled():
             return self._query_fused(pts, model, 0.0, 0)
-        pts_cano, valid = self.deform(pts)
-        rgb = torch.zeros_like(pts_cano)
-        sigma = torch.zeros_like(pts_cano[..., 0])
-        if valid.any():
-            r, s = model(pts_cano[valid], None)
-            rgb[valid], sigma[valid] = r.float(), s.float()
-        return rgb, sigma
+        from .. import dense_routes
+        return dense_routes.deform_query_single(self, pts, model, eval_mode=True)
 
     def deform_train(self, pts, model):
         """smpl_deformer.py:112-120: invalid or non-finite -> rgb 0, sigma -1e5"""
-        pts_cano, valid = self.deform(pts)
-        rgb = torch.zeros_like(pts_cano)
-        sigma = torch.ones_like(pts_cano[..., 0]) * -1e5
-        if valid.any():
-            r, s = model(pts_cano[valid], None)
-            rgb = rgb.index_put((valid,), r.float())
-            sigma = sigma.index_put((valid,), s.float())
-            ok = torch.isfinite(rgb).all(-1) & torch.isfinite(sigma)
-            rgb = torch.where(ok[:, None], rgb, torch.zeros_like(rgb))
-            sigma = torch.where(ok, sigma, torch.full_like(sigma, -1e5))
-        return rgb, sigma
+        from .. import dense_routes
+        return dense_routes.deform_query_single(self, pts, model, eval_mode=False)
 
     def __call__(self, pts, model, eval_mode=True):
         return self.deform_test(pts, model) if eval_mode else self.deform_train(pts, model)

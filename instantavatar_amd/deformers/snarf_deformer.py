@@ -312,16 +312,8 @@ class SNARFDeformer():
         pts = pts.type(self.dtype)
         if self._is_native_field(model) and pts.is_cuda:
             return self.query_fused(pts, model)
-        pts_cano_all, valid = self.deform(pts, eval_mode=True)
-        rgb_cano = torch.zeros_like(pts_cano_all).float()
-        sigma_cano = torch.zeros_like(pts_cano_all[..., 0]).float()
-        if valid.any():
-            r, s = model(pts_cano_all[valid], None)
-            sigma_cano[valid] = torch.nan_to_num(s.float(), 0, 0, 0)
-            rgb_cano[valid] = torch.nan_to_num(r.float(), 0, 0, 0)
-        sigma_cano, idx = torch.max(sigma_cano, dim=-1)
-        rgb_cano = torch.gather(rgb_cano, 1, idx[:, None, None].repeat(1, 1, 3))
-        return rgb_cano.reshape(-1, 3), sigma_cano.reshape(-1)
+        from .. import dense_routes
+        return dense_routes.deform_query(self, pts, model, eval_mode=True)
 
     @torch.no_grad()
     def query_fused(self, pts, net, dmax=None, want_rgb=True):
@@ -439,15 +431,8 @@ class SNARFDeformer():
         """snarf_deformer.py:143-159."""
         if self._is_native_field(model) and pts.is_cuda and self.fused_train_route():
             return self.query_train_fused(pts.type(self.dtype), model)
-        pts_cano_all, valid = self.deform(pts.type(self.dtype), eval_mode=False)
-        rgb_cano = torch.zeros_like(pts_cano_all).float()
-        sigma_cano = -torch.ones_like(pts_cano_all[..., 0]).float() * 1e5
-        if valid.any():
-            r, s = model(pts_cano_all[valid], None)
-            rgb_cano[valid], sigma_cano[valid] = r.float(), s.float()
-        sigma_cano, idx = torch.max(sigma_cano, dim=-1)
-        rgb_cano = torch.gather(rgb_cano, 1, idx[:, None, None].repeat(1, 1, 3))
-        return rgb_cano.reshape(-1, 3), sigma_cano.reshape(-1)
+        from .. import dense_routes
+        return dense_routes.deform_query(self, pts.type(self.dtype), model, eval_mode=False)
 
     def __call__(self, pts, model, eval_mode=True):
         if eval_mode:

@@ -10,9 +10,8 @@ Two test-time routes with identical results:
     (march -> deformer query -> composite -> alive compaction, device-side N_step
     schedule) enqueued without a single host sync.  Taken when the model closure
     is recognised as (SNARFDeformer, NeRFNGPNet) or after `bind_fused(deformer, net)`;
-  * closure: the reference's loop structure with `ia_raymarch_test` /
-    `ia_composite_test` replacing the JIT CUDA extension (raymarcher_acc.py:13-16)
-    and an arbitrary `model(pts, _)` callable in between.
+  * dense (instantavatar_amd/dense_routes.py): any other `model(pts, _)` callable -- the unfused
+    kernels `ia_raymarch_test` / `ia_composite_test` driven from the host with the callable in between.
 """
 import ctypes as C
 
@@ -20,16 +19,6 @@ import torch
 
 from .. import _lib
 from ..models.structures.density_grid import DensityGrid
-
-
-def composite(sigma_vals, dists, thresh=0):
-    """raymarcher_acc.py:25-36 (training compositing, differentiable torch ops)."""
-    tau = torch.relu(sigma_vals) * dists
-    alpha = 1.0 - torch.exp(-tau)
-    if thresh > 0:
-        alpha = torch.where(alpha < thresh, torch.zeros_like(alpha), alpha)
-    trans = torch.cat([torch.ones_like(alpha[..., 0:1]), torch.cumprod(1 - alpha + 1e-10, dim=-1)], dim=-1)
-    return alpha * trans[..., :-1], trans
 
 
 def _find_native_pair(model):
@@ -159,7 +148,8 @@ class Raymarcher(torch.nn.Module):
         pair = self._fused or _find_native_pair(model)
         if pair is not None and rays.o.is_cuda:
             return self.render_test_fused(rays, pair[0], pair[1], bg_color)
-        return self.render_test_closure(rays, model, bg_color)
+        from .. import dense_routes
+        return dense_routes.render_test(self, rays, model, bg_color)     # any other callable: host-driven loop, dense blocks
 
     @torch.no_grad()
     def render_test_fused(self, rays, deformer, net, bg_color=None, sync=True):
@@ -211,59 +201,6 @@ class Raymarcher(torch.nn.Module):
             "rgb_coarse": rgb.reshape(rays.o.shape),
             "depth_coarse": depth.reshape(rays.near.shape),
             "alpha_coarse": alpha.reshape(rays.near.shape),
-            "counter_coarse": counter.reshape(rays.near.shape),
-        }
-
-    @torch.no_grad()
-    def render_test_closure(self, rays, model, bg_color):
-        """Reference loop structure (raymarcher_acc.py:83-138) around an arbitrary model."""
-        L = _lib.lib()
-        dev = rays.o.device
-        _lib.require_cuda(rays.o)
-        rays_o = rays.o.reshape(-1, 3).float().contiguous()
-        rays_d = rays.d.reshape(-1, 3).float().contiguous()
-        near = rays.near.reshape(-1).float().clone()
-        far = rays.far.reshape(-1).float().contiguous()
-        N = rays_o.shape[0]
-        color = torch.zeros(N, 3, device=dev)
-        depth = torch.zeros(N, device=dev)
-        no_hit = torch.ones(N, device=dev)
-        counter = torch.zeros_like(depth)
-        alive = torch.arange(N, device=dev)
-        step_size = ((far - near) / self.MAX_SAMPLES).contiguous()
-        grid = self.density_grid_test
-        occ = self._occ_desc(grid)
-        k = 0
-        while k < self.MAX_SAMPLES:
-            N_alive = len(alive)
-            if N_alive == 0:
-                break
-            N_step = max(min(self.MAX_BATCH_SIZE // N_alive, self.MAX_SAMPLES), 1)
-            pts = torch.empty((N_alive, N_step, 3), device=dev)
-            d_new = torch.empty((N_alive, N_step), device=dev)
-            z_new = torch.empty((N_alive, N_step), device=dev)
-            _lib.check(L.ia_raymarch_test(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(near), _lib.ptr(far),
-                                          _lib.ptr(alive), N_alive, _lib.ptr(grid.occ_bits), C.byref(occ),
-                                          _lib.ptr(step_size), N_step, _lib.ptr(pts), _lib.ptr(d_new), _lib.ptr(z_new),
-                                          _lib.stream()), "ia_raymarch_test")
-            mask = d_new > 0
-            counter[alive] += mask.sum(dim=-1)
-            rgb_vals = torch.zeros_like(pts)
-            sigma_vals = torch.zeros_like(d_new)
-            if mask.any():
-                r, s = model(pts[mask], None)
-                rgb_vals[mask], sigma_vals[mask] = r.float(), s.float()
-            _lib.check(L.ia_composite_test(_lib.ptr(rgb_vals), _lib.ptr(sigma_vals), _lib.ptr(d_new), _lib.ptr(z_new),
-                                           _lib.ptr(alive), N_alive, N_step, _lib.ptr(color), _lib.ptr(depth),
-                                           _lib.ptr(no_hit), 0.01, _lib.stream()), "ia_composite_test")
-            alive = alive[(no_hit[alive] > 1e-4) & (z_new[:, -1] > 0)]
-            k += N_step
-        bg = bg_color.reshape(-1, 3) if bg_color is not None else 1.0
-        color = color + no_hit[..., None] * bg
-        return {
-            "rgb_coarse": color.reshape(rays.o.shape),
-            "depth_coarse": depth.reshape(rays.near.shape),
-            "alpha_coarse": (1 - no_hit).reshape(rays.near.shape),
             "counter_coarse": counter.reshape(rays.near.shape),
         }
 
@@ -374,52 +311,9 @@ class Raymarcher(torch.nn.Module):
         return self._occ_cache
 
     def render_train(self, rays, model, noise, bg_color):
-        """raymarcher_acc.py:140-186: fixed MAX_SAMPLES slots per ray from
-        `ia_raymarch_train`, jitter, masked field evaluation, cumprod compositing."""
+        """raymarcher_acc.py:140-186."""
         pair = self._fused or _find_native_pair(model)
         if pair is not None and rays.o.is_cuda and pair[0].fused_train_route():
             return self.render_train_fused(rays, pair[0], pair[1], noise, bg_color)
-        L = _lib.lib()
-        _lib.require_cuda(rays.o)
-        rays_o = rays.o.reshape(-1, 3).float().contiguous()
-        rays_d = rays.d.reshape(-1, 3).float().contiguous()
-        near = rays.near.reshape(-1).float().contiguous()
-        far = rays.far.reshape(-1).float().contiguous()
-        N_step = self.MAX_SAMPLES
-        step_size = ((far - near) / N_step).contiguous()
-        grid = self.density_grid_train
-        occ = self._occ_desc(grid)
-        n_rays = rays_o.shape[0]
-        z_vals = torch.empty((n_rays, N_step), device=rays_o.device)
-        with torch.no_grad():
-            _lib.check(L.ia_raymarch_train(_lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), _lib.ptr(near.detach()),
-                                           _lib.ptr(far.detach()), n_rays, _lib.ptr(grid.occ_bits), C.byref(occ),
-                                           _lib.ptr(step_size.detach()), N_step, _lib.ptr(z_vals), _lib.stream()),
-                       "ia_raymarch_train")
-        mask = z_vals > 0
-        draws = getattr(self, "train_draws", None) or {}
-        jit = draws["ray_jitter"].to(z_vals).reshape(z_vals.shape) if "ray_jitter" in draws else torch.rand_like(z_vals)
-        z_vals = z_vals + jit * step_size[:, None]
-        pts = z_vals[..., None] * rays_d[:, None] + rays_o[:, None]
-        rgb_vals = torch.zeros_like(pts, dtype=torch.float32)
-        sigma_vals = -torch.ones_like(rgb_vals[..., 0], dtype=torch.float32) * 1e3
-        if mask.sum() > 0:
-            r, s = model(pts[mask], None)
-            rgb_vals = rgb_vals.masked_scatter(mask[..., None].expand_as(rgb_vals), r.float())
-            sigma_vals = sigma_vals.masked_scatter(mask, s.float())
-        if noise > 0:
-            sigma_vals = sigma_vals + noise * (draws["noise"].to(sigma_vals).reshape(sigma_vals.shape) if "noise" in draws
-                                               else torch.randn_like(sigma_vals))
-        dists = torch.ones_like(sigma_vals) * step_size[:, None]
-        weights, transmittance = composite(sigma_vals.reshape(z_vals.shape), dists, thresh=0)
-        no_hit = transmittance[..., -1]
-        color = (weights[..., None] * rgb_vals.reshape(pts.shape)).sum(dim=-2)
-        bg = bg_color.reshape(-1, 3) if bg_color is not None else 1.0
-        color = color + no_hit[..., None] * bg
-        depth = (weights * z_vals).sum(dim=-1)
-        return {
-            "rgb_coarse": color.reshape(rays.o.shape),
-            "depth_coarse": depth.reshape(rays.near.shape),
-            "alpha_coarse": (weights.sum(-1)).reshape(rays.near.shape),
-            "weight_coarse": weights.reshape(*rays.near.shape, -1),
-        }
+        from .. import dense_routes
+        return dense_routes.render_train(self, rays, model, noise, bg_color)   # any other callable / the dense deformer route

@@ -421,7 +421,8 @@ def test_render_closure_route_equals_fused_route(gpu_world):
     rgb_f, depth_f, alpha_f, cnt_f = model.render_image_fast(batch, (res, res), jitter=jit)
     rays = Rays(o=batch["rays_o"], d=batch["rays_d"], near=batch["near"], far=batch["far"])
     model.deformer.transform_rays_w2s(rays)
-    out = model.renderer.render_test_closure(rays, lambda x, _: model.deformer(x, lambda p, d: model.net_coarse(p, d), True), None)
+    from instantavatar_amd import dense_routes
+    out = dense_routes.render_test(model.renderer, rays, lambda x, _: model.deformer(x, lambda p, d: model.net_coarse(p, d), True), None)
     assert torch.allclose(out["rgb_coarse"].reshape(-1, 3), rgb_f.reshape(-1, 3), atol=1e-6)
     assert torch.allclose(out["alpha_coarse"].reshape(-1), alpha_f.reshape(-1), atol=1e-6)
     assert torch.equal(out["counter_coarse"].reshape(-1), cnt_f.reshape(-1))
