@@ -155,7 +155,8 @@ def _make_renderer(model, first, size, in_flight, probes, jitter):
     return PipelinedRenderer(model, first, size, n_in_flight=in_flight, margin=1, probe_batches=probes, jitter=jitter)
 
 
-def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_flight=2, jitter=None, make_renderer=None, log=print):
+def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_flight=2, jitter=None, make_renderer=None, log=print,
+                    max_buffer_bytes=1 << 30):
     """animate.py:104-118 / novel_view.py:117-127 for one rank of a job of `launch.world_size` ranks.
 
     The frames of `seq` are dealt round-robin to the ranks (parallel.shard_frames; frames are independent: no data-path
@@ -175,9 +176,13 @@ def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_fl
     on_gpu = dev.type == "cuda"
     mine = shard_frames(len(seq), launch.rank, launch.world_size)
     n = len(mine)
-    # the packed frames stay on the device (the GIF gather travels over RCCL from there) and in pinned host memory (PNG encoding)
-    dev_frames = torch.empty((n, seq.H, seq.W, 4), dtype=torch.uint8, device=dev)
-    host = torch.empty((n, seq.H, seq.W, 4), dtype=torch.uint8, pin_memory=on_gpu)
+    # the packed frames stay on the device (the GIF gather travels over RCCL from there) and in pinned host memory (PNG encoding).
+    # With a GIF every frame is kept until the end, as the reference does (animate.py:106-116); without one the sequence goes
+    # through buffers of at most `max_buffer_bytes` (render a chunk, write its files, reuse the buffers)
+    per_frame = seq.H * seq.W * 4
+    cap = n if gif else max(1, min(n, int(max_buffer_bytes) // per_frame))
+    dev_frames = torch.empty((cap, seq.H, seq.W, 4), dtype=torch.uint8, device=dev)
+    host = torch.empty((cap, seq.H, seq.W, 4), dtype=torch.uint8, pin_memory=on_gpu)
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     render_s, redo = 0.0, []
     if n:
@@ -185,38 +190,43 @@ def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_fl
         renderer = (make_renderer or _make_renderer)(model, seq.batch(mine[0]), size, max(1, min(in_flight, n)), probes, jitter)
 
         # device -> host copies run on their own stream behind an event: a frame's stream goes straight on to its next frame
-        # instead of standing still for the PCIe transfer (every frame has its own slot in `dev_frames`: nothing is reused)
+        # instead of standing still for the PCIe transfer (every frame of a chunk has its own slot: nothing is reused in flight)
         copier = torch.cuda.Stream(device=dev) if on_gpu else None
 
-        def keep(j):
+        def keep(slot):
             def consume(out, k):
-                pack_rgba8(out, dev_frames[j])
+                pack_rgba8(out, dev_frames[slot])
                 if copier is None:
-                    host[j].copy_(dev_frames[j])
+                    host[slot].copy_(dev_frames[slot])
                     return
                 ev = torch.cuda.Event()
                 ev.record()
                 copier.wait_event(ev)
                 with torch.cuda.stream(copier):
-                    host[j].copy_(dev_frames[j], non_blocking=True)
+                    host[slot].copy_(dev_frames[slot], non_blocking=True)
             return consume
         with torch.inference_mode():
-            sync()
-            t0 = time.perf_counter()
-            for j, i in enumerate(mine):
-                renderer(seq.batch(i, rays=False), keep(j))
-            renderer.synchronize()
-            if copier is not None:
-                copier.synchronize()
-            render_s = time.perf_counter() - t0
-            renderer.finish()
-            redo = list(renderer.incomplete_calls)
-            for j in redo:
-                keep(j)(model.render_image_fast(seq.batch(mine[j]), size, jitter=jitter), 0)
-            sync()
+            for c0 in range(0, n, cap):
+                c1 = min(n, c0 + cap)
+                sync()
+                t0 = time.perf_counter()
+                for j in range(c0, c1):
+                    renderer(seq.batch(mine[j], rays=False), keep(j - c0))
+                renderer.synchronize()
+                if copier is not None:
+                    copier.synchronize()
+                render_s += time.perf_counter() - t0
+                renderer.finish()
+                bad = [c for c in renderer.incomplete_calls if c0 <= c < c1]     # (call number = position in `mine`)
+                for c in bad:
+                    keep(c - c0)(model.render_image_fast(seq.batch(mine[c]), size, jitter=jitter), 0)
+                sync()
+                redo += bad
+                if not gif:
+                    write_frames(host[:c1 - c0].numpy(), out_dir, indices=mine[c0:c1])
     slowest = launch.max_over_ranks(render_s)
-    write_frames(host.numpy(), out_dir, indices=mine)
     if gif:
+        write_frames(host.numpy(), out_dir, indices=mine)
         parts = launch.gather_to_main(dev_frames if launch.backend == "nccl" else host)
         if launch.is_main:
             w = launch.world_size

@@ -446,8 +446,12 @@ def _animate_worker(rank, world, port, out_dir, q):
     def make(model, first, size, in_flight, probes, jitter):
         assert "rays_o" in first and all("rays_o" in p for p in probes) and size == (seq.H, seq.W)
         made.append(_FakePipelined(seq, {1} if rank == 0 else set()))
-        return made[0]
+        return made[-1]
     res = animate.render_sequence(Model(), seq, out_dir, gif="a.gif", launch=launch, make_renderer=make, log=None)
+    # the same sequence without a GIF through frame buffers that hold TWO frames: rendered and written chunk by chunk
+    res2 = animate.render_sequence(Model(), seq, out_dir + "_chunked", gif=None, launch=launch, make_renderer=make, log=None,
+                                   max_buffer_bytes=2 * seq.H * seq.W * 4)
+    assert (res2["frames"], res2["local"], res2["incomplete"]) == (res["frames"], res["local"], res["incomplete"]) and made[1].calls == made[0].calls
     q.put((rank, res["frames"], res["local"], res["incomplete"], made[0].calls))
     launch.close()
 
@@ -478,6 +482,10 @@ def test_gloo_world2_animate_driver_shards_frames_and_gathers_the_gif(tmp_path):
         a, b = open(os.path.join(one, "%d.png" % i), "rb").read(), open(os.path.join(two, "%d.png" % i), "rb").read()
         assert a == b, "frame %d differs between the 1-rank and the 2-rank run" % i
     assert sorted(os.listdir(two)) == sorted(["%d.png" % i for i in range(7)] + ["a.gif"])
+    for d in (one, two):                                     # the chunked, GIF-less pass wrote the same files
+        assert sorted(os.listdir(d + "_chunked")) == sorted("%d.png" % i for i in range(7))
+        for i in range(7):
+            assert open(os.path.join(d + "_chunked", "%d.png" % i), "rb").read() == open(os.path.join(one, "%d.png" % i), "rb").read(), (d, i)
     frames = [np.asarray(Image.open(os.path.join(one, "%d.png" % i))) for i in range(7)]
     assert all(not np.array_equal(frames[0], f) for f in frames[1:])
     assert not (frames[2][..., 0] == 127).all(), "the unfinished frame was not rendered again"    # (call 1 of rank 0 = frame 2)
