@@ -577,3 +577,11 @@ def render_train(o, d, near, far, occ, aabb, model, jitter, MAX_SAMPLES=256, bg=
     bgc = 1.0 if bg is None else _f32(bg).reshape(-1, 3)
     color = (w[..., None] * rgb).sum(1) + trans[:, -1:] * bgc
     return dict(rgb=color.astype(np.float32), depth=(w * z).sum(1), alpha=w.sum(1), weights=w, n_field=int(mask.sum()))
+
+
+def pack_rgba8(rgb, alpha):
+    """animate.py:107-113 / novel_view.py:120-125: `img = cat([rgb, alpha[..., None]], -1)`, `(img * 255).astype(np.uint8)` --
+    the product in fp32, truncated; values outside [0, 1] clamped first (numpy's out-of-range float -> uint8 cast is
+    undefined; the reference's images stay inside but for an ulp).  rgb [...,3], alpha [...] -> uint8 [...,4]."""
+    img = np.concatenate([_f32(rgb), _f32(alpha)[..., None]], axis=-1)
+    return (np.clip(img, np.float32(0), np.float32(1)) * np.float32(255)).astype(np.uint8)

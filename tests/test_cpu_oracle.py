@@ -1387,3 +1387,18 @@ def test_tcnn_golden_consumer_runs_on_a_self_made_file(tmp_path, r3):
     TG.assert_oracle(res)
     with pytest.raises(SystemExit):
         t.main(["--self-made", TG.PIN_PATH])                                                       # a self-made file cannot take the pin's place
+
+
+def test_pack_rgba8_oracle_is_the_reference_expression():
+    """oracle.pack_rgba8 == `(img.cpu().numpy() * 255).astype(np.uint8)` of animate.py:107-113 on images inside [0, 1] (where
+    the reference's expression is defined), clamps outside, and truncates (254.999 -> 254, k / 255 -> k)."""
+    from oracle import oracle as orc
+    rs = np.random.RandomState(3)
+    rgb, alpha = rs.rand(17, 9, 3).astype(np.float32), rs.rand(17, 9).astype(np.float32)
+    img = np.concatenate([rgb, alpha[..., None]], -1)
+    assert np.array_equal(orc.pack_rgba8(rgb, alpha), (img * 255).astype(np.uint8))
+    lv = (np.arange(256, dtype=np.float32) / np.float32(255))
+    got = orc.pack_rgba8(np.stack([lv, np.nextafter(lv, np.float32(-1)), np.nextafter(lv, np.float32(2))], -1), lv)
+    assert np.array_equal(got[:, 0], (lv * np.float32(255)).astype(np.uint8)) and np.array_equal(got[:, 3], got[:, 0])
+    assert (np.abs(got[:, 0].astype(int) - np.arange(256)) <= 1).all() and got[0, 1] == 0 and got[255, 2] == 255      # clamped below 0 / above 1
+    assert orc.pack_rgba8(np.float32([[1.5, -0.5, 0.999999]]), np.float32([2.0]))[0].tolist() == [255, 0, 254, 255]

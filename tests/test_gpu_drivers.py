@@ -38,7 +38,7 @@ def _run(module, args, ranks=1, timeout=600):
     return r.stdout
 
 
-def test_pack_rgba8_equals_the_reference_expression():
+def test_pack_rgba8_equals_the_reference_expression(oracle):
     """ia_pack_rgba8 == (cat([rgb, alpha[..., None]]) * 255).astype(uint8) of animate.py:107-113 (clamped), bit for bit,
     including values an ulp outside [0, 1], exact k / 255 levels and NaN-free extremes."""
     from instantavatar_amd.drivers.animate import pack_rgba8
@@ -55,6 +55,7 @@ def test_pack_rgba8_equals_the_reference_expression():
     pack_rgba8((rgb, None, alpha, None), out)
     want = (torch.cat([rgb, alpha[..., None]], -1)[0].clamp(0, 1) * 255).to(torch.uint8)
     assert torch.equal(out, want)
+    assert np.array_equal(out.cpu().numpy(), oracle.pack_rgba8(rgb[0].cpu().numpy(), alpha[0].cpu().numpy()))      # the CPU restatement
 
 
 def test_animate_driver_two_ranks_write_the_same_files_as_one(tmp_path):
