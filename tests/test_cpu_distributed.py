@@ -170,7 +170,7 @@ def test_bench_supervised_training_child_job_dry_run():
     sup = r["train"]["supervised"]["attempts"]
     assert len(sup) == 1 and sup[0]["all_ranks_ok"] and sup[0]["IA_GRAPH_COLLECTIVES"] == "1", sup
     assert r["train"]["ranks_in_child_group"] == 2 and r["train"]["graph_collectives"] is True and r["value"] == 8192.0
-    r = _bench_dry({"IA_TEST_CHILD_HANG_RANK": "1", "IA_BENCH_CHILD_TIMEOUT": "12"})
+    r = _bench_dry({"IA_TEST_CHILD_HANG_RANK": "1", "IA_BENCH_CHILD_TIMEOUT": "30"})
     sup = r["train"]["supervised"]["attempts"]
     assert len(sup) == 2 and not sup[0]["all_ranks_ok"] and "killed" in sup[0]["this_rank"], sup
     assert sup[1]["all_ranks_ok"] and sup[1]["IA_GRAPH_COLLECTIVES"] == "0" and r["train"]["graph_collectives"] is False, sup

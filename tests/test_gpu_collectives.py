@@ -132,7 +132,7 @@ def test_bench_two_ranks_share_the_one_gpu(mode):
     env["IA_BENCH_SHARE_DEVICE"] = "1"
     extra = {"render": ["--train-steps", "12"], "train": ["--train-only"], "tile": ["--tile-shard"], "train-hang": ["--train-only"]}[mode]
     if mode == "train-hang":
-        env.update(IA_TEST_CHILD_HANG_RANK="1", IA_BENCH_CHILD_TIMEOUT="45")
+        env.update(IA_TEST_CHILD_HANG_RANK="1", IA_BENCH_CHILD_TIMEOUT="70")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--cpu-frames", "0",
                           "--spinup-max-ms", "200"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
