@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantavatar_amd.pipeline import build_synthetic_model, make_batch
 dev = "cuda:0"
-coherent = len(sys.argv) > 1 and sys.argv[1] == "coherent"
+coherent = len(sys.argv) > 1 and sys.argv[1].startswith("coherent")      # coherent | coherent-morton | coherent-shuffled (the same points re-ordered)
 model, body, fp = build_synthetic_model(dev, resolution=128 if coherent else 32)
 net = model.net_coarse
 bb = model.deformer.bbox
@@ -18,7 +18,11 @@ if coherent:
     spec.loader.exec_module(bench)
     poses, tr = syn.load_animation_track(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "aist_demo_200.npz"))
     x = bench.frame_coherent_samples(model, make_batch(dev, 512, poses[0], tr[0]), 512)
-    print("frame-coherent samples:", x.shape[0])
+    if sys.argv[1] == "coherent-morton":
+        x = x[bench._morton_order(x, bb)[0]].contiguous()
+    elif sys.argv[1] == "coherent-shuffled":
+        x = x[torch.randperm(x.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(1))].contiguous()
+    print("frame-coherent samples (%s):" % sys.argv[1], x.shape[0])
     torch.cuda.synchronize()
     for _ in range(4):
         net.encode_planes(x)
