@@ -237,6 +237,28 @@ int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *cand_Jinv, 
                                   const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes,
                                   void *stream);
 
+/* ---- a7, `version: 2` of ForwardDeformer (deformer_torch.py:68-75, confs/deformer/fast_snarf_debug.yaml) ----------------
+ * In training the reference replaces every valid root x_c* by the closed-form inverse skinning  x_c = R^T (x_d - t),
+ * T = sum_n w_n(x_c*) tfs_n  (query_weights at the detached root, einsum "pn,nij->pij", `(pts - T[:, :3, 3]) @ T[:, :3, :3]`)
+ * and differentiates it w.r.t. tfs.  Entries e = 0..n-1: root xc[e], target xd[pt] with pt = cand_pt[e] when cand_pt is
+ * given (compact candidate lists) or e / n_init (the dense [P, n_init] layout); live entries: e < *n_dev and / or valid[e].
+ *   ia_snarf_inverse_skinning      out [n,3] = the value (0 for entries that are not live)
+ *   ia_snarf_inverse_skinning_bwd  d_tfs [24,4,4] += the gradient (rows 0..2); d_xd_entry [n,3] (optional) = R g of every entry, the
+ *                                  gradient w.r.t. ITS target (sum the entries of a point: x_d reaches the SMPL parameters through
+ *                                  the ray frame, snarf_deformer.py:95-103); ws as for ia_snarf_implicit_bwd
+ *   ia_expand_candidate_points     cand_pt[pt_off[p] + j] = p, j < pt_cnt[p] (the point of every compact candidate)       */
+int ia_snarf_inverse_skinning(const float *xc, const float *xd, const int32_t *cand_pt, int n_init,
+                              const uint8_t *valid, long n, const int32_t *n_dev, const float *voxel_w,
+                              int channel_last, const ia_snarf_grid *grid, const float *tfs, float *out,
+                              void *stream);
+int ia_snarf_inverse_skinning_bwd(const float *xc, const float *xd, const int32_t *cand_pt, int n_init,
+                                  const uint8_t *valid, const float *grad_out, long n, const int32_t *n_dev,
+                                  const float *voxel_w, int channel_last, const ia_snarf_grid *grid,
+                                  const float *tfs, float *d_tfs, float *d_xd_entry, void *ws, size_t ws_bytes,
+                                  void *stream);
+int ia_expand_candidate_points(const int32_t *pt_off, const uint8_t *pt_cnt, int P, const int32_t *n_pts_dev,
+                               int32_t *cand_pt, int cap, void *stream);
+
 /* ---- a9 + a10 + a11: canonical field ---------------------------------------
  * Replaces NeRFNGPNet.forward (ngp.py:73-83) = tcnn NetworkWithInputEncoding
  * (HashGrid -> FullyFusedMLP 32-64-16) + tcnn Network (16-64-64-16, sigmoid).

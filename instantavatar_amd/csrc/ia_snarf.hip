@@ -523,18 +523,73 @@ __device__ __forceinline__ float id_border_index(float g, int size) {
 
 // CL: voxel_w is channel-LAST [D,H,W,24] (96 contiguous bytes per voxel: six 16-byte loads per corner instead of 24 four-byte
 // loads 2 MB apart; the refine step's launch went from 176 us to the figure in DESIGN.md with it)
+// query_weights (deformer_torch.py:190-202): trilinear sample of the 24 skinning weights at x, align_corners, border padding
 template <bool CL>
+__device__ __forceinline__ void id_sample_weights(const float *__restrict__ voxel_w, const SnarfGridDev &g, float x0, float x1, float x2,
+                                                  float *__restrict__ w) {
+  const long vol = (long)g.D * g.H * g.W;
+  const float ix = id_border_index(g.scl[0] * (x0 + g.off[0]), g.W);
+  const float iy = id_border_index(g.scl[1] * (x1 + g.off[1]), g.H);
+  const float iz = id_border_index(g.scl[2] * (x2 + g.off[2]), g.D);
+  const int xa = (int)floorf(ix), ya = (int)floorf(iy), za = (int)floorf(iz);
+  const float fx = ix - xa, fy = iy - ya, fz = iz - za;
+#pragma unroll
+  for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+    for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+      for (int cx = 0; cx < 2; cx++) {
+        const int xx = xa + cx, yy = ya + cy, zz = za + cz;
+        if (xx >= g.W || yy >= g.H || zz >= g.D) continue;  // only at the clamped border, weight 0
+        const float wt = (cx ? fx : 1.f - fx) * (cy ? fy : 1.f - fy) * (cz ? fz : 1.f - fz);
+        if (CL) {
+          const float4 *p4 = reinterpret_cast<const float4 *>(voxel_w + (((long)zz * g.H + yy) * g.W + xx) * 24);
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            const float4 v = p4[q];
+            w[4 * q] = __builtin_fmaf(wt, v.x, w[4 * q]); w[4 * q + 1] = __builtin_fmaf(wt, v.y, w[4 * q + 1]);
+            w[4 * q + 2] = __builtin_fmaf(wt, v.z, w[4 * q + 2]); w[4 * q + 3] = __builtin_fmaf(wt, v.w, w[4 * q + 3]);
+          }
+        } else {
+          const float *p = voxel_w + ((long)zz * g.H + yy) * g.W + xx;
+#pragma unroll
+          for (int k = 0; k < 24; k++) w[k] = __builtin_fmaf(wt, p[(long)k * vol], w[k]);
+        }
+      }
+}
+
+// the blended transform T = sum_n w_n tfs_n (rows 0..2) of an entry's skinning weights; s_tfs: [24][12] in LDS
+__device__ __forceinline__ void id_blend_transform(const float *__restrict__ w, const float (*__restrict__ s_tfs)[12], float *__restrict__ T) {
+#pragma unroll
+  for (int q = 0; q < 12; q++) T[q] = 0.f;
+  for (int nb = 0; nb < 24; nb++)
+#pragma unroll
+    for (int q = 0; q < 12; q++) T[q] = __builtin_fmaf(w[nb], s_tfs[nb][q], T[q]);
+}
+
+// MODE 0: version 1, the implicit differentiation above (inputs J_inv, grad).
+// MODE 1: version 2 (deformer_torch.py:68-75), x_c = R^T (x_d - t) with T = sum_n w_n(x_c*) tfs_n:
+//         dL/dT[i][j] = (x_d - t)_i g_j (j < 3), dL/dT[i][3] = -sum_j R[i][j] g_j; the entry's target x_d is xd[pt] with
+//         pt = cand_pt[e] (compact candidate lists) or e / n_init (the dense [P, n_init] layout).
+template <bool CL, int MODE>
 __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
     const float *__restrict__ xc, const float *__restrict__ J_inv, const uint8_t *__restrict__ valid,
     const float *__restrict__ grad, long n, const int32_t *__restrict__ n_dev, const float *__restrict__ voxel_w,
-    SnarfGridDev g, float *__restrict__ partial) {
+    SnarfGridDev g, float *__restrict__ partial, const float *__restrict__ xd, const int32_t *__restrict__ cand_pt, int n_init,
+    const float *__restrict__ tfs, float *__restrict__ d_xd) {
+  const long n_all = n;
   if (n_dev) n = min(n, (long)*n_dev);   // compact candidate lists: device-side live count, no validity mask
   __shared__ float s_w[IA_ID_THREADS][25];   // +1: the 24-float rows start in different banks
   __shared__ float s_vh[IA_ID_THREADS][13];
+  __shared__ float s_tfs[24][12];
   const int tid = threadIdx.x;
-  const long vol = (long)g.D * g.H * g.W;
+  if (MODE == 1) {
+    for (int e = tid; e < 24 * 12; e += IA_ID_THREADS) s_tfs[e / 12][e % 12] = tfs[(e / 12) * 16 + e % 12];
+    __syncthreads();
+  }
   float acc0 = 0.f, acc1 = 0.f;              // outputs tid and tid + 256 of the 288 (bone, row, col) sums
-  for (long base = (long)blockIdx.x * IA_ID_THREADS; base < n; base += (long)gridDim.x * IA_ID_THREADS) {
+  const long n_loop = (MODE == 1 && d_xd) ? n_all : n;   // (entries past the live count still get their zero in d_xd)
+  for (long base = (long)blockIdx.x * IA_ID_THREADS; base < n_loop; base += (long)gridDim.x * IA_ID_THREADS) {
     const long i = base + tid;
     const bool ok = i < n && (!valid || valid[i]);
     float w[24], vh[12];
@@ -545,42 +600,32 @@ __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
     if (ok) {
       const float x0 = xc[i * 3], x1 = xc[i * 3 + 1], x2 = xc[i * 3 + 2];
       const float g0 = grad[i * 3], g1 = grad[i * 3 + 1], g2 = grad[i * 3 + 2];
-      const float *Ji = J_inv + i * 9;
-      const float v[3] = {-(Ji[0] * g0 + Ji[3] * g1 + Ji[6] * g2), -(Ji[1] * g0 + Ji[4] * g1 + Ji[7] * g2),
-                          -(Ji[2] * g0 + Ji[5] * g1 + Ji[8] * g2)};
-      const float h[4] = {x0, x1, x2, 1.f};
+      id_sample_weights<CL>(voxel_w, g, x0, x1, x2, w);
+      if (MODE == 0) {
+        const float *Ji = J_inv + i * 9;
+        const float v[3] = {-(Ji[0] * g0 + Ji[3] * g1 + Ji[6] * g2), -(Ji[1] * g0 + Ji[4] * g1 + Ji[7] * g2),
+                            -(Ji[2] * g0 + Ji[5] * g1 + Ji[8] * g2)};
+        const float h[4] = {x0, x1, x2, 1.f};
 #pragma unroll
-      for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) vh[c * 4 + k] = v[c] * h[k];
-      const float ix = id_border_index(g.scl[0] * (x0 + g.off[0]), g.W);
-      const float iy = id_border_index(g.scl[1] * (x1 + g.off[1]), g.H);
-      const float iz = id_border_index(g.scl[2] * (x2 + g.off[2]), g.D);
-      const int xa = (int)floorf(ix), ya = (int)floorf(iy), za = (int)floorf(iz);
-      const float fx = ix - xa, fy = iy - ya, fz = iz - za;
+          for (int k = 0; k < 4; k++) vh[c * 4 + k] = v[c] * h[k];
+      } else {
+        float T[12];
+        id_blend_transform(w, s_tfs, T);
+        const long pt = cand_pt ? (long)cand_pt[i] : i / n_init;
+        const float gg[3] = {g0, g1, g2};
 #pragma unroll
-      for (int cz = 0; cz < 2; cz++)
+        for (int c = 0; c < 3; c++) {
+          const float a = xd[pt * 3 + c] - T[c * 4 + 3];
 #pragma unroll
-        for (int cy = 0; cy < 2; cy++)
-#pragma unroll
-          for (int cx = 0; cx < 2; cx++) {
-            const int xx = xa + cx, yy = ya + cy, zz = za + cz;
-            if (xx >= g.W || yy >= g.H || zz >= g.D) continue;  // only at the clamped border, weight 0
-            const float wt = (cx ? fx : 1.f - fx) * (cy ? fy : 1.f - fy) * (cz ? fz : 1.f - fz);
-            if (CL) {
-              const float4 *p4 = reinterpret_cast<const float4 *>(voxel_w + (((long)zz * g.H + yy) * g.W + xx) * 24);
-#pragma unroll
-              for (int q = 0; q < 6; q++) {
-                const float4 v = p4[q];
-                w[4 * q] = __builtin_fmaf(wt, v.x, w[4 * q]); w[4 * q + 1] = __builtin_fmaf(wt, v.y, w[4 * q + 1]);
-                w[4 * q + 2] = __builtin_fmaf(wt, v.z, w[4 * q + 2]); w[4 * q + 3] = __builtin_fmaf(wt, v.w, w[4 * q + 3]);
-              }
-            } else {
-              const float *p = voxel_w + ((long)zz * g.H + yy) * g.W + xx;
-#pragma unroll
-              for (int k = 0; k < 24; k++) w[k] = __builtin_fmaf(wt, p[(long)k * vol], w[k]);
-            }
-          }
+          for (int k = 0; k < 3; k++) vh[c * 4 + k] = a * gg[k];
+          vh[c * 4 + 3] = -(T[c * 4] * g0 + T[c * 4 + 1] * g1 + T[c * 4 + 2] * g2);
+        }
+      }
+    }
+    if (MODE == 1 && d_xd && i < n_all) {   // dL/dx_d of the entry = R g (x_d reaches the SMPL parameters through the ray frame w2s)
+      d_xd[i * 3] = -vh[3]; d_xd[i * 3 + 1] = -vh[7]; d_xd[i * 3 + 2] = -vh[11];
     }
     __syncthreads();  // previous tile consumed
 #pragma unroll
@@ -601,6 +646,46 @@ __global__ __launch_bounds__(IA_ID_THREADS) void k_implicit_bwd(
   }
   partial[(size_t)blockIdx.x * 288 + tid] = acc0;
   if (tid + IA_ID_THREADS < 288) partial[(size_t)blockIdx.x * 288 + tid + IA_ID_THREADS] = acc1;
+}
+
+// version 2, forward: out[e] = R^T (x_d - t) for the live / valid entries, 0 elsewhere (the reference scatters into zeros)
+template <bool CL>
+__global__ __launch_bounds__(IA_ID_THREADS) void k_inverse_skinning(
+    const float *__restrict__ xc, const float *__restrict__ xd, const int32_t *__restrict__ cand_pt, int n_init,
+    const uint8_t *__restrict__ valid, long n, const int32_t *__restrict__ n_dev, const float *__restrict__ voxel_w, SnarfGridDev g,
+    const float *__restrict__ tfs, float *__restrict__ out) {
+  __shared__ float s_tfs[24][12];
+  for (int e = threadIdx.x; e < 24 * 12; e += IA_ID_THREADS) s_tfs[e / 12][e % 12] = tfs[(e / 12) * 16 + e % 12];
+  __syncthreads();
+  const long live = n_dev ? min(n, (long)*n_dev) : n;
+  for (long i = (long)blockIdx.x * IA_ID_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * IA_ID_THREADS) {
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (i < live && (!valid || valid[i])) {
+      float w[24], T[12];
+#pragma unroll
+      for (int k = 0; k < 24; k++) w[k] = 0.f;
+      id_sample_weights<CL>(voxel_w, g, xc[i * 3], xc[i * 3 + 1], xc[i * 3 + 2], w);
+      id_blend_transform(w, s_tfs, T);
+      const long pt = cand_pt ? (long)cand_pt[i] : i / n_init;
+      const float a0 = xd[pt * 3] - T[3], a1 = xd[pt * 3 + 1] - T[7], a2 = xd[pt * 3 + 2] - T[11];
+      o0 = a0 * T[0] + a1 * T[4] + a2 * T[8];
+      o1 = a0 * T[1] + a1 * T[5] + a2 * T[9];
+      o2 = a0 * T[2] + a1 * T[6] + a2 * T[10];
+    }
+    out[i * 3] = o0; out[i * 3 + 1] = o1; out[i * 3 + 2] = o2;
+  }
+}
+
+// candidate -> sample point: cand_pt[pt_off[p] + j] = p for j < pt_cnt[p] (the compaction of k_search keeps a point's
+// candidates contiguous); entries past the live candidate count are never read
+__global__ __launch_bounds__(256) void k_expand_candidate_points(const int32_t *__restrict__ pt_off, const uint8_t *__restrict__ pt_cnt, int P,
+                                                                 const int32_t *__restrict__ n_pts_dev, int32_t *__restrict__ cand_pt, int cap) {
+  if (n_pts_dev) P = min(P, *n_pts_dev);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int o = pt_off[p], c = pt_cnt[p];
+  for (int j = 0; j < c; j++)
+    if (o + j < cap) cand_pt[o + j] = p;
 }
 
 // one wave per output o = bone * 12 + row * 4 + col: lanes sum the per-workgroup partials b = lane, lane + 64, ... and the
@@ -627,21 +712,29 @@ static int ia_implicit_blocks(long n) {
 
 extern "C" size_t ia_snarf_implicit_bwd_workspace_bytes(long n) { return (size_t)ia_implicit_blocks(n) * 288 * sizeof(float); }
 
+struct InvSkinArgs { const float *xd; const int32_t *cand_pt; int n_init; const float *tfs; float *d_xd; };
+
 static int ia_implicit_bwd_impl(const char *who, const float *xc, const float *J_inv, const uint8_t *valid,
                                 const float *grad_xc, long n, const int32_t *n_dev, const float *voxel_w,
                                 const ia_snarf_grid *grid, float *d_tfs, void *ws, size_t ws_bytes, hipStream_t s,
-                                bool channel_last = false) {
+                                bool channel_last = false, const InvSkinArgs *v2 = nullptr) {
   IA_CHECK_ARG(n >= 0, "%s: n < 0", who);
   if (n == 0) return IA_OK;
-  IA_CHECK_ARG(xc && J_inv && (valid || n_dev) && grad_xc && voxel_w && grid && d_tfs && ws, "%s: null pointer", who);
+  IA_CHECK_ARG(xc && (J_inv || v2) && (valid || n_dev) && grad_xc && voxel_w && grid && d_tfs && ws, "%s: null pointer", who);
+  IA_CHECK_ARG(!v2 || (v2->xd && v2->tfs && (v2->cand_pt || v2->n_init > 0)), "%s: version-2 arguments (xd, tfs, cand_pt or n_init)", who);
   if (ws_bytes < ia_snarf_implicit_bwd_workspace_bytes(n)) return ia_set_error(IA_ERR_WORKSPACE, "%s: workspace too small", who);
   const int blocks = ia_implicit_blocks(n);
-  if (channel_last)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_implicit_bwd<true>), dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev,
-                       voxel_w, ia_make_grid_dev(grid), static_cast<float *>(ws));
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_implicit_bwd<false>), dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, valid, grad_xc, n, n_dev,
-                       voxel_w, ia_make_grid_dev(grid), static_cast<float *>(ws));
+  const SnarfGridDev g = ia_make_grid_dev(grid);
+  float *part = static_cast<float *>(ws);
+  const float *xd = v2 ? v2->xd : nullptr, *tfs = v2 ? v2->tfs : nullptr;
+  const int32_t *cpt = v2 ? v2->cand_pt : nullptr;
+  const int ni = v2 ? v2->n_init : 1;
+  float *dxd = v2 ? v2->d_xd : nullptr;
+#define IA_ID_LAUNCH(CL, MODE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_implicit_bwd<CL, MODE>), dim3(blocks), dim3(IA_ID_THREADS), 0, s, xc, J_inv, \
+                                                  valid, grad_xc, n, n_dev, voxel_w, g, part, xd, cpt, ni, tfs, dxd)
+  if (v2) { if (channel_last) IA_ID_LAUNCH(true, 1); else IA_ID_LAUNCH(false, 1); }
+  else    { if (channel_last) IA_ID_LAUNCH(true, 0); else IA_ID_LAUNCH(false, 0); }
+#undef IA_ID_LAUNCH
   hipLaunchKernelGGL(k_implicit_bwd_reduce, dim3(288), dim3(64), 0, s, static_cast<const float *>(ws), blocks, d_tfs);
   IA_LAUNCH_CHECK("k_implicit_bwd");
   return IA_OK;
@@ -660,4 +753,42 @@ extern "C" int ia_snarf_implicit_bwd_compact(const float *cand_xc, const float *
   IA_CHECK_ARG(n_cand, "ia_snarf_implicit_bwd_compact: n_cand is null");
   return ia_implicit_bwd_impl("ia_snarf_implicit_bwd_compact", cand_xc, cand_Jinv, nullptr, grad_xc, cap, n_cand, voxel_w,
                               grid, d_tfs, ws, ws_bytes, (hipStream_t)stream, channel_last != 0);
+}
+
+// ---- ForwardDeformer `version: 2` (deformer_torch.py:68-75): closed-form inverse skinning of the roots -----------------
+extern "C" int ia_snarf_inverse_skinning(const float *xc, const float *xd, const int32_t *cand_pt, int n_init, const uint8_t *valid, long n,
+                                         const int32_t *n_dev, const float *voxel_w, int channel_last, const ia_snarf_grid *grid,
+                                         const float *tfs, float *out, void *stream) {
+  IA_CHECK_ARG(n >= 0, "ia_snarf_inverse_skinning: n < 0");
+  if (n == 0) return IA_OK;
+  IA_CHECK_ARG(xc && xd && voxel_w && grid && tfs && out && (cand_pt || n_init > 0), "ia_snarf_inverse_skinning: null pointer / n_init");
+  const int blocks = ia_implicit_blocks(n);
+  const SnarfGridDev g = ia_make_grid_dev(grid);
+  if (channel_last)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inverse_skinning<true>), dim3(blocks), dim3(IA_ID_THREADS), 0, (hipStream_t)stream, xc, xd, cand_pt, n_init,
+                       valid, n, n_dev, voxel_w, g, tfs, out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inverse_skinning<false>), dim3(blocks), dim3(IA_ID_THREADS), 0, (hipStream_t)stream, xc, xd, cand_pt, n_init,
+                       valid, n, n_dev, voxel_w, g, tfs, out);
+  IA_LAUNCH_CHECK("k_inverse_skinning");
+  return IA_OK;
+}
+
+extern "C" int ia_snarf_inverse_skinning_bwd(const float *xc, const float *xd, const int32_t *cand_pt, int n_init, const uint8_t *valid,
+                                             const float *grad_out, long n, const int32_t *n_dev, const float *voxel_w, int channel_last,
+                                             const ia_snarf_grid *grid, const float *tfs, float *d_tfs, float *d_xd_entry, void *ws,
+                                             size_t ws_bytes, void *stream) {
+  const InvSkinArgs a = {xd, cand_pt, n_init, tfs, d_xd_entry};
+  return ia_implicit_bwd_impl("ia_snarf_inverse_skinning_bwd", xc, nullptr, valid, grad_out, n, n_dev, voxel_w, grid, d_tfs, ws, ws_bytes,
+                              (hipStream_t)stream, channel_last != 0, &a);
+}
+
+extern "C" int ia_expand_candidate_points(const int32_t *pt_off, const uint8_t *pt_cnt, int P, const int32_t *n_pts_dev, int32_t *cand_pt,
+                                          int cap, void *stream) {
+  IA_CHECK_ARG(P >= 0 && cap >= 0, "ia_expand_candidate_points: negative size");
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pt_off && pt_cnt && cand_pt, "ia_expand_candidate_points: null pointer");
+  hipLaunchKernelGGL(k_expand_candidate_points, dim3(ia_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, pt_off, pt_cnt, P, n_pts_dev, cand_pt, cap);
+  IA_LAUNCH_CHECK("k_expand_candidate_points");
+  return IA_OK;
 }

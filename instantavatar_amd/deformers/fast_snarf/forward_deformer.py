@@ -153,6 +153,9 @@ class ForwardDeformer(torch.nn.Module):
             return xc, others
         mask = others["valid_ids"]
         if self.version != 1:
+            # :68-75, closed-form inverse skinning of the roots (value AND gradient differ from version 1)
+            if FUSED_IMPLICIT_DIFF and xc.is_cuda and tfs.shape[0] == 1:
+                return _InverseSkinningFn.apply(tfs, xc.detach(), xd, mask, None, None, self).reshape(xc.shape), others
             T = torch.einsum("pn,nij->pij", self.query_weights(xc, cond, mask=mask)[mask], tfs[0])
             xd_rep = xd[..., None, :].expand(1, -1, len(self.init_bones), 3)[mask]
             out = torch.zeros_like(xc)
@@ -212,6 +215,50 @@ class _ImplicitDiffFn(torch.autograd.Function):
                                            _lib.ptr(d.lbs_voxel_final), C.byref(d.grid_desc()), _lib.ptr(d_tfs),
                                            _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_implicit_bwd")
         return d_tfs, None, None, None, None
+
+
+class _InverseSkinningFn(torch.autograd.Function):
+    """`version: 2` (deformer_torch.py:68-75): x_c = R^T (x_d - t), T = sum_n w_n(x_c*) tfs_n, as the kernels
+    `ia_snarf_inverse_skinning` / `ia_snarf_inverse_skinning_bwd`.  Two layouts: dense (xc [1,P,I,3] with `mask` [1,P,I], the
+    entry's target is xd[e // I]) and compact (xc [cap,3] with the live count `n_dev` and `cand_pt` [cap], the sample point of
+    every candidate).  The roots carry no gradient (the reference searches under no_grad); tfs does, and so does the target
+    x_d: in the refine configuration the sample points are rays in the SMPL-root frame, i.e. functions of w2s."""
+
+    @staticmethod
+    def forward(ctx, tfs, xc, xd, mask, cand_pt, n_dev, deformer):
+        L = _lib.lib()
+        x = xc.reshape(-1, 3).float().contiguous()
+        t = xd.reshape(-1, 3).float().contiguous()
+        m = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
+        n_init = xc.shape[-2] if mask is not None else 1
+        tf = tfs.detach().reshape(-1, 4, 4).float().contiguous()
+        out = torch.empty_like(x)
+        _lib.check(L.ia_snarf_inverse_skinning(_lib.ptr(x), _lib.ptr(t), _lib.ptr(cand_pt), n_init, _lib.ptr(m), x.shape[0], _lib.ptr(n_dev),
+                                               _lib.ptr(deformer.lbs_voxel_channel_last()), 1, C.byref(deformer.grid_desc()), _lib.ptr(tf),
+                                               _lib.ptr(out), _lib.stream()), "ia_snarf_inverse_skinning")
+        ctx.deformer, ctx.n_init, ctx.tfs_shape, ctx.xd_shape = deformer, n_init, tfs.shape, xd.shape
+        ctx.save_for_backward(x, t, m, cand_pt, n_dev, tf)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, m, cand_pt, n_dev, tf = ctx.saved_tensors
+        d, L = ctx.deformer, _lib.lib()
+        gg = g.reshape(-1, 3).float().contiguous()
+        d_tfs = torch.zeros(ctx.tfs_shape, device=x.device)
+        want_dx = ctx.needs_input_grad[2]
+        d_e = torch.empty_like(x) if want_dx else None
+        ws = torch.empty(int(L.ia_snarf_implicit_bwd_workspace_bytes(x.shape[0])), dtype=torch.uint8, device=x.device)
+        _lib.check(L.ia_snarf_inverse_skinning_bwd(_lib.ptr(x), _lib.ptr(t), _lib.ptr(cand_pt), ctx.n_init, _lib.ptr(m), _lib.ptr(gg), x.shape[0],
+                                                   _lib.ptr(n_dev), _lib.ptr(d.lbs_voxel_channel_last()), 1, C.byref(d.grid_desc()), _lib.ptr(tf),
+                                                   _lib.ptr(d_tfs), _lib.ptr(d_e), _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_snarf_inverse_skinning_bwd")
+        d_xd = None
+        if want_dx:   # sum the entries of every point: the n_init slots of the dense layout, or the candidates that name the point
+            if cand_pt is None:
+                d_xd = d_e.reshape(-1, ctx.n_init, 3).sum(1).reshape(ctx.xd_shape)
+            else:
+                d_xd = torch.zeros((t.shape[0], 3), device=x.device).index_add_(0, cand_pt.long().clamp_(0, t.shape[0] - 1), d_e).reshape(ctx.xd_shape)
+        return d_tfs, None, d_xd, None, None, None, None
 
 
 class _ImplicitDiffCompactFn(torch.autograd.Function):

@@ -344,7 +344,8 @@ class SNARFDeformer():
         dev = pts.device
         cap = P * k if cap is None else min(int(cap), P * k)
         out = dict(cand_xc=torch.empty((cap, 3), device=dev), pt_off=torch.empty(P, dtype=torch.int32, device=dev),
-                   pt_cnt=torch.empty(P, dtype=torch.uint8, device=dev), n_cand=torch.zeros(1, dtype=torch.int32, device=dev))
+                   pt_cnt=torch.empty(P, dtype=torch.uint8, device=dev), n_cand=torch.zeros(1, dtype=torch.int32, device=dev),
+                   pts=pts, n_pts_dev=n_pts_dev)
         tfs = self.tfs.detach().float().contiguous()
         L = _lib.lib()
         head = (_lib.ptr(pts), P, _lib.ptr(n_pts_dev), _lib.ptr(self.deformer.voxel_J_cl), _lib.ptr(tfs),
@@ -364,18 +365,29 @@ class SNARFDeformer():
         """The compact candidate positions of `search_compact`, carrying -- when the bone transforms are under
         optimisation (`tfs.requires_grad`: SMPL refinement, DNeRF.py:113-128) -- the gradient of the implicit
         differentiation of deformer_torch.py:50-67 (`ia_snarf_implicit_bwd_compact`); plain tensor otherwise."""
+        if self.deformer.version != 1:
+            # `version: 2` (deformer_torch.py:68-75): in training every root is REPLACED by its closed-form inverse skinning
+            # x_c = R^T (x_d - t) -- another value, not only another gradient -- whether or not tfs is under optimisation
+            from .fast_snarf.forward_deformer import _InverseSkinningFn
+            P = sc["pts"].shape[0]
+            cand_pt = torch.empty(sc["cand_xc"].shape[0], dtype=torch.int32, device=sc["pts"].device)
+            _lib.check(_lib.lib().ia_expand_candidate_points(_lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), P, _lib.ptr(sc["n_pts_dev"]), _lib.ptr(cand_pt),
+                                                             cand_pt.numel(), _lib.stream()), "ia_expand_candidate_points")
+            return _InverseSkinningFn.apply(self.tfs, sc["cand_xc"], sc["pts"], None, cand_pt, sc["n_cand"], self.deformer)
         if "cand_Jinv" not in sc:
             return sc["cand_xc"]
         from .fast_snarf.forward_deformer import _ImplicitDiffCompactFn
         return _ImplicitDiffCompactFn.apply(self.tfs, sc["cand_xc"], sc["cand_Jinv"], sc["n_cand"], self.deformer)
 
     def fused_train_route(self):
-        """True when the fused training route covers the current state: always without a gradient to tfs; with one,
-        for the implicit differentiation of version 1 (version 2's closed-form inverse skinning, deformer_torch.py:68-75,
-        stays on the dense torch route)."""
+        """True when the fused training route covers the current state: always for version 1 (implicit differentiation of the
+        roots on the compact candidate list) and for version 2 (closed-form inverse skinning, deformer_torch.py:68-75) as long
+        as the SMPL parameters are not under optimisation -- with them, version 2's x_c = R^T (x_d - t) also sends a gradient
+        through the sample points x_d into the ray frame w2s (snarf_deformer.py:95-103), which only the dense route's autograd
+        over the rays carries (its inverse skinning is the same kernel pair, in the dense layout)."""
         if getattr(self, "force_dense_train", False):   # tests: the route that keeps the reference's dense structure
             return False
-        return not self.tfs.requires_grad or self.deformer.version == 1
+        return self.deformer.version == 1 or not self.tfs.requires_grad
 
     #: number of `query_train_fused` calls whose candidates exceeded the capacity (they were dropped); the
     #: capacity doubles after every such call (deferred check, see `_cand_count_check`)
@@ -415,7 +427,7 @@ class SNARFDeformer():
         k = len(self.deformer.init_bones)
         self._cand_count_check()
         cap = P * k if self.train_cand_capacity is None else min(P * k, self.train_cand_capacity)
-        want_J_inv = self.tfs.requires_grad and torch.is_grad_enabled()
+        want_J_inv = self.tfs.requires_grad and torch.is_grad_enabled() and self.deformer.version == 1
         with torch.no_grad():
             sc = self.search_compact(pts, cap=cap, want_J_inv=want_J_inv)
         from ..training import field_autograd

@@ -225,7 +225,7 @@ class Raymarcher(torch.nn.Module):
                   ray_off=i32(n), ray_cnt=i32(n), n_samples=i32(1), near=near, far=far, n=n, S=S)
         draws = getattr(self, "train_draws", None) or {}                           # injected by reproducible tests
         jitter = draws["ray_jitter"].to(dev).float().reshape(n, S).contiguous() if "ray_jitter" in draws else torch.rand((n, S), device=dev)  # :156
-        want_J_inv = deformer.tfs.requires_grad and torch.is_grad_enabled()
+        want_J_inv = deformer.tfs.requires_grad and torch.is_grad_enabled() and deformer.deformer.version == 1
         with torch.no_grad():
             _lib.check(L.ia_march_train_compact(_lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), n, _lib.ptr(grid.occ_bits),
                                                 C.byref(occ), S, _lib.ptr(jitter), _lib.ptr(st["s_pts"]), _lib.ptr(st["s_z"]),

@@ -544,6 +544,31 @@ def implicit_diff_grad(init, xc, J_inv, valid, grad_xc):
     return out.astype(np.float32)
 
 
+def inverse_skinning(init, xc, xd, valid, tfs, grad_out=None):
+    """ForwardDeformer.forward, `version != 1` (deformer_torch.py:68-75): for every valid root x_c* the blended transform
+    T = sum_n w_n(x_c*) tfs_n of its skinning weights (query_weights, no gradient: the roots are detached) and
+    x_c = (x_d - t)^T R   (row vector times matrix: R^T (x_d - t)); invalid slots 0.
+    xc [P,I,3], xd [P,3], valid [P,I], tfs [24,4,4] -> value [P,I,3]; with grad_out [P,I,3] also dL/dtfs [24,4,4]:
+    dL/dR[i][j] = (x_d - t)_i g_j, dL/dt[i] = -sum_j R[i][j] g_j, dL/dtfs_n = w_n dL/dT (rows 0..2)."""
+    xc = _f32(xc)
+    P, I = xc.shape[0], xc.shape[1]
+    m = np.asarray(valid).reshape(P, I).astype(bool)
+    w = query_weights(init, xc[m]).astype(np.float64)                        # [V,24]
+    T = np.einsum("pn,nij->pij", w, _f32(tfs).astype(np.float64))           # [V,4,4]
+    a = np.repeat(_f32(xd)[:, None, :], I, axis=1)[m].astype(np.float64) - T[:, :3, 3]
+    val = np.zeros((P, I, 3), np.float32)
+    val[m] = np.einsum("pi,pij->pj", a, T[:, :3, :3]).astype(np.float32)
+    if grad_out is None:
+        return val
+    g = _f32(grad_out)[m].astype(np.float64)
+    dT = np.zeros((len(w), 3, 4), np.float64)
+    dT[:, :, :3] = a[:, :, None] * g[:, None, :]
+    dT[:, :, 3] = -np.einsum("pij,pj->pi", T[:, :3, :3], g)
+    d_tfs = np.zeros((24, 4, 4), np.float64)
+    d_tfs[:, :3, :] = np.einsum("pn,pik->nik", w, dT)
+    return val, d_tfs.astype(np.float32)
+
+
 # ---- a15: Raymarcher.render_train (raymarcher_acc.py:140-186) + composite (:25-36) -----------------
 def render_train(o, d, near, far, occ, aabb, model, jitter, MAX_SAMPLES=256, bg=None, noise=None):
     """One training render: fixed MAX_SAMPLES slots per ray (raymarch_train), z += jitter * step

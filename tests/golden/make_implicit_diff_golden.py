@@ -1,7 +1,8 @@
 """Generates tests/golden/implicit_diff_golden.npz: the gradient w.r.t. the bone transforms that the REFERENCE's
 autograd produces for the training branch of ForwardDeformer.forward (version 1: "trick for implicit diff with autodiff",
 /root/reference/instant_avatar/deformers/fast_snarf/deformer_torch.py:50-67 with forward_skinning :118-128,
-query_weights :190-202, skinning_mask :204-219, bmv :222-223).
+query_weights :190-202, skinning_mask :204-219, bmv :222-223; and version 2, :68-75: value and gradient of the closed-form
+inverse skinning).
 
 The reference module is imported on the CPU with its three JIT-compiled CUDA extensions, pytorch3d's KNN and `.cuda()`
 stubbed out -- none of them is on the differentiated path: the roots, their validity and J_inv (outputs of the CUDA search,
@@ -82,8 +83,19 @@ def main():
     cos = float((g_ref * g_orc).sum() / (np.linalg.norm(g_ref) * np.linalg.norm(g_orc)))
     print("valid roots %d; |g_ref| %.4f; max abs diff to the oracle's closed form %.3e; cos %.8f" % (
         int(keep.sum()), float(np.abs(g_ref).max()), float(np.abs(g_ref - g_orc).max()), cos))
+    # ---- version 2 (deformer_torch.py:68-75, selected by confs/deformer/fast_snarf_debug.yaml): closed-form inverse skinning
+    # x_c = R^T (x_d - t) with the blended transform of the root's skinning weights; value AND gradient differ from version 1 ----
+    d.version = 2
+    tfs_2 = torch.tensor(tfs[None], requires_grad=True)
+    xc2, _ = d.forward(torch.as_tensor(xd)[None], {}, tfs_2, eval_mode=False)
+    (xc2 * torch.as_tensor(r)[None]).sum().backward()
+    g_ref2 = tfs_2.grad[0].numpy()
+    v_orc2, g_orc2 = oracle.inverse_skinning(init, x, xd, keep, tfs, r)
+    print("version 2: |xc2 - roots| max %.3e; value vs the oracle %.3e; |g_ref2| %.4f; gradient max abs diff to the oracle %.3e" % (
+        float((xc2.detach()[0] - torch.as_tensor(x))[torch.as_tensor(keep)].abs().max()), float(np.abs(xc2.detach().numpy()[0] - v_orc2).max()),
+        float(np.abs(g_ref2).max()), float(np.abs(g_ref2 - g_orc2).max())))
     np.savez_compressed(OUT, xd=xd, xc=x, J_inv=Jinv, valid=keep, r=r, tfs=tfs, grad_tfs=g_ref,
-                        xc_value=xc.detach().numpy()[0])
+                        xc_value=xc.detach().numpy()[0], xc_value_v2=xc2.detach().numpy()[0], grad_tfs_v2=g_ref2)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 

@@ -836,6 +836,23 @@ def test_implicit_differentiation_matches_reference_autograd_golden(oracle, smal
     assert np.array_equal(x, g["xc"]) and np.array_equal(oracle.filter_dup(x, valid).astype(bool), g["valid"])
 
 
+def test_inverse_skinning_version2_matches_reference_autograd_golden(oracle, small_world):
+    """ForwardDeformer `version: 2` (deformer_torch.py:68-75, confs/deformer/fast_snarf_debug.yaml): oracle.inverse_skinning --
+    what the HIP kernels of that branch are tested against -- equals the VALUE the reference's forward returns and the gradient
+    w.r.t. tfs its autograd produces (same generator, same roots as the version-1 golden)."""
+    body, init, fp, world = small_world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "implicit_diff_golden.npz"))
+    val, grad = oracle.inverse_skinning(init, g["xc"], g["xd"], g["valid"], g["tfs"], g["r"])
+    ref_v, ref_g = g["xc_value_v2"], g["grad_tfs_v2"]
+    m = g["valid"].astype(bool)
+    assert np.abs(ref_v[~m]).max() == 0 and np.abs(val[~m]).max() == 0                     # invalid slots are zero
+    assert np.abs(val - ref_v).max() < 2e-6, float(np.abs(val - ref_v).max())
+    assert np.abs(ref_v[m] - g["xc"][m]).max() > 1e-2                                       # NOT the roots: a blended R is not orthogonal
+    assert np.abs(ref_g).max() > 1.0 and np.abs(ref_g[:, 3]).max() == 0
+    assert np.abs(grad - ref_g).max() < 2e-5 * np.abs(ref_g).max(), float(np.abs(grad - ref_g).max())
+    assert np.abs(ref_g - g["grad_tfs"]).max() > 0.1                                        # and not version 1's gradient either
+
+
 def test_oracle_pipeline_matches_reference_python_golden(oracle, small_world):
     """The oracle's restatement of the reference's Python glue against the REFERENCE'S PYTHON EXECUTING
     (tests/golden/make_pipeline_golden.py + ref_cpu_harness.py: instant_avatar.* imported on the CPU, its native

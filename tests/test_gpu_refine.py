@@ -157,6 +157,97 @@ def test_refine_fused_route_equals_dense_torch_route():
         assert _cos(g0[name], g1[name]) > 0.9999 and _rel(g0[name], g1[name]) < 5e-3, (name, _cos(g0[name], g1[name]), _rel(g0[name], g1[name]))
 
 
+@pytest.mark.parametrize("with_grad", [True, False])
+def test_version2_fused_route_equals_dense_torch_route(with_grad):
+    """ForwardDeformer `version: 2` (deformer_torch.py:68-75, confs/deformer/fast_snarf_debug.yaml): the fused route (compact
+    candidates, `ia_expand_candidate_points` + `ia_snarf_inverse_skinning[_bwd]`) against the dense route whose version-2 branch
+    is the reference's torch expression (FUSED_IMPLICIT_DIFF off: grid_sample + einsum + batched vector-matrix under autograd).
+    With the SMPL tables under optimisation the gradients must agree; without, the inverse-skinned candidates still replace the
+    roots (the reference's training branch does so whether or not tfs requires a gradient) -- and differ from version 1's."""
+    from instantavatar_amd.deformers.fast_snarf import forward_deformer as fdm
+    res = {}
+    for route in ("fused", "dense-kernel", "dense-torch", "v1"):
+        model, opt, loss_fn = _setup()
+        model.deformer.deformer.version = 1 if route == "v1" else 2
+        model.deformer.force_dense_train = route.startswith("dense")
+        old = fdm.FUSED_IMPLICIT_DIFF
+        fdm.FUSED_IMPLICIT_DIFF = route != "dense-torch"
+        try:
+            if not with_grad:
+                for p in model.SMPL_param.parameters():
+                    p.requires_grad_(False)
+            losses = training_step(model, _batch(0), opt, loss_fn, is_refine=True, draws=_draws(0, model))
+        finally:
+            fdm.FUSED_IMPLICIT_DIFF = old
+        n1 = model.net_coarse.sig_w1_size + 1024
+        mlp = dict(mlp_sigma=model.net_coarse.encoder.params.grad.detach().cpu().numpy()[:n1],
+                   mlp_color=model.net_coarse.color_net.params.grad.detach().cpu().numpy())
+        res[route] = (float(losses["loss"].detach()), {k: v for k, v in _grads(model).items() if k != "table"} if with_grad else mlp)
+    l_ref, g_ref = res["dense-torch"]
+    for route in ("fused", "dense-kernel"):
+        l, g = res[route]
+        assert abs(l - l_ref) < 1e-5 * abs(l_ref), (route, l, l_ref)
+        for name in g_ref:
+            assert _cos(g[name], g_ref[name]) > 0.9999 and _rel(g[name], g_ref[name]) < 5e-3, (route, name, _cos(g[name], g_ref[name]), _rel(g[name], g_ref[name]))
+    assert abs(res["v1"][0] - l_ref) > 1e-4 * abs(l_ref), "version 2 must not render from the roots themselves"
+
+
+def test_inverse_skinning_kernels_match_oracle(oracle):
+    """`ia_snarf_inverse_skinning` / `_bwd` (dense layout with a validity mask AND compact layout with cand_pt + device count)
+    against oracle.inverse_skinning -- itself pinned to the reference's forward and autograd
+    (test_inverse_skinning_version2_matches_reference_autograd_golden)."""
+    import ctypes as C
+    from instantavatar_amd import _lib
+    from instantavatar_amd.pipeline import make_batch
+    model, opt, loss_fn = _setup()
+    dfm = model.deformer
+    poses, tr = syn.procedural_pose_track(8)
+    dfm.prepare_deformer(make_batch(DEV, 16, poses[1], tr[1]))
+    fd = dfm.deformer
+    g = torch.Generator(device=DEV).manual_seed(21)
+    vd = fd.voxel_d[0].reshape(3, -1)
+    sel = torch.randint(0, vd.shape[1], (3000,), device=DEV, generator=g)
+    pts = (vd[:, sel].T + 0.01 * torch.randn((3000, 3), device=DEV, generator=g)).contiguous()
+    tfs = dfm.tfs.detach()
+    xc, others = fd.search(pts[None], None, tfs, eval_mode=True, want_J_inv=False)
+    valid = others["valid_ids"]
+    r = torch.randn(xc.shape, device=DEV, generator=g)
+    init = dict(lbs_voxel=fd.lbs_voxel_final[0].cpu().numpy(), offset_kernel=fd.offset_kernel.reshape(3).cpu().numpy(),
+                scale_kernel=fd.scale_kernel.reshape(3).cpu().numpy())
+    ref_v, ref_g = oracle.inverse_skinning(init, xc[0].cpu().numpy(), pts.cpu().numpy(), valid[0].cpu().numpy(), tfs[0].cpu().numpy(), r[0].cpu().numpy())
+    assert valid.float().mean() > 0.05 and np.abs(ref_g).max() > 1
+    L = _lib.lib()
+    # dense layout
+    t = tfs.clone().requires_grad_(True)
+    out = fdm_apply(t, xc, pts[None], valid, None, None, fd)
+    (out.reshape(xc.shape) * r).sum().backward()
+    assert np.abs(out.reshape(xc.shape)[0].detach().cpu().numpy() - ref_v).max() < 2e-5
+    assert np.linalg.norm(t.grad[0].cpu().numpy() - ref_g) / np.linalg.norm(ref_g) < 1e-4
+    # compact layout: the same roots through the compacting search, candidate -> point map from the kernel
+    sc = dfm.search_compact(pts)
+    n = int(sc["n_cand"])
+    cand_pt = torch.full((sc["cand_xc"].shape[0],), -1, dtype=torch.int32, device=DEV)
+    _lib.check(L.ia_expand_candidate_points(_lib.ptr(sc["pt_off"]), _lib.ptr(sc["pt_cnt"]), pts.shape[0], None, _lib.ptr(cand_pt), cand_pt.numel(), _lib.stream()))
+    want_pt = torch.repeat_interleave(torch.arange(pts.shape[0], device=DEV), sc["pt_cnt"].long())
+    order = torch.argsort(sc["pt_off"].long()[want_pt] * 16 + 0, stable=True)
+    assert n == int(valid.sum()) and int((cand_pt[:n] >= 0).sum()) == n
+    assert torch.equal(torch.sort(cand_pt[:n].long())[0], torch.sort(want_pt)[0])
+    t2 = tfs.clone().requires_grad_(True)
+    out_c = fdm_apply(t2, sc["cand_xc"], pts, None, cand_pt, sc["n_cand"], fd)
+    rc = torch.randn(out_c.shape, device=DEV, generator=g)
+    (out_c[:n] * rc[:n]).sum().backward()
+    # reference for the compact list: every candidate is a (point, root) pair; evaluate the oracle on it as a [n, 1] dense problem
+    cx, cp = sc["cand_xc"][:n].cpu().numpy(), cand_pt[:n].long().cpu().numpy()
+    v2, g2 = oracle.inverse_skinning(init, cx[:, None, :], pts.cpu().numpy()[cp], np.ones((n, 1), bool), tfs[0].cpu().numpy(), rc[:n].cpu().numpy()[:, None, :])
+    assert np.abs(out_c[:n].detach().cpu().numpy() - v2[:, 0]).max() < 2e-5 and float(out_c[n:].detach().abs().max()) == 0.0
+    assert np.linalg.norm(t2.grad[0].cpu().numpy() - g2) / np.linalg.norm(g2) < 1e-4
+
+
+def fdm_apply(*a):
+    from instantavatar_amd.deformers.fast_snarf.forward_deformer import _InverseSkinningFn
+    return _InverseSkinningFn.apply(*a)
+
+
 def test_refine_step_rendered_image_matches_golden():
     """rgb / alpha of the training render of step 0 (same rays, same jitter) within 1e-3 of the reference's."""
     model, opt, loss_fn = _setup()
