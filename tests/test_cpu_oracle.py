@@ -1419,3 +1419,31 @@ def test_pack_rgba8_oracle_is_the_reference_expression():
     assert np.array_equal(got[:, 0], (lv * np.float32(255)).astype(np.uint8)) and np.array_equal(got[:, 3], got[:, 0])
     assert (np.abs(got[:, 0].astype(int) - np.arange(256)) <= 1).all() and got[0, 1] == 0 and got[255, 2] == 255      # clamped below 0 / above 1
     assert orc.pack_rgba8(np.float32([[1.5, -0.5, 0.999999]]), np.float32([2.0]))[0].tolist() == [255, 0, 254, 255]
+
+
+def test_round5_entry_points_validate_arguments_before_any_launch():
+    """ia_pack_rgba8 / ia_snarf_inverse_skinning[_bwd] / ia_expand_candidate_points: empty inputs are no-ops, bad arguments
+    are refused with a message, nothing reaches a launch (so this runs without a GPU)."""
+    from instantavatar_amd import _lib
+    L = _lib.lib()
+    g = _lib.SnarfGrid()
+    g.D, g.H, g.W = 8, 32, 32
+    one, odd = C.c_void_p(16), C.c_void_p(18)
+    assert L.ia_pack_rgba8(None, None, 0, None, None) == 0                                               # an empty frame
+    assert L.ia_pack_rgba8(one, one, -1, one, None) != 0 and b"R < 0" in L.ia_last_error()
+    assert L.ia_pack_rgba8(one, None, 4, one, None) != 0 and b"null pointer" in L.ia_last_error()
+    assert L.ia_pack_rgba8(one, one, 4, odd, None) != 0 and b"aligned" in L.ia_last_error()             # one 32-bit store per ray
+    assert L.ia_snarf_inverse_skinning(None, None, None, 13, None, 0, None, None, 1, C.byref(g), None, None, None) == 0
+    assert L.ia_snarf_inverse_skinning(one, one, None, 13, None, -1, None, one, 1, C.byref(g), one, one, None) != 0 and b"n < 0" in L.ia_last_error()
+    assert L.ia_snarf_inverse_skinning(one, one, None, 0, None, 8, None, one, 1, C.byref(g), one, one, None) != 0       # neither cand_pt nor n_init
+    assert L.ia_snarf_inverse_skinning(one, None, None, 13, None, 8, None, one, 1, C.byref(g), one, one, None) != 0 and b"null pointer" in L.ia_last_error()
+    big = 1 << 20
+    assert L.ia_snarf_inverse_skinning_bwd(None, None, None, 13, None, None, 0, None, None, 1, C.byref(g), None, None, None, None, 0, None) == 0
+    assert L.ia_snarf_inverse_skinning_bwd(one, one, None, 13, None, one, 8, None, one, 1, C.byref(g), one, one, None, one, big, None) != 0   # no mask, no count
+    assert L.ia_snarf_inverse_skinning_bwd(one, one, None, 13, one, one, 8, None, one, 1, C.byref(g), one, one, None, one, 8, None) != 0
+    assert b"workspace" in L.ia_last_error()
+    assert L.ia_snarf_inverse_skinning_bwd(one, None, None, 13, one, one, 8, None, one, 1, C.byref(g), one, one, None, one, big, None) != 0
+    assert b"version-2" in L.ia_last_error()
+    assert L.ia_expand_candidate_points(None, None, 0, None, None, 0, None) == 0
+    assert L.ia_expand_candidate_points(one, None, 4, None, one, 8, None) != 0 and b"null pointer" in L.ia_last_error()
+    assert L.ia_expand_candidate_points(one, one, -1, None, one, 8, None) != 0
