@@ -1447,3 +1447,26 @@ def test_round5_entry_points_validate_arguments_before_any_launch():
     assert L.ia_expand_candidate_points(None, None, 0, None, None, 0, None) == 0
     assert L.ia_expand_candidate_points(one, None, 4, None, one, 8, None) != 0 and b"null pointer" in L.ia_last_error()
     assert L.ia_expand_candidate_points(one, one, -1, None, one, 8, None) != 0
+
+
+def test_search_kernel_isa_has_no_dpp_read_after_valu_write_hazard():
+    """k_search issues `v_add_u32_dpp` from inline asm, which the compiler's hazard recogniser cannot see into; the
+    guard (`s_nop 1` and the eight DPP adds as ONE asm statement) is structural, and this checks the result: in the gfx950
+    assembly of ia_search.hip no DPP instruction reads a VGPR that a VALU instruction wrote within the two preceding wait
+    states (tools/analyse_search_isa.py: dpp_hazards, which is first shown to catch a planted hazard)."""
+    import importlib.util
+    from instantavatar_amd import build
+    if not build.have_compiler():
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("analyse_search_isa", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "analyse_search_isa.py"))
+    A = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(A)
+    dpp = "  v_add_u32_dpp v7, v5, v3 quad_perm:[0,0,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    assert len(A.dpp_hazards(["  v_add_u32_e32 v5, v1, v2", dpp])) == 1
+    assert len(A.dpp_hazards(["  v_add_u32_e32 v5, v1, v2", "  v_mov_b32_e32 v9, v1", dpp])) == 1          # one wait state is not enough
+    assert A.dpp_hazards(["  v_add_u32_e32 v5, v1, v2", "  s_nop 1", dpp]) == []
+    assert A.dpp_hazards(["  v_add_u32_e32 v6, v1, v2", dpp]) == []                                          # another register
+    isa = A.device_isa()
+    n_dpp = sum(1 for l in isa if "_dpp" in l or "quad_perm:" in l)
+    assert n_dpp >= 72, n_dpp                                                                                 # 3 kernels x 24 DPP adds at least
+    assert A.dpp_hazards(isa) == []

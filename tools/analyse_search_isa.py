@@ -38,6 +38,70 @@ CLASSES = [
 ]
 
 
+def device_isa(flags=()):
+    """the gfx950 assembly of ia_search.hip as a list of lines (the shipped per-unit flags applied)"""
+    sys.path.insert(0, ROOT)
+    from instantavatar_amd import build
+    src = os.path.join(ROOT, "instantavatar_amd", "csrc", "ia_search.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        cmd = [build.HIPCC] + [f for f in build.FLAGS if f != "-fPIC"] + list(build.TU_FLAGS.get("ia_search.hip", [])) + list(flags) + [
+            "-x", "hip", "--cuda-device-only", "-S", src, "-o", out]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return open(out).read().splitlines()
+
+
+def dpp_hazards(text):
+    """a DPP read needs two wait states after a VALU write of its source register, and inline asm is opaque to the
+    compiler's hazard recogniser.  Walks every instruction stream of the file: for each `*_dpp` instruction (or one carrying a
+    quad_perm / row_* modifier) the VGPRs it READS through DPP (src0) must not have been written by a VALU instruction in the
+    two preceding wait states (a VALU instruction = 1, `s_nop N` = N + 1; labels and branches end the look-back conservatively:
+    nothing is assumed across them, a hazard INSIDE a straight-line run is what inline asm can create).
+    Returns a list of (line number, instruction, offending earlier instruction)."""
+    bad = []
+    hist = []          # [(wait states this instruction provides, set of vgprs it writes, text)] of the current straight-line run
+    reg = re.compile(r"v(\d+)|v\[(\d+):(\d+)\]")
+
+    def regs(tok):
+        m = reg.fullmatch(tok.strip().rstrip(","))
+        if not m:
+            return set()
+        if m.group(1) is not None:
+            return {int(m.group(1))}
+        return set(range(int(m.group(2)), int(m.group(3)) + 1))
+    for ln, l in enumerate(text, 1):
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        if t.endswith(":") or t.startswith("s_cbranch") or t.startswith("s_branch") or t.startswith("s_setpc") or t.startswith("s_endpgm"):
+            hist = []
+            continue
+        m = re.match(r"^([a-z][a-z0-9_]+)\s*(.*)$", t)
+        if not m:
+            continue
+        op, rest = m.group(1), m.group(2).split(";")[0]
+        ops = [o for o in re.split(r",\s*|\s+", rest) if o]
+        is_dpp = op.endswith("_dpp") or " quad_perm:" in l or " row_shr:" in l or " row_shl:" in l or " row_bcast" in l or " row_mirror" in l
+        if is_dpp and len(ops) >= 2:
+            src = regs(ops[1])                                     # vdst, src0 (the DPP-permuted operand), ...
+            need = 2
+            for ws, wr, txt in reversed(hist):
+                if need <= 0:
+                    break
+                if wr & src:
+                    bad.append((ln, t, txt))
+                    break
+                need -= ws
+        if op == "s_nop":
+            hist.append((int(ops[0], 0) + 1 if ops else 1, set(), t))
+        elif op.startswith("v_"):
+            hist.append((1, regs(ops[0]) if ops else set(), t))
+        elif op.startswith("s_") or op.startswith("ds_") or op.startswith("global_") or op.startswith("buffer_") or op.startswith("scratch_") or op.startswith("flat_"):
+            hist.append((1, set(), t))                              # any other instruction is at least one wait state
+        hist = hist[-4:]
+    return bad
+
+
 def main(flags):
     src = os.path.join(ROOT, "instantavatar_amd", "csrc", "ia_search.hip")
     with tempfile.TemporaryDirectory() as d:
@@ -81,5 +145,11 @@ def main(flags):
     print("  %-68s %4d" % ("== VALU total", valu))
 
 
+if __name__ == "__main__" and "--dpp-hazards" in sys.argv:
+    bad = dpp_hazards(device_isa([a for a in sys.argv[1:] if a != "--dpp-hazards"]))
+    print("DPP read-after-VALU-write hazards in ia_search.hip's device code: %d" % len(bad))
+    for b in bad[:20]:
+        print("  line %d: %s   <-   %s" % b)
+    sys.exit(1 if bad else 0)
 if __name__ == "__main__":
     main(sys.argv[1:])
