@@ -63,11 +63,15 @@ class SMPLDeformer():
         out = self.body_model(betas=smpl_params["betas"], body_pose=smpl_params["body_pose"],
                               global_orient=smpl_params["global_orient"], transl=smpl_params["transl"])
         s2w = out.A[:, 0]
-        w2s = torch.inverse(s2w)
-        T_inv = torch.inverse(out.T.float()).clone() @ s2w[:, None]
+        # (smpl_deformer.py:69-70 uses torch.inverse twice: the LU route reads its status back to the host and, for the 6 890
+        # per-vertex transforms, is a chain of library kernels; both matrices are affine -- closed form, differentiable)
+        from .snarf_deformer import affine_inverse
+        from .smplx import small_matmul
+        w2s = affine_inverse(s2w)
+        T_inv = small_matmul(affine_inverse(out.T.float()), s2w[:, None])
         T_inv[..., :3, 3] += self.pose_offset_t - out.pose_offsets   # remove & re-apply the blend shapes
         T_inv[..., :3, 3] += self.shape_offset_t - out.shape_offsets
-        self.T_inv = (self.T_template @ T_inv).float().contiguous()
+        self.T_inv = small_matmul(self.T_template, T_inv).float().contiguous()
         self.vertices = ((out.vertices @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]).float().contiguous()
         self.w2s = w2s
 
@@ -106,9 +110,11 @@ class SMPLDeformer():
             # SMPL refinement with this deformer (SNARF_NGP_refine + deformer=smpl): the reference's pts_cano
             # (smpl_deformer.py:100-107) is differentiable w.r.t. the per-vertex transforms; the nearest-vertex
             # index comes from the kernel, the affine map is re-applied in torch so that autograd reaches T_inv
-            T = self.T_inv[0][idx.long()]
+            # (index_select: its backward is an index_add, not the sort-based indexing backward of T_inv[0][idx] -- 250 us a call;
+            # the 3 x 3 products as multiply + sum: a batched GEMM over ~10^5 tiny matrices is 260 us forward and twice that back)
+            T = torch.index_select(self.T_inv[0], 0, idx.long())
             xh = pts.reshape(-1, 3).float()
-            cano = (T[:, :3, :3] @ xh[:, :, None])[:, :, 0] + T[:, :3, 3]
+            cano = (T[:, :3, :3] * xh[:, None, :]).sum(-1) + T[:, :3, 3]
         return cano, valid.bool()
 
     def _workspace(self, nbytes, device):

@@ -43,6 +43,13 @@ def batch_rodrigues(rot_vecs):
     return ident + sin * K + (1 - cos) * torch.bmm(K, K)
 
 
+def small_matmul(a, b):
+    """a [..., m, k] @ b [..., k, n] for tiny m, k, n (3 or 4) as one multiply and one sum instead of a library GEMM: on this
+    stack a 4 x 4 `torch.matmul` is a ~40 us rocBLAS launch (forward) plus two more in the backward pass, and the joint chain
+    issues 23 of them per frame one after the other (tools/prof_fit.sh: 150 such launches = 6 ms of a 14 ms fit step)."""
+    return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
+
+
 def batch_rigid_transform(rot_mats, joints, parents, parents_list=None):
     """lbs.py:345-401"""
     joints = joints.unsqueeze(-1)
@@ -57,11 +64,11 @@ def batch_rigid_transform(rot_mats, joints, parents, parents_list=None):
     par = parents_list if parents_list is not None else [int(p) for p in parents.tolist()]
     chain = [tm[:, 0]]
     for i in range(1, N):
-        chain.append(torch.matmul(chain[par[i]], tm[:, i]))
+        chain.append(small_matmul(chain[par[i]], tm[:, i]))
     transforms = torch.stack(chain, dim=1)
     posed = transforms[:, :, :3, 3]
     jh = torch.nn.functional.pad(joints, [0, 0, 0, 1])
-    rel_t = transforms - torch.nn.functional.pad(torch.matmul(transforms, jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    rel_t = transforms - torch.nn.functional.pad(small_matmul(transforms, jh), [3, 0, 0, 0, 0, 0, 0, 0])
     return posed, rel_t
 
 
@@ -73,7 +80,9 @@ class SMPL(nn.Module):
         super().__init__()
         if data is None:
             data = self._load(model_path, gender)
-        f32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
+        # (C-contiguous copies: the pickle layout arrives transposed / Fortran-ordered, and the reductions below sum in memory
+        # order -- the same data must give the same bits whichever file it came from)
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32))
         self.register_buffer("v_template", f32(data["v_template"]))
         self.register_buffer("shapedirs", f32(data["shapedirs"])[..., :10])
         posedirs = np.asarray(data["posedirs"])
@@ -143,8 +152,8 @@ class SMPL(nn.Module):
         if global_orient is None:
             global_orient = torch.zeros(B, 3, dtype=betas.dtype, device=betas.device)
         full_pose = torch.cat([global_orient, body_pose], dim=1)
-        v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)
-        J = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
+        v_shaped = self.v_template + (betas[:, None, None, :] * self.shapedirs[None]).sum(-1)          # einsum("bl,mkl->bmk")
+        J = (self.J_regressor[None, :, :, None] * v_shaped[:, None, :, :]).sum(2)                       # einsum("bik,ji->bjk")
         rot = batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
         Jt, A = batch_rigid_transform(rot, J, self.parents, self.parents_list)
         verts = None
@@ -153,13 +162,16 @@ class SMPL(nn.Module):
         if return_verts:
             ident = torch.eye(3, dtype=betas.dtype, device=betas.device)
             pose_feature = (rot[:, 1:] - ident).view(B, -1)
-            pose_offsets = torch.matmul(pose_feature, self.posedirs).view(B, -1, 3)      # lbs.py:211-222
+            # lbs.py:211-222: [B,207] x [207, V*3] -- a GEMV the GEMM library runs in ~0.9 ms (and twice more backwards); the same
+            # sum as a broadcast multiply + reduction is two bandwidth-bound launches over 17 MB
+            pose_offsets = (pose_feature[:, :, None] * self.posedirs[None]).sum(1).view(B, -1, 3)
             shape_offsets = v_shaped - self.v_template                                    # lbs.py:185-187
             v_posed = v_shaped + pose_offsets
-            W = self.lbs_weights.unsqueeze(0).expand(B, -1, -1)
-            T = torch.matmul(W, A.view(B, 24, 16)).view(B, -1, 4, 4)
+            # per-vertex blend T = W A ([V,24] x [24,16]) and v' = T v: skinny shapes the GEMM library serves badly (638 us
+            # per call here); the same sums as one multiply + one reduction each
+            T = (self.lbs_weights[None, :, :, None] * A.reshape(B, 1, 24, 16)).sum(2).view(B, -1, 4, 4)
             vh = torch.cat([v_posed, torch.ones_like(v_posed[..., :1])], dim=2)
-            verts = torch.matmul(T, vh.unsqueeze(-1))[:, :, :3, 0]
+            verts = (T[:, :, :3, :] * vh[:, :, None, :]).sum(-1)
         if transl is not None:  # body_models.py:353-360
             Jt = Jt + transl.unsqueeze(1)
             A = A.clone()

@@ -9,5 +9,5 @@ tot=sum(float(r["TotalDurationNs"]) for r in rows)
 n=${1:-100}
 print("total GPU kernel time %.1f ms over %d steps (+setup) -> %.2f ms/step; launches per step %.0f" % (tot/1e6, n, tot/1e6/n, sum(int(r["Calls"]) for r in rows)/n))
 for r in rows[:18]:
-    print("%-70s calls %6s avg %9.1f us total %8.1f ms" % (r["Name"].split("(")[0][-70:], r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
+    print("%-110s calls %6s avg %9.1f us total %8.1f ms" % (r["Name"][:110], r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
 PY
