@@ -61,7 +61,7 @@ class SMPLDeformer():
         if not self.initialized:
             self.initialize(smpl_params["betas"], device)  # the reference re-initialises every frame (betas may change)
         out = self.body_model(betas=smpl_params["betas"], body_pose=smpl_params["body_pose"],
-                              global_orient=smpl_params["global_orient"], transl=smpl_params["transl"])
+                              global_orient=smpl_params["global_orient"], transl=smpl_params["transl"], small_ops=True)
         s2w = out.A[:, 0]
         # (smpl_deformer.py:69-70 uses torch.inverse twice: the LU route reads its status back to the host and, for the 6 890
         # per-vertex transforms, is a chain of library kernels; both matrices are affine -- closed form, differentiable)

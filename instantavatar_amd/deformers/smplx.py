@@ -50,8 +50,9 @@ def small_matmul(a, b):
     return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
 
 
-def batch_rigid_transform(rot_mats, joints, parents, parents_list=None):
-    """lbs.py:345-401"""
+def batch_rigid_transform(rot_mats, joints, parents, parents_list=None, small_ops=False):
+    """lbs.py:345-401.  small_ops: the 4 x 4 products as multiply + sum (`small_matmul`) instead of library GEMMs"""
+    mm = small_matmul if small_ops else torch.matmul
     joints = joints.unsqueeze(-1)
     rel = joints.clone()
     rel[:, 1:] -= joints[:, parents[1:]]
@@ -64,11 +65,11 @@ def batch_rigid_transform(rot_mats, joints, parents, parents_list=None):
     par = parents_list if parents_list is not None else [int(p) for p in parents.tolist()]
     chain = [tm[:, 0]]
     for i in range(1, N):
-        chain.append(small_matmul(chain[par[i]], tm[:, i]))
+        chain.append(mm(chain[par[i]], tm[:, i]))
     transforms = torch.stack(chain, dim=1)
     posed = transforms[:, :, :3, 3]
     jh = torch.nn.functional.pad(joints, [0, 0, 0, 1])
-    rel_t = transforms - torch.nn.functional.pad(small_matmul(transforms, jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    rel_t = transforms - torch.nn.functional.pad(mm(transforms, jh), [3, 0, 0, 0, 0, 0, 0, 0])
     return posed, rel_t
 
 
@@ -146,32 +147,45 @@ class SMPL(nn.Module):
         v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)[0]
         return torch.matmul(self.J_regressor, v_shaped)  # [24,3]
 
-    def forward(self, betas, body_pose, global_orient=None, transl=None, return_verts=True):
-        """body_models.py:289-372 + lbs.py:152-250 (torch ops; used at init)."""
+    def forward(self, betas, body_pose, global_orient=None, transl=None, return_verts=True, small_ops=False):
+        """body_models.py:289-372 + lbs.py:152-250 (torch ops).
+        small_ops=False (initialisation: the rest pose whose vertices feed the one-time KNN voxelisation; same library calls as
+        the reference, results as in rounds 1-4).  small_ops=True (the per-step caller, SMPLDeformer.prepare_deformer under
+        autograd): every tiny or skinny GEMM as a broadcast multiply + sum -- a 4 x 4 `matmul` is a ~40 us rocBLAS launch here
+        and the [1,207] x [207, 20 670] pose blend 0.9 ms, forward and twice backward (tools/prof_fit.sh); results differ from
+        the library's by summation order (ulps)."""
         B = max(betas.shape[0], body_pose.shape[0])
         if global_orient is None:
             global_orient = torch.zeros(B, 3, dtype=betas.dtype, device=betas.device)
         full_pose = torch.cat([global_orient, body_pose], dim=1)
-        v_shaped = self.v_template + (betas[:, None, None, :] * self.shapedirs[None]).sum(-1)          # einsum("bl,mkl->bmk")
-        J = (self.J_regressor[None, :, :, None] * v_shaped[:, None, :, :]).sum(2)                       # einsum("bik,ji->bjk")
+        if small_ops:
+            v_shaped = self.v_template + (betas[:, None, None, :] * self.shapedirs[None]).sum(-1)      # einsum("bl,mkl->bmk")
+            J = (self.J_regressor[None, :, :, None] * v_shaped[:, None, :, :]).sum(2)                   # einsum("bik,ji->bjk")
+        else:
+            v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)
+            J = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
         rot = batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
-        Jt, A = batch_rigid_transform(rot, J, self.parents, self.parents_list)
+        Jt, A = batch_rigid_transform(rot, J, self.parents, self.parents_list, small_ops=small_ops)
         verts = None
         T = None
         shape_offsets = pose_offsets = None
         if return_verts:
             ident = torch.eye(3, dtype=betas.dtype, device=betas.device)
             pose_feature = (rot[:, 1:] - ident).view(B, -1)
-            # lbs.py:211-222: [B,207] x [207, V*3] -- a GEMV the GEMM library runs in ~0.9 ms (and twice more backwards); the same
-            # sum as a broadcast multiply + reduction is two bandwidth-bound launches over 17 MB
-            pose_offsets = (pose_feature[:, :, None] * self.posedirs[None]).sum(1).view(B, -1, 3)
+            if small_ops:
+                pose_offsets = (pose_feature[:, :, None] * self.posedirs[None]).sum(1).view(B, -1, 3)   # lbs.py:211-222
+            else:
+                pose_offsets = torch.matmul(pose_feature, self.posedirs).view(B, -1, 3)
             shape_offsets = v_shaped - self.v_template                                    # lbs.py:185-187
             v_posed = v_shaped + pose_offsets
-            # per-vertex blend T = W A ([V,24] x [24,16]) and v' = T v: skinny shapes the GEMM library serves badly (638 us
-            # per call here); the same sums as one multiply + one reduction each
-            T = (self.lbs_weights[None, :, :, None] * A.reshape(B, 1, 24, 16)).sum(2).view(B, -1, 4, 4)
             vh = torch.cat([v_posed, torch.ones_like(v_posed[..., :1])], dim=2)
-            verts = (T[:, :, :3, :] * vh[:, :, None, :]).sum(-1)
+            if small_ops:   # per-vertex blend T = W A ([V,24] x [24,16]) and v' = T v as multiply + reduction
+                T = (self.lbs_weights[None, :, :, None] * A.reshape(B, 1, 24, 16)).sum(2).view(B, -1, 4, 4)
+                verts = (T[:, :, :3, :] * vh[:, :, None, :]).sum(-1)
+            else:
+                W = self.lbs_weights.unsqueeze(0).expand(B, -1, -1)
+                T = torch.matmul(W, A.view(B, 24, 16)).view(B, -1, 4, 4)
+                verts = torch.matmul(T, vh.unsqueeze(-1))[:, :, :3, 0]
         if transl is not None:  # body_models.py:353-360
             Jt = Jt + transl.unsqueeze(1)
             A = A.clone()

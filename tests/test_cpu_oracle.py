@@ -166,12 +166,13 @@ def test_lbs_product_torch_matches_reference_golden():
                                J_regressor=g["J_regressor"], lbs_weights=g["lbs_weights"], parents=g["parents"]))
     for i in range(int(g["n_cases"])):
         pose = torch.as_tensor(g["pose%d" % i])
-        out = smpl(torch.as_tensor(g["betas%d" % i]), pose[:, 3:], pose[:, :3], torch.as_tensor(g["transl%d" % i]))
-        assert (out.A - torch.as_tensor(g["A%d" % i])).abs().max() < 2e-5
-        assert (out.vertices - torch.as_tensor(g["verts%d" % i])).abs().max() < 2e-5
-        assert (out.T - torch.as_tensor(g["T%d" % i])).abs().max() < 2e-5
-        assert (out.shape_offsets - torch.as_tensor(g["shape_offsets%d" % i])).abs().max() < 1e-6
-        assert (out.pose_offsets - torch.as_tensor(g["pose_offsets%d" % i])).abs().max() < 1e-6
+        for small_ops in (False, True):     # library GEMMs (initialisation) / broadcast multiply + sum (the per-step SMPLDeformer path)
+            out = smpl(torch.as_tensor(g["betas%d" % i]), pose[:, 3:], pose[:, :3], torch.as_tensor(g["transl%d" % i]), small_ops=small_ops)
+            assert (out.A - torch.as_tensor(g["A%d" % i])).abs().max() < 2e-5
+            assert (out.vertices - torch.as_tensor(g["verts%d" % i])).abs().max() < 2e-5
+            assert (out.T - torch.as_tensor(g["T%d" % i])).abs().max() < 2e-5
+            assert (out.shape_offsets - torch.as_tensor(g["shape_offsets%d" % i])).abs().max() < 1e-6
+            assert (out.pose_offsets - torch.as_tensor(g["pose_offsets%d" % i])).abs().max() < 1e-6
 
 
 # ---------------------------------------------------------------- oracle self-consistency
