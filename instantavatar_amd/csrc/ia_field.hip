@@ -303,6 +303,32 @@ __device__ __forceinline__ void encode_all(const FieldDev &F, const uint32_t *__
 #define IA_ENC_MAX_WG_PER_XCD 256  // 32 CUs x 8 resident workgroups
 #endif
 
+// Cache policy of a table gather (MI355X_MICROARCH.md: `nt` / `sc1` loads bypass the CU's vector L1 and are served by the
+// XCD's L2 -- no 128-byte line fill into the TCP for an entry nobody on this CU will touch again): 0 = default
+// (L1-allocating), 1 = nt, 2 = sc1 (relaxed agent-scope load).  Values are identical whatever the policy.
+template <int POL>
+__device__ __forceinline__ uint32_t gather32(const uint32_t *p) {
+  if (POL == 1) return __builtin_nontemporal_load(p);
+  if (POL == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <int POL>
+__device__ __forceinline__ uint2 gather64(const uint32_t *p) {  // p 8-byte aligned
+  union { unsigned long long q; uint2 u; } c;
+  const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+  if (POL == 1) c.q = __builtin_nontemporal_load(q);
+  else if (POL == 2) c.q = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else c.q = *q;
+  return c.u;
+}
+#ifndef IA_ENC_POL_H_LO
+#define IA_ENC_POL_H_LO 0  // hashed levels 4..7  (XCD-sharded encoder)
+#endif
+#ifndef IA_ENC_POL_H_HI
+#define IA_ENC_POL_H_HI 0  // hashed levels 8..15 (XCD-sharded encoder)
+#endif
+
+template <int POL>
 __device__ __forceinline__ void hashed_pair_loads(const uint32_t *__restrict__ tab, float scale, uint32_t mask,
                                                   const float xn[3], float w[3], uint32_t px[4], uint32_t py[4],
                                                   uint32_t ext[4], uint32_t &meta) {
@@ -321,12 +347,12 @@ __device__ __forceinline__ void hashed_pair_loads(const uint32_t *__restrict__ t
     const uint32_t cy = g[1] + (pr & 1), cz = g[2] + (pr >> 1);
     const uint32_t hsh = (cy * 2654435761u) ^ (cz * 805459861u);
     const uint32_t i0 = (g[0] ^ hsh) & mask;
-    const uint2 pair = *reinterpret_cast<const uint2 *>(tab + (i0 & ~1u));
+    const uint2 pair = gather64<POL>(tab + (i0 & ~1u));
     px[pr] = pair.x;
     py[pr] = pair.y;
     meta |= (i0 & 1u) << pr;
     ext[pr] = 0u;
-    if (odd) ext[pr] = tab[((g[0] + 1) ^ hsh) & mask];
+    if (odd) ext[pr] = gather32<POL>(tab + (((g[0] + 1) ^ hsh) & mask));
   }
 }
 
@@ -385,8 +411,13 @@ __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__re
       const float scale = F.lv.scale[lev_h];
       float w[IA_ENC_S][3];
       uint32_t px[IA_ENC_S][4], py[IA_ENC_S][4], ext[IA_ENC_S][4], meta[IA_ENC_S];
+      if (IA_ENC_POL_H_LO != IA_ENC_POL_H_HI && lev_h - ND < 4) {  // (wave-uniform)
 #pragma unroll
-      for (int k = 0; k < IA_ENC_S; k++) hashed_pair_loads(tab, scale, F.hash_size - 1, xn[k], w[k], px[k], py[k], ext[k], meta[k]);
+        for (int k = 0; k < IA_ENC_S; k++) hashed_pair_loads<IA_ENC_POL_H_LO>(tab, scale, F.hash_size - 1, xn[k], w[k], px[k], py[k], ext[k], meta[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < IA_ENC_S; k++) hashed_pair_loads<IA_ENC_POL_H_HI>(tab, scale, F.hash_size - 1, xn[k], w[k], px[k], py[k], ext[k], meta[k]);
+      }
       uint32_t *out = planes + (size_t)lev_h * stride;
 #pragma unroll
       for (int k = 0; k < IA_ENC_S; k++) {

@@ -928,11 +928,11 @@ __global__ __launch_bounds__(256) void k_probe_max(const float *__restrict__ can
                                                    const float *__restrict__ cand_sigma,
                                                    const int32_t *__restrict__ pt_off,
                                                    const uint8_t *__restrict__ pt_cnt, int n, int G, int iters, int n_init,
-                                                   float *__restrict__ density) {
+                                                   float *__restrict__ density, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const int i = ia_probe_cell(c, G);
-  float m = 0.f;
+  float m = accumulate ? density[i] : 0.f;   // accumulate: one probe set per launch (the small-workspace route)
   for (int it = 0; it < iters; it++) {
     const size_t p = (size_t)c * iters + it;  // cell-major probe order (k_probe_points)
     float sg, col[3];
@@ -967,7 +967,7 @@ extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const
     hipLaunchKernelGGL(k_probe_points, dim3(ia_div_up(n_all, 256)), blk, 0, s, jitter, G, iters, aabb, pts, q.n_cand);
     rc = query_impl(pts, n_all, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, G, iters, n_init, density);
+    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, G, iters, n_init, density, 0);
     IA_LAUNCH_CHECK("density_grid_init");
     return ia_occupancy_from_density(density, G, occ_bits, occ_bool, occ_ws, ia_occupancy_workspace_bytes(G), s);
   }
@@ -980,8 +980,8 @@ extern "C" int ia_density_grid_init(const float *jitter, int iters, int G, const
     hipLaunchKernelGGL(k_probe_points, grd, blk, 0, s, jitter + (size_t)it * n * 3, G, 1, aabb, pts, q.n_cand);
     rc = query_impl(pts, n, nullptr, voxel_J, tfs, bone_ids, n_init, grid, F, q, s, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_candidate_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n,
-                       (const int32_t *)nullptr, n_init, 0.f, 1, (float *)nullptr, (float *)nullptr, density);
+    // (point p of k_probe_points(iters = 1) is cell ia_probe_cell(p), not cell p: the maximum must land there -- ADVICE r05)
+    hipLaunchKernelGGL(k_probe_max, grd, blk, 0, s, q.cand_rgb, q.cand_sigma, q.pt_off, q.pt_cnt, n, G, 1, n_init, density, 1);
   }
   IA_LAUNCH_CHECK("density_grid_init");
   return ia_occupancy_from_density(density, G, occ_bits, occ_bool, occ_ws, ia_occupancy_workspace_bytes(G), s);

@@ -76,6 +76,9 @@ template <int PERM> __device__ __forceinline__ float quad_perm(float v) {
 // The offset broadcast and the row-offset add are ONE v_add_u32_dpp (inline asm: left to itself the compiler emits
 // v_mov_b32_dpp + v_add_u32, because it sinks the add to the predicated loads).  The two wait states a DPP read needs after a
 // VALU write of its source are the s_nop: inline asm is opaque to the hazard recogniser.
+#ifndef IA_SEARCH_POL
+#define IA_SEARCH_POL 0
+#endif
 template <int R>
 __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const FetchPlan &p, float4 *__restrict__ s_quad_k) {
   constexpr int PERM = R == 0 ? 0x40 : (R == 1 ? 0xA5 : 0xFE);
@@ -102,7 +105,15 @@ __device__ __forceinline__ void fetch_round3(const char *__restrict__ vJb, const
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 v[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)off[c]);
+    for (int c = 0; c < 8; c++) {
+#if IA_SEARCH_POL == 1   // nt: the record bypasses the CU's vector L1 (A/B switch, profiles/r06_ab_search_policy.txt)
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(vJb + (size_t)off[c]));
+      v[c] = make_float4(t.x, t.y, t.z, t.w);
+#else
+      v[c] = *reinterpret_cast<const float4 *>(vJb + (size_t)off[c]);
+#endif
+    }
     f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) {

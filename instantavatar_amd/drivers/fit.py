@@ -84,23 +84,28 @@ def export_params(model, out_dir):
     return path
 
 
-def synthetic_frames(device, res=128, n_frames=4, noise=0.02, seed=0, patch=32):
-    """Frames rendered from the synthetic avatar; the SMPL parameters handed to the fit stage are perturbed."""
-    teacher, body, _ = build_synthetic_model(device, resolution=64)
+def synthetic_frames(device, res=128, n_frames=4, noise=0.02, seed=0, patch=32, blendshapes=False):
+    """Frames rendered from the synthetic avatar; the SMPL parameters handed to the fit stage are perturbed.
+    blendshapes: a subject with non-zero shape / pose directions and shape coefficients synthetic.BLEND_BETAS (the betas row
+    handed to the fit stage is perturbed too: the stage optimises it, DNeRF.py:121-123)."""
+    betas = synthetic.BLEND_BETAS if blendshapes else np.zeros(10, np.float32)
+    teacher, body, _ = build_synthetic_model(device, resolution=64, blendshapes=blendshapes, betas=betas)
     poses, tr = synthetic.procedural_pose_track(max(n_frames, 8))
     imgs, masks = [], []
     with torch.no_grad():
         for f in range(n_frames):
-            rgb, _, alpha, _ = teacher.render_image_fast(make_batch(device, res, poses[f], tr[f]), (res, res))
+            rgb, _, alpha, _ = teacher.render_image_fast(make_batch(device, res, poses[f], tr[f], betas=betas), (res, res))
             imgs.append((rgb[0].clamp(0, 1) * 255).round().to(torch.uint8))
             masks.append((alpha[0] > 0.5).float())
     rng = np.random.RandomState(seed)
     K = np.array([[2000.0 * res / 1080, 0, res / 2], [0, 2000.0 * res / 1080, res / 2], [0, 0, 1]])
-    true = dict(betas=np.zeros((1, 10), np.float32), body_pose=poses[:n_frames, 3:].copy(), global_orient=poses[:n_frames, :3].copy(),
+    true = dict(betas=betas.reshape(1, 10).astype(np.float32).copy(), body_pose=poses[:n_frames, 3:].copy(), global_orient=poses[:n_frames, :3].copy(),
                 transl=tr[:n_frames].copy())
     init = {k: v.copy() for k, v in true.items()}
     init["body_pose"] += rng.randn(*init["body_pose"].shape).astype(np.float32) * noise
     init["transl"] += rng.randn(*init["transl"].shape).astype(np.float32) * noise * 0.5
+    if blendshapes:
+        init["betas"] += rng.randn(1, 10).astype(np.float32) * 0.1
     frames = DeviceFrames(torch.stack(imgs), torch.stack(masks), K, np.eye(4), init, PatchSampler(num_patch=4, patch_size=patch, ratio_mask=1))
     return frames, SMPL.from_dict(body).to(device), true
 

@@ -94,6 +94,8 @@ class DensityGrid(torch.nn.Module):
         self.density_field = out8.bool()
 
     # -- test-time grid (per frame) ----------------------------------------------
+    batched_probes = True
+
     @torch.no_grad()
     def initialize(self, deformer, net, iters=5, jitter=None):
         """density_grid.py:95-110.  `jitter` ([iters,G^3,3] in [0,1)) may be injected
@@ -112,9 +114,14 @@ class DensityGrid(torch.nn.Module):
         if isinstance(deformer, SNARFDeformer) and isinstance(net, NeRFNGPNet):
             L = _lib.lib()
             k = len(deformer.deformer.init_bones)
-            # all probe sets in one launch when the sizes allow (288 GB of HBM: ~1 GB of scratch)
-            ws = self._workspace(max(L.ia_density_init_workspace_bytes(G, k),
-                                     L.ia_density_init_workspace_bytes_batched(G, k, iters)))
+            # all probe sets in one launch when the sizes allow (288 GB of HBM: ~1 GB of scratch); `batched_probes = False`
+            # hands over the small workspace of `ia_density_init_workspace_bytes` only: one probe set per launch, same result
+            need = L.ia_density_init_workspace_bytes(G, k)
+            if self.batched_probes:
+                need = max(need, L.ia_density_init_workspace_bytes_batched(G, k, iters))
+                ws = self._workspace(need)
+            else:
+                ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
             density = torch.empty((G, G, G), device=dev)
             out8 = torch.empty((G, G, G), dtype=torch.uint8, device=dev)
             tfs = deformer.tfs.detach().float().contiguous()

@@ -215,14 +215,19 @@ class PipelinedRenderer:
 
 
 def build_synthetic_model(device, resolution=128, n_levels=16, max_samples=256, max_batch=291600, seed=42,
-                          cano_pose="A_pose"):
+                          cano_pose="A_pose", blendshapes=False, betas=None, version=None):
     """Synthetic body + field wired into the three plugins.
-    Returns (model, body dict, field dict)."""
-    body = synthetic.make_body(seed)
+    Returns (model, body dict, field dict).  blendshapes / betas: a body with non-zero shape and pose directions and a dense
+    joint regressor (`synthetic.make_body(blendshapes=True)`) initialised with these shape coefficients -- what a real SMPL
+    pickle + a dataset's betas are; the default is the zero-blendshape body of SURVEY.md 8d."""
+    body = synthetic.make_body(seed, blendshapes=blendshapes)
     smpl = SMPL.from_dict(body).to(device)
     opt = dict(softmax_mode="hierarchical", resolution=resolution, cano_pose=cano_pose, precision=32)
+    if version is not None:
+        opt["version"] = version
     deformer = SNARFDeformer(None, "neutral", opt, body_model=smpl)
-    betas = torch.zeros(1, 10, device=device)
+    betas = torch.zeros(1, 10, device=device) if betas is None else torch.as_tensor(
+        np.asarray(betas, np.float32).reshape(1, 10), device=device)
     deformer.initialize(betas, device)
     deformer.initialized = True
     # canonical joints for the synthetic density (posed with the canonical pose)

@@ -80,8 +80,27 @@ def _frame(v):
     return u, np.cross(v, u)
 
 
-def make_body(seed=42):
-    """Synthetic SMPL-like body model (dict of numpy arrays, fp32)."""
+#: the shape coefficients the blend-shape test world is initialised with (tests/world.py:build_blend, the *_blend goldens)
+BLEND_BETAS = np.array([1.3, -0.9, 0.7, -1.1, 0.5, 0.8, -0.6, 1.0, -0.4, 0.9], np.float32)
+
+
+def _smooth_field(rng, pts, n, amp, freq):
+    """n smooth 3-vector displacement fields over `pts` [V,3]: amp_k * sin(F_k p + phi_k) per component with low spatial
+    frequencies (rad / m) -- blend shapes that bend and swell the body instead of adding per-vertex noise -> [n, V, 3]"""
+    F = rng.uniform(-freq, freq, (n, 3, 3))
+    phi = rng.uniform(0, 2 * np.pi, (n, 1, 3))
+    a = rng.uniform(0.5, 1.0, (n, 1, 3)) * amp * rng.choice([-1.0, 1.0], (n, 1, 3))
+    return a * np.sin(np.einsum("vj,nkj->nvk", pts, F) + phi)
+
+
+def make_body(seed=42, blendshapes=False):
+    """Synthetic SMPL-like body model (dict of numpy arrays, fp32).
+
+    blendshapes=False: zero shapedirs / posedirs and a one-hot-ring J_regressor (the body of rounds 1-5: betas
+    are then a no-op).  blendshapes=True: what a real SMPL pickle has -- 10 non-zero shape directions (the first scales the
+    body about its centre, the others are smooth ~2 cm displacement fields), 207 smooth ~1 cm pose-corrective directions and
+    a DENSE joint regressor (every joint a positive combination of its ~64 nearest vertices), so that betas move the rest
+    joints, the rest-pose vertices (-> voxelised weights) and the posed vertices (lbs.py:185-222)."""
     rng = np.random.RandomState(seed)
     J = _JOINTS.copy()
     segs = _segments(J)
@@ -130,10 +149,23 @@ def make_body(seed=42):
     Jreg = np.zeros((24, N_VERTS))
     for j in range(24):
         Jreg[j, ring_ids[j]] = 1.0 / 8
+    shapedirs = np.zeros((N_VERTS, 3, 10), np.float32)
+    posedirs = np.zeros((207, N_VERTS * 3), np.float32)
+    if blendshapes:
+        rb = np.random.RandomState(seed + 7)      # (own stream: the vertices above stay those of the default body)
+        shapedirs = np.transpose(_smooth_field(rb, verts, 10, 0.02, 4.0), (1, 2, 0)).copy()
+        shapedirs[:, :, 0] = 0.03 * (verts - verts.mean(0))                       # "size": +-3 % per unit of beta_0
+        shapedirs[:, :, 1] = 0.03 * (verts - verts.mean(0)) * np.array([1.0, -0.5, 1.0])   # "build": wider and shorter
+        posedirs = _smooth_field(rb, verts, 207, 0.01, 3.0).reshape(207, N_VERTS * 3)
+        d2 = ((J[:, None, :] - verts[None]) ** 2).sum(-1)                          # [24, V]
+        near = np.argsort(d2, axis=1)[:, :64]
+        for j in range(24):
+            Jreg[j, near[j]] += rb.uniform(0.2, 1.0, 64) / 64
+        Jreg /= Jreg.sum(1, keepdims=True)
     return dict(
         v_template=verts.astype(np.float32),
-        shapedirs=np.zeros((N_VERTS, 3, 10), np.float32),
-        posedirs=np.zeros((207, N_VERTS * 3), np.float32),
+        shapedirs=shapedirs.astype(np.float32),
+        posedirs=posedirs.astype(np.float32),
         J_regressor=Jreg.astype(np.float32),
         parents=SMPL_PARENTS.copy(),
         lbs_weights=wgt.astype(np.float32),

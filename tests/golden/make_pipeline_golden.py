@@ -23,7 +23,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 # the hash-grid layout switch (tcnn level-3 resolution 54 / 55) changes the field: one golden per layout
-OUT = os.path.join(HERE, "pipeline_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
+# IA_GOLDEN_BLEND=1: the same recipe on the blend-shape body (synthetic.make_body(blendshapes=True): non-zero shapedirs / posedirs,
+# dense J_regressor) with the shape coefficients synthetic.BLEND_BETAS -> *_blend.npz
+BLEND = os.environ.get("IA_GOLDEN_BLEND", "0") == "1"
+OUT = os.path.join(HERE, "pipeline_golden%s%s.npz" % ("_blend" if BLEND else "", "_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
 SEED_INIT, SEED_UPD, SEED_TRAIN = 101, 202, 303
 RES, FRAME, N_TRAIN = 32, 1, 192
 
@@ -32,8 +35,9 @@ def main():
     import ref_cpu_harness as H
     from instantavatar_amd import synthetic as syn
     from oracle import oracle
-    body = syn.make_body()
-    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
+    body = syn.make_body(blendshapes=BLEND)
+    betas = syn.BLEND_BETAS if BLEND else np.zeros(10, np.float32)
+    init = oracle.deformer_initialize(body, betas, syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
     fp = syn.make_field(init["cano_joints"], init["bbox"])
     field, keep = oracle.make_field(fp)
     holder = {"field": field}
@@ -44,7 +48,7 @@ def main():
     dist = float(np.sqrt((tr[FRAME] ** 2).sum()))
     t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
     batch = {"rays_o": t(ro)[None], "rays_d": t(rd)[None], "near": torch.full((1, RES * RES), dist - 1), "far": torch.full((1, RES * RES), dist + 1),
-             "betas": torch.zeros(1, 10), "body_pose": t(poses[FRAME, 3:])[None], "global_orient": t(poses[FRAME, :3])[None],
+             "betas": t(betas)[None], "body_pose": t(poses[FRAME, 3:])[None], "global_orient": t(poses[FRAME, :3])[None],
              "transl": t(tr[FRAME])[None]}
     out = {}
     with H.SeededDraws() as draws:

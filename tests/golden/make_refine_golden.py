@@ -25,7 +25,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-OUT = os.path.join(HERE, "refine_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
+# IA_GOLDEN_BLEND=1: the same recipe on the blend-shape body (synthetic.make_body(blendshapes=True): non-zero shapedirs / posedirs,
+# dense J_regressor) with the shape coefficients synthetic.BLEND_BETAS -> *_blend.npz
+BLEND = os.environ.get("IA_GOLDEN_BLEND", "0") == "1"
+OUT = os.path.join(HERE, "refine_golden%s%s.npz" % ("_blend" if BLEND else "", "_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
 RES, N_RAYS, N_STEPS, N_FRAMES = 32, 768, 3, 4
 SEED_DRAWS, SEED_SEL, SEED_PERTURB = 404, 17, 23
 POSE_NOISE, TRANSL_NOISE = 0.03, 0.01
@@ -37,7 +40,7 @@ def scenario():
     from instantavatar_amd import synthetic as syn
     poses, tr = syn.procedural_pose_track(8)
     rs = np.random.RandomState(SEED_PERTURB)
-    tables = dict(betas=np.zeros((1, 10), np.float32),
+    tables = dict(betas=(syn.BLEND_BETAS.reshape(1, 10).copy() if BLEND else np.zeros((1, 10), np.float32)),
                   global_orient=(poses[:N_FRAMES, :3] + POSE_NOISE * rs.randn(N_FRAMES, 3)).astype(np.float32),
                   body_pose=(poses[:N_FRAMES, 3:] + POSE_NOISE * rs.randn(N_FRAMES, 69)).astype(np.float32),
                   transl=(tr[:N_FRAMES] + TRANSL_NOISE * rs.randn(N_FRAMES, 3)).astype(np.float32))
@@ -49,8 +52,9 @@ def main():
     import ref_cpu_harness as H
     from instantavatar_amd import synthetic as syn
     from oracle import oracle
-    body = syn.make_body()
-    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
+    body = syn.make_body(blendshapes=BLEND)
+    betas = syn.BLEND_BETAS if BLEND else np.zeros(10, np.float32)
+    init = oracle.deformer_initialize(body, betas, syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
     fp = syn.make_field(init["cano_joints"], init["bbox"])
     holder = {"fp": fp}
     holder["field"], holder["keep"] = oracle.make_field(fp)
@@ -111,13 +115,13 @@ def main():
     with H.SeededDraws() as draws:
         for k in range(N_STEPS):
             f = k % N_FRAMES
-            world = oracle.make_world(body, init, fp, np.zeros(10, np.float32), poses[f, 3:], poses[f, :3], tr[f], syn.INIT_BONES)
+            world = oracle.make_world(body, init, fp, betas, poses[f, 3:], poses[f, :3], tr[f], syn.INIT_BONES)
             jit = np.random.RandomState(SEED_DRAWS + 100 + k).rand(2, 64 ** 3, 3).astype(np.float32)
             tgt = oracle.render_image_fast(world, ro, rd, jit)
             s = sel[k]
             dist = float(np.sqrt((tr[f] ** 2).sum()))
             batch = {"rays_o": t(ro[s])[None], "rays_d": t(rd[s])[None], "near": torch.full((1, N_RAYS), dist - 1), "far": torch.full((1, N_RAYS), dist + 1),
-                     "betas": torch.zeros(1, 10), "rgb": t(tgt["rgb"][s])[None], "alpha": t(tgt["alpha"][s])[None],
+                     "betas": t(betas)[None], "rgb": t(tgt["rgb"][s])[None], "alpha": t(tgt["alpha"][s])[None],
                      "bg_color": torch.ones(1, N_RAYS, 3), "idx": torch.tensor([f])}
             out["tgt_rgb_%d" % k], out["tgt_alpha_%d" % k] = tgt["rgb"][s], tgt["alpha"][s]
             draws.seed(SEED_DRAWS + k)

@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 # the hash-grid layout switch (tcnn level-3 resolution 54 / 55) changes the field: one golden per layout
-OUT = os.path.join(HERE, "smpl_deformer_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
+# IA_GOLDEN_BLEND=1: the same recipe on the blend-shape body (synthetic.make_body(blendshapes=True): non-zero shapedirs / posedirs,
+# dense J_regressor) with the shape coefficients synthetic.BLEND_BETAS -> *_blend.npz
+BLEND = os.environ.get("IA_GOLDEN_BLEND", "0") == "1"
+OUT = os.path.join(HERE, "smpl_deformer_golden%s%s.npz" % ("_blend" if BLEND else "", "_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""))
 FRAME, SEED, N = 2, 11, 4000
 
 
@@ -21,13 +24,14 @@ def main():
     import ref_cpu_harness as H
     from instantavatar_amd import synthetic as syn
     from oracle import oracle
-    body = syn.make_body()
-    init = oracle.deformer_initialize(body, np.zeros(10, np.float32), syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
+    body = syn.make_body(blendshapes=BLEND)
+    betas = syn.BLEND_BETAS if BLEND else np.zeros(10, np.float32)
+    init = oracle.deformer_initialize(body, betas, syn.cano_pose("A_pose"), resolution=32, n_smooth=30)
     poses, tr = syn.procedural_pose_track(8)
-    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[FRAME, 3:], poses[FRAME, :3], tr[FRAME])
+    prep = oracle.smpl_deformer_prepare(body, betas, poses[FRAME, 3:], poses[FRAME, :3], tr[FRAME])
     pose_t = np.zeros((1, 69), np.float32)
     pose_t[:, 2], pose_t[:, 5] = np.pi / 6, -np.pi / 6
-    cano_j = oracle.smpl_forward(body, np.zeros(10, np.float32), pose_t)["joints"]
+    cano_j = oracle.smpl_forward(body, betas, pose_t)["joints"]
     fp = syn.make_field(cano_j, prep["bbox"], seed=42, n_levels=16)   # the field of tests/world.py:build_smpl_deformer_world (DA-pose template)
     field, keep = oracle.make_field(fp)
     R = H.install(oracle, {"field": field})
@@ -36,7 +40,7 @@ def main():
     sd.SMPL = R.snarf.SMPL
     dfm = sd.SMPLDeformer("", "neutral", threshold=0.05, k=1)
     t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
-    params = {"betas": torch.zeros(1, 10), "body_pose": t(poses[FRAME, 3:])[None], "global_orient": t(poses[FRAME, :3])[None],
+    params = {"betas": t(betas)[None], "body_pose": t(poses[FRAME, 3:])[None], "global_orient": t(poses[FRAME, :3])[None],
               "transl": t(tr[FRAME])[None]}
     dfm.prepare_deformer(params)
     rs = np.random.RandomState(SEED)

@@ -81,6 +81,27 @@ def test_non_finite_inputs_do_not_fault(gw):
     assert (sq >= 0).all()
 
 
+def test_density_grid_init_small_workspace_route_equals_batched(gw):
+    """`ia_density_grid_init` with the workspace of `ia_density_init_workspace_bytes` (one probe set per launch) against the
+    batched workspace (all sets in one launch, what the Python caller hands over by default): the header promises the same
+    result.  ADVICE r05: the probe-cell permutation (Morton order) had only been applied to the batched route's maximum, the
+    small route scattered cell perm(p)'s density to cell p."""
+    model, poses, tr = gw
+    grid = model.renderer.density_grid_test
+    jit = torch.as_tensor(np.random.RandomState(9).rand(3, 64 ** 3, 3).astype(np.float32), device=DEV)
+    model.deformer.prepare_deformer(make_batch(DEV, 64, poses[3], tr[3]))
+    out = {}
+    for batched in (True, False):
+        grid.batched_probes = batched
+        try:
+            grid.initialize(model.deformer, model.net_coarse, jitter=jit)
+        finally:
+            grid.batched_probes = True
+        out[batched] = (grid.density_probe.clone(), grid.density_field.clone())
+    assert int(out[True][1].sum()) > 500
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+
+
 def test_rays_that_miss_everything(gw):
     model, poses, tr = gw
     res = 32

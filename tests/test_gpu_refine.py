@@ -17,7 +17,25 @@ import world as W
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine_golden%s.npz" % ("_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else "")))
+_L55 = "_l55" if os.environ.get("IA_TCNN_LEVEL3_RES", "54") == "55" else ""
+# Every test runs twice: on the zero-blendshape body of SURVEY 8d (refine_golden.npz) and on the blend-shape body with
+# betas = synthetic.BLEND_BETAS (refine_golden_blend.npz = the same recipe with IA_GOLDEN_BLEND=1: the reference's lbs.py under
+# autograd with non-zero shapedirs / posedirs and a dense J_regressor -- the rest joints `ia_smpl_tfs[_bwd]` chains from then
+# depend on betas) -- VERDICT r05 missing 3.
+G = None
+BLEND = False
+
+
+@pytest.fixture(autouse=True, params=[False, True], ids=["zero-blendshapes", "blendshapes"])
+def golden(request):
+    global G, BLEND
+    BLEND = request.param
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine_golden%s%s.npz" % ("_blend" if BLEND else "", _L55)))
+    return G
+
+
+def _betas():
+    return torch.as_tensor(syn.BLEND_BETAS, device=DEV)[None] if BLEND else torch.zeros(1, 10, device=DEV)
 
 
 def _cos(a, b):
@@ -32,7 +50,7 @@ def _rel(a, b):
 
 def _setup():
     from instantavatar_amd.pipeline import build_synthetic_model
-    model, body, fp = build_synthetic_model(DEV, resolution=32, n_levels=16)
+    model, body, fp = build_synthetic_model(DEV, resolution=32, n_levels=16, blendshapes=BLEND, betas=syn.BLEND_BETAS if BLEND else None)
     model.SMPL_param = SMPLParamEmbedding(**{k: torch.as_tensor(G["table_" + k]) for k in ("betas", "global_orient", "transl", "body_pose")}).to(DEV)
     opt = configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=1e-5)       # SNARF_NGP_refine.yaml
     loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1))
@@ -57,7 +75,7 @@ def _batch(k):
     dist = float(np.sqrt((tr[f] ** 2).sum()))
     t = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)
     return {"rays_o": t(ro[s])[None], "rays_d": t(rd[s])[None], "near": torch.full((1, n_rays), dist - 1, device=DEV),
-            "far": torch.full((1, n_rays), dist + 1, device=DEV), "betas": torch.zeros(1, 10, device=DEV),
+            "far": torch.full((1, n_rays), dist + 1, device=DEV), "betas": _betas(),
             "rgb": t(G["tgt_rgb_%d" % k])[None], "alpha": t(G["tgt_alpha_%d" % k])[None],
             "bg_color": torch.ones(1, n_rays, 3, device=DEV), "idx": torch.tensor([f])}
 
@@ -312,7 +330,7 @@ def test_smpl_chain_backward_kernel_equals_autograd_through_lbs():
         sd.FUSED_SMPL_BACKWARD = fused
         try:
             body = model.SMPL_param(torch.tensor([1], device=DEV))
-            params = {"betas": torch.zeros(1, 10, device=DEV), "body_pose": body["body_pose"], "global_orient": body["global_orient"],
+            params = {"betas": _betas(), "body_pose": body["body_pose"], "global_orient": body["global_orient"],
                       "transl": body["transl"]}
             model.deformer.prepare_deformer(params)
             tfs = model.deformer.tfs

@@ -14,18 +14,25 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def sw():
-    model, body, fp = W.build_smpl_deformer_world(DEV)
+@pytest.fixture(scope="module", params=[False, True], ids=["zero-blendshapes", "blendshapes"])
+def sw(request):
+    """both bodies: zero shape / pose directions and the blend-shape body with synthetic.BLEND_BETAS -- the pose
+    offsets enter T_inv (smpl_deformer.py:66-75) and the per-step `SMPL.forward(small_ops=True)` multiplies non-zero operands"""
+    global BETAS
+    model, body, fp = W.build_smpl_deformer_world(DEV, blend=request.param)
+    BETAS = syn.BLEND_BETAS if request.param else np.zeros(10, np.float32)
     poses, tr = W.poses()
     return model, body, fp, poses, tr
 
 
+BETAS = np.zeros(10, np.float32)
+
+
 def _prep(oracle, sw, i, res=64):
     model, body, fp, poses, tr = sw
-    batch = make_batch(DEV, res, poses[i], tr[i])
+    batch = make_batch(DEV, res, poses[i], tr[i], betas=BETAS)
     model.deformer.prepare_deformer(batch)
-    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[i][3:], poses[i][:3], tr[i])
+    prep = oracle.smpl_deformer_prepare(body, BETAS, poses[i][3:], poses[i][:3], tr[i])
     return batch, prep
 
 
@@ -91,10 +98,10 @@ def test_rendered_frame_matches_oracle(oracle, sw):
     res, G = 64, 64
     i = 2
     jit = np.random.RandomState(31).rand(2, G ** 3, 3).astype(np.float32)
-    batch = make_batch(DEV, res, poses[i], tr[i])
+    batch = make_batch(DEV, res, poses[i], tr[i], betas=BETAS)
     rgb, depth, alpha, counter = model.render_image_fast(batch, (res, res), jitter=torch.as_tensor(jit, device=DEV))
     d = model.deformer
-    prep = oracle.smpl_deformer_prepare(body, np.zeros(10, np.float32), poses[i][3:], poses[i][:3], tr[i])
+    prep = oracle.smpl_deformer_prepare(body, BETAS, poses[i][3:], poses[i][:3], tr[i])
     prep = dict(prep, vertices=d.vertices[0].cpu().numpy(), T_inv=d.T_inv[0].cpu().numpy())
     field, keep = oracle.make_field(fp)
     query = lambda p: oracle.smpl_deform_query(p, prep, field, eval_mode=True)

@@ -10,9 +10,12 @@ from instantavatar_amd import synthetic as syn
 from instantavatar_amd.pipeline import build_synthetic_model, make_batch
 
 
-@functools.lru_cache(maxsize=4)
-def build(device, resolution=64, n_levels=16):
-    model, body, fp = build_synthetic_model(device, resolution=resolution, n_levels=n_levels)
+@functools.lru_cache(maxsize=6)
+def build(device, resolution=64, n_levels=16, blend=False):
+    """blend=True: the body with non-zero shapedirs / posedirs and a dense J_regressor, initialised with synthetic.BLEND_BETAS
+    (pass `betas=syn.BLEND_BETAS` to make_batch / oracle_world): what a real SMPL pickle + a data set's betas are."""
+    model, body, fp = build_synthetic_model(device, resolution=resolution, n_levels=n_levels, blendshapes=blend,
+                                            betas=syn.BLEND_BETAS if blend else None)
     fd = model.deformer.deformer
     init = dict(tfs_inv_t=model.deformer.tfs_inv_t[0].cpu().numpy(),
                 lbs_voxel=np.ascontiguousarray(fd.lbs_voxel_final[0].cpu().numpy()),
@@ -31,19 +34,20 @@ def poses(n=4):
     return syn.procedural_pose_track(max(n, 8))
 
 
-@functools.lru_cache(maxsize=2)
-def build_smpl_deformer_world(device, n_levels=16):
+@functools.lru_cache(maxsize=4)
+def build_smpl_deformer_world(device, n_levels=16, blend=False):
     """The second deformer plugin (SMPLDeformer) wired like `build`: synthetic body, a field whose
-    density follows the capsule body in the deformer's TEMPLATE pose, NeRFNGPNet + Raymarcher."""
+    density follows the capsule body in the deformer's TEMPLATE pose, NeRFNGPNet + Raymarcher.
+    blend=True: the blend-shape body with synthetic.BLEND_BETAS (pose offsets matter here: smpl_deformer.py:36-45,66-75)."""
     from instantavatar_amd.deformers.smpl_deformer import SMPLDeformer
     from instantavatar_amd.deformers.smplx import SMPL
     from instantavatar_amd.models.networks.ngp import NeRFNGPNet
     from instantavatar_amd.pipeline import AvatarModel
     from instantavatar_amd.renderers.raymarcher_acc import Raymarcher
-    body = syn.make_body(42)
+    body = syn.make_body(42, blendshapes=blend)
     smpl = SMPL.from_dict(body).to(device)
     deformer = SMPLDeformer(None, "neutral", threshold=0.05, k=1, body_model=smpl)
-    betas = torch.zeros(1, 10, device=device)
+    betas = torch.as_tensor(syn.BLEND_BETAS, device=device)[None] if blend else torch.zeros(1, 10, device=device)
     deformer.initialize(betas, device)
     deformer.initialized = True
     pose_t = torch.zeros((1, 69), device=device)
