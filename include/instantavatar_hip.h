@@ -276,10 +276,12 @@ int ia_field_fwd_train(const float *x, int V, const int32_t *n_dev, const ia_fie
 /* NeRFLoss (instant_avatar/utils/loss.py:53-77), value and gradient in one pass:
  * out5 (zero-filled by the caller) = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density};
  * d_rgb [n_rays,3], d_alpha [n_rays], d_weight [n_weights] = d loss / d input.
- * weight: the dense weight_coarse tensor [n_rays x MAX_SAMPLES] (raymarcher_acc.py:181-186). */
+ * weight: the dense weight_coarse tensor [n_rays x MAX_SAMPLES] (raymarcher_acc.py:181-186).
+ * poison: optional device scalar; > 0 multiplies the loss and all gradients by NaN (the step of a training render that
+ * dropped candidates is then skipped by the optimiser's non-finite check, the way GradScaler skips a step: DNeRF.py:151-154). */
 int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
                  const float *tgt_alpha, const float *weight, int n_rays, long long n_weights,
-                 float w_rgb, float w_alpha, float w_reg, float *out5, float *d_rgb,
+                 float w_rgb, float w_alpha, float w_reg, const float *poison, float *out5, float *d_rgb,
                  float *d_alpha, float *d_weight, void *stream);
 
 /* Fused backward of both tiny MLPs (tcnn FullyFusedMLP backward; reached in the reference
@@ -577,6 +579,33 @@ int ia_search_kernel_info(int *vgprs, int *lds_bytes, int *threads, int *workgro
 int ia_selftest_shared_rcp(const float *num, const float *den, int n, float *q_shared, float *q_ieee, void *stream);
 int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int n, float *out_shared, float *out_plain,
                             uint8_t *took_shared, void *stream);
+
+
+/* ---- optimiser step (DNeRF.py:46-50, :151-159) ---------------------------------------------------------------------
+ * One call replaces what the reference's `self.scaler.unscale_(optimizer); self.scaler.step(optimizer);
+ * optimizer.zero_grad()` launch per step through torch: GradScaler's inf / NaN check over ALL gradients (any non-finite
+ * element skips the whole update: parameters, moments and step counters stay as they are), `torch.optim.Adam` (betas
+ * (0.9, 0.99), eps 1e-15 in every shipped config; no weight decay, no amsgrad) over up to IA_ADAM_MAX_TENSORS parameter
+ * tensors with their own learning rates (the three parameter groups of DNeRF.py:46-50), the refresh of the half-precision
+ * copy of the parameters that the field kernels read (tcnn holds fp32 master weights next to its half parameters), and,
+ * with `zero_grad`, the gradient zero-fill for the next step.  Arithmetic: torch/optim/adam.py `_single_tensor_adam`
+ * (see csrc/ia_optim.hip); `step` is the device-resident counter of torch's capturable state, so the call can be captured
+ * in a HIP graph; `lr_dev` (device scalar, optional) lets an lr scheduler reach a captured step.
+ *   skip_in   optional device scalar: non-zero = skip this step whatever the gradients hold (candidate overflow)
+ *   found_inf optional device scalar, written: 1.0 when the step was skipped, else 0.0
+ *   ws        ia_adam_workspace_bytes() bytes, zero-filled ONCE by the caller, private to one stream                     */
+#define IA_ADAM_MAX_TENSORS 8
+typedef struct ia_adam_tensor {
+  float *param, *grad, *exp_avg, *exp_avg_sq; /* device fp32 [numel], 16-byte aligned */
+  uint16_t *shadow;                           /* device fp16 [numel] copy of param (8-byte aligned) or NULL */
+  float *step;                                /* device scalar: steps taken so far */
+  const float *lr_dev;                        /* device scalar or NULL -> lr */
+  double lr, beta1, beta2, eps;
+  long long numel;
+} ia_adam_tensor;
+size_t ia_adam_workspace_bytes(void);
+int ia_adam_step(const ia_adam_tensor *tensors, int n_tensors, const float *skip_in, float *found_inf,
+                 int zero_grad, void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,14 @@ class OccGrid(C.Structure):
     _fields_ = [("G", C.c_int), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("shadow", C.c_void_p), ("step", C.c_void_p), ("lr_dev", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("numel", C.c_longlong)]
+
+
+IA_ADAM_MAX_TENSORS = 8
+
 _lib = None
 
 _VP = C.c_void_p
@@ -93,7 +101,7 @@ _SIGS = {
     "ia_snarf_inverse_skinning_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, C.c_long, _VP, _VP, C.c_int, C.POINTER(SnarfGrid), _VP, _VP,
                                                 _VP, _VP, C.c_size_t, _VP]),
     "ia_expand_candidate_points": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, _VP]),
-    "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 5),
+    "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 6),
     "ia_field_grad_scale": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "ia_field_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_field_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, C.POINTER(Field)] + [_VP] * 7 + [C.c_size_t, _VP]),
@@ -133,6 +141,8 @@ _SIGS = {
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "ia_pack_rgba8": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "ia_adam_workspace_bytes": (C.c_size_t, []),
+    "ia_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int, _VP, _VP, C.c_int, _VP, C.c_size_t, _VP]),
     "ia_selftest_shared_rcp": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ia_selftest_jinv_update": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
 }

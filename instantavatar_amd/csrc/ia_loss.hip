@@ -27,9 +27,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb, const float *__restrict__ tgt_rgb,
                                                    const float *__restrict__ alpha, const float *__restrict__ tgt_alpha,
                                                    const float *__restrict__ weight, int N, long long M, float w_rgb,
-                                                   float w_alpha, float w_reg, float *__restrict__ out,
+                                                   float w_alpha, float w_reg, const float *__restrict__ poison,
+                                                   float *__restrict__ out,
                                                    float *__restrict__ d_rgb, float *__restrict__ d_alpha,
                                                    float *__restrict__ d_weight) {
+  // poison (optional device scalar): > 0 turns the loss and every gradient into NaN -- a training render that dropped
+  // candidates must not update anything; its NaN gradients make the optimiser's non-finite check skip the step on every rank
+  const float pz = (poison != nullptr && *poison > 0.f) ? __int_as_float(0x7fc00000) : 1.0f;
   __shared__ float s_part[4][4];
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
   const float inv3n = 1.0f / (3.0f * (float)N), invn = 1.0f / (float)N, invm = M > 0 ? 1.0f / (float)M : 0.f;
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
   for (long long i = tid; i < 3LL * N; i += stride) {
     const float d = rgb[i] - tgt_rgb[i];
     s_mse += d * d;
-    d_rgb[i] = w_rgb * 2.0f * d * inv3n;
+    d_rgb[i] = w_rgb * 2.0f * d * inv3n * pz;
   }
   for (long long i = tid; i < N; i += stride) {
     const float v = alpha[i], d = v - tgt_alpha[i];
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
     ent_and_grad(v, e, de);
     s_la += d * d;
     s_ra += e;
-    d_alpha[i] = w_alpha * 2.0f * d * invn + w_reg * de * invn;
+    d_alpha[i] = (w_alpha * 2.0f * d * invn + w_reg * de * invn) * pz;
   }
   // the weights are the bulk (n_rays x MAX_SAMPLES): 16-byte loads / stores, four of them in flight per thread -- one value
   // per iteration made this loop a chain of dependent round trips (r02: 25 -> 9 us at 4 096 rays)
@@ -61,14 +65,14 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
       float4 g;
       ent_and_grad(v.x, e0, g.x); ent_and_grad(v.y, e1, g.y); ent_and_grad(v.z, e2, g.z); ent_and_grad(v.w, e3, g.w);
       s_rd += (e0 + e1) + (e2 + e3);
-      dw4[i] = make_float4(w_reg * g.x * invm, w_reg * g.y * invm, w_reg * g.z * invm, w_reg * g.w * invm);
+      dw4[i] = make_float4(w_reg * g.x * invm * pz, w_reg * g.y * invm * pz, w_reg * g.z * invm * pz, w_reg * g.w * invm * pz);
     }
   } else {
     for (long long i = tid; i < M; i += stride) {
       float e, de;
       ent_and_grad(weight[i], e, de);
       s_rd += e;
-      d_weight[i] = w_reg * de * invm;
+      d_weight[i] = w_reg * de * invm * pz;
     }
   }
   s_mse = wave_sum(s_mse); s_la = wave_sum(s_la); s_ra = wave_sum(s_ra); s_rd = wave_sum(s_rd);
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
       atomicAdd(out + 3, IA_LOSS_OFFSET);
       atomicAdd(out + 4, IA_LOSS_OFFSET);
     }
-    atomicAdd(out + 0, total);
+    atomicAdd(out + 0, total * pz);
     atomicAdd(out + 1, mse);
     atomicAdd(out + 2, la);
     atomicAdd(out + 3, ra);
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
 
 extern "C" int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha, const float *tgt_alpha,
                             const float *weight, int n_rays, long long n_weights, float w_rgb, float w_alpha,
-                            float w_reg, float *out5, float *d_rgb, float *d_alpha, float *d_weight, void *stream) {
+                            float w_reg, const float *poison, float *out5, float *d_rgb, float *d_alpha, float *d_weight,
+                            void *stream) {
   IA_CHECK_ARG(n_rays > 0 && n_weights >= 0, "ia_nerf_loss: bad sizes");
   IA_CHECK_ARG(rgb && tgt_rgb && alpha && tgt_alpha && out5 && d_rgb && d_alpha && (n_weights == 0 || (weight && d_weight)),
                "ia_nerf_loss: null pointer");
@@ -105,7 +110,7 @@ extern "C" int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float 
   if (blocks > 128) blocks = 128;           // ... but few workgroups: each ends in five atomics on the same words
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_nerf_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rgb, tgt_rgb, alpha, tgt_alpha,
-                     weight, n_rays, n_weights, w_rgb, w_alpha, w_reg, out5, d_rgb, d_alpha, d_weight);
+                     weight, n_rays, n_weights, w_rgb, w_alpha, w_reg, poison, out5, d_rgb, d_alpha, d_weight);
   IA_LAUNCH_CHECK("k_nerf_loss");
   return IA_OK;
 }

@@ -38,7 +38,9 @@
 // (91 VGPRs -> 5 waves per SIMD) together with 32 points per workgroup (9.5 KB -> the LDS allows them): 128 x 32 with
 // group 2 = 2.55 ms against 2.66 ms; group 2 alone 2.71, 32 points alone (group 4) 3.08, group 1 (82 VGPRs, still 5
 // waves) 2.67, forcing 6 waves per SIMD (spills) 2.86, 64 x 32 2.67, 64 x 16 2.58, 256 x 32 2.68, 256 x 64 2.62.
+#ifndef IA_SEARCH_NP
 #define IA_SEARCH_NP 64        // points per workgroup (threads x points, round 3): 256 x 64 199.6 us, 128 x 32 206.7, 512 x 128 206.7,
+#endif
 #define IA_SEARCH_THREADS 256  // 256 x 128 212.1, 128 x 64 215.3, 64 x 32 223.0, 256 x 32 228.6, 512 x 64 229.2
 #define IA_SEARCH_ATTR
 

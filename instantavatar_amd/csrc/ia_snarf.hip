@@ -310,6 +310,11 @@ __global__ void k_bbox_init(float *bbox) {
   else if (threadIdx.x < 6) bbox[threadIdx.x] = __int_as_float(0xff800000);
 }
 
+#ifndef IA_PRE_LDS_STORE
+#define IA_PRE_LDS_STORE 1  // stage the channel-last transform records through LDS so that every store instruction is contiguous:
+                            // 25.8 -> 18.9 us for the product call (d + bbox, incl. the reduce launch), streams alone 19.7 -> 13.2 us
+                            // (profiles/r06_ab_precompute.txt)
+#endif
 #ifndef IA_PRE_VPT
 #define IA_PRE_VPT 4  // consecutive voxels (along W) per thread: 1, 2 or 4 (measured 173 / 185 / 95 us)
 #endif
@@ -318,7 +323,7 @@ template <> struct PreVec<1> { typedef float type; };
 template <> struct PreVec<2> { typedef float2 type; };
 template <> struct PreVec<4> { typedef float4 type; };
 
-template <int VPT>
+template <int VPT, bool LDS_STORE>
 __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ voxel_w,
                                                     const float *__restrict__ tfs,
                                                     float *__restrict__ voxel_J,
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
   // contiguous bytes of output per thread.  W % VPT == 0 is checked by the host.
   typedef typename PreVec<VPT>::type vec_t;
   const int n = g.D * g.H * g.W;
+  __shared__ float4 s_stage[LDS_STORE ? 4 * 64 * (3 * VPT + 1) : 1];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n / VPT; q += gridDim.x * blockDim.x) {
     const int index0 = q * VPT;
@@ -363,12 +369,39 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
         for (int v = 0; v < VPT; v++) J[v][c] = __builtin_fmaf(w.f[v], t, J[v][c]);
       }
     }
+    if (LDS_STORE) {
+    // The wave's VPT x 64 records are ONE contiguous run of 64 * VPT * 48 bytes, but lane t holds bytes [192 t, 192 t + 192) of
+    // it: a direct store instruction writes 64 sixteen-byte pieces 192 bytes apart (1.3 M of the kernel's 2.1 M L2 requests).
+    // Through LDS (row stride 3 VPT + 1 float4: conflict-free for both phases) every store instruction writes 1 024 contiguous
+    // bytes.  Wave-private staging: no workgroup barrier (all lanes of a wave take the same trip count when n / VPT % 64 == 0,
+    // which the host checks before it picks this variant).
+    {
+      constexpr int RS = 3 * VPT + 1;
+      float4 *const sw = s_stage + (threadIdx.x >> 6) * (64 * RS);
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int v = 0; v < VPT; v++) {
+        sw[lane * RS + 3 * v + 0] = make_float4(J[v][0], J[v][1], J[v][2], J[v][3]);
+        sw[lane * RS + 3 * v + 1] = make_float4(J[v][4], J[v][5], J[v][6], J[v][7]);
+        sw[lane * RS + 3 * v + 2] = make_float4(J[v][8], J[v][9], J[v][10], J[v][11]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      float4 *const o = reinterpret_cast<float4 *>(voxel_J + (size_t)(index0 - lane * VPT) * 12);   // the wave's first record
+#pragma unroll
+      for (int k = 0; k < 3 * VPT; k++) {
+        const int e = k * 64 + lane;              // float4 index inside the wave's run
+        o[e] = sw[(e / (3 * VPT)) * RS + e % (3 * VPT)];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    } else {
     float4 *o = reinterpret_cast<float4 *>(voxel_J + (size_t)index0 * 12);
 #pragma unroll
     for (int v = 0; v < VPT; v++) {
       o[3 * v + 0] = make_float4(J[v][0], J[v][1], J[v][2], J[v][3]);
       o[3 * v + 1] = make_float4(J[v][4], J[v][5], J[v][6], J[v][7]);
       o[3 * v + 2] = make_float4(J[v][8], J[v][9], J[v][10], J[v][11]);
+    }
     }
     const int hw = g.H * g.W;
     const int idx_d = index0 / hw, idx_h = index0 % hw / g.W, idx_w0 = index0 % hw % g.W;
@@ -487,8 +520,14 @@ extern "C" int ia_precompute_ws(const float *voxel_w, const float *tfs, float *v
     hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
     IA_LAUNCH_CHECK("k_bbox_init");
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
-                     partial, ia_make_grid_dev(grid));
+  // (the LDS-staged stores need whole waves: every lane of a wave takes the same number of trips)
+  const long n_thr = (long)grid->D * grid->H * grid->W / IA_PRE_VPT;
+  if (IA_PRE_LDS_STORE && n_thr % 64 == 0 && n_thr % ((long)blocks * 256) == 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT, true>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
+                       partial, ia_make_grid_dev(grid));
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_precompute<IA_PRE_VPT, false>), dim3(blocks), dim3(256), 0, s, voxel_w, tfs, voxel_J, voxel_d, bbox,
+                       partial, ia_make_grid_dev(grid));
   IA_LAUNCH_CHECK("k_precompute");
   if (partial) {
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(384), 0, s, partial, blocks, bbox);

@@ -150,11 +150,18 @@ class DeviceFrames:
         if out is not None:
             # SMPL parameters of the frame into the caller's tensors too; what was written in place is returned as the
             # caller's own tensor objects, so that `batch is out`-style identity checks downstream see no copy to make
+            dsts, srcs = [], []
             for k in ("betas", "global_orient", "body_pose", "transl", "idx_dev"):
                 t = out.get(k)
                 if torch.is_tensor(t) and t.is_cuda and t.shape == res[k].shape:
-                    t.copy_(res[k], non_blocking=True)
+                    if t.dtype == torch.float32 and res[k].dtype == torch.float32:
+                        dsts.append(t)
+                        srcs.append(res[k])
+                    else:
+                        t.copy_(res[k], non_blocking=True)
                     res[k] = t
+            if dsts:
+                torch._foreach_copy_(dsts, srcs, non_blocking=True)   # the four SMPL vectors in ONE launch (was four ~5 us copies)
             for k in ("rgb", "rays_o", "rays_d", "alpha", "bg_color", "near", "far"):
                 t = out.get(k)
                 if torch.is_tensor(t) and t.data_ptr() == res[k].data_ptr() and t.shape == res[k].shape:

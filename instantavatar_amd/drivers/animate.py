@@ -75,7 +75,7 @@ class AnimateSequence:
 
 def build_model(args, device, quiet=False):
     if args.synthetic:
-        model, _, _ = build_synthetic_model(device)
+        model, _, _ = build_synthetic_model(device, seed=int(getattr(args, "seed", None) or 42))
         if args.ckpt:  # synthetic body, trained weights (e.g. written by drivers.train --synthetic)
             missing, unexpected = ckpt_io.load_checkpoint(model, args.ckpt, map_location=device, strict_self_check=True)
             if not quiet:
@@ -264,13 +264,34 @@ def main(argv=None):
     ap.add_argument("--max-frames", type=int, default=0)
     ap.add_argument("--out", default="animation/out")
     ap.add_argument("--no-gif", action="store_true")
+    ap.add_argument("--subjects", help="BASELINE config 5 (a batch of subjects, one per GPU): a JSON list of per-subject overrides "
+                    "[{\"ckpt\": ..., \"betas\": ..., \"gender\": ..., \"out\": ..., (\"poses\": ..., \"seed\": ...)}, ...]; rank r of the job renders "
+                    "the WHOLE sequence of subject r (r modulo the list) with that subject's weights into its `out` -- independent "
+                    "replicas, no frame sharding, no data-path collective")
+    ap.add_argument("--seed", type=int, default=None, help="--synthetic: seed of the synthetic body + field (another seed = another subject)")
     add_launch_args(ap)
     args = ap.parse_args(argv)
-    if not args.synthetic and not (args.ckpt and args.poses):
-        ap.error("--ckpt and --poses are required unless --synthetic is given")
     from .launch import Launch
     launch = Launch.from_env(who="animate")
     device = launch.device
+    replica = None
+    if args.subjects:
+        import json
+        with open(args.subjects) as f:
+            subjects = json.load(f)
+        if not isinstance(subjects, list) or not subjects:
+            ap.error("--subjects: a non-empty JSON list of objects")
+        mine = subjects[launch.rank % len(subjects)]
+        unknown = set(mine) - {"ckpt", "betas", "gender", "out", "poses", "seed", "smpl_dir"}
+        if unknown:
+            ap.error("--subjects: unknown keys %s" % sorted(unknown))
+        for k, v in mine.items():
+            setattr(args, k, v)
+        if "out" not in mine:
+            args.out = os.path.join(args.out, "subject_%d" % (launch.rank % len(subjects)))
+        replica = Launch(device=device)     # this rank's own one-rank "job": render_sequence deals it every frame
+    if not args.synthetic and not (args.ckpt and args.poses):
+        ap.error("--ckpt and --poses are required unless --synthetic is given")
     try:
         model, betas = build_model(args, device, quiet=not launch.is_main)
         model.eval()
@@ -286,9 +307,18 @@ def main(argv=None):
             poses, trans = poses[:args.max_frames], trans[:args.max_frames]
         seq = AnimateSequence(poses, trans, betas, device, args.downscale, size=args.size or None)
         jitter = None if args.jitter_seed is None else fixed_jitter(args.jitter_seed, device)
-        res = render_sequence(model, seq, args.out, gif=None if args.no_gif else "animation.gif", launch=launch,
-                              in_flight=args.in_flight, jitter=jitter)
-        if launch.is_main:
+        res = render_sequence(model, seq, args.out, gif=None if args.no_gif else "animation.gif", launch=replica or launch,
+                              in_flight=args.in_flight, jitter=jitter, log=None if replica else print)
+        if replica is not None:
+            # whole-job figure of the replicas: all frames of all subjects over the slowest rank's render loop
+            slowest = launch.max_over_ranks(res["render_s"])
+            total = launch.sum_over_ranks(res["frames"])
+            print("rank %d: subject %d, %d frames (%dx%d) to %s" % (launch.rank, launch.rank % len(subjects), res["frames"], seq.W, seq.H, args.out))
+            launch.barrier()
+            if launch.is_main:
+                print("rendered %d frames of %d subject replica(s) in %.3f s = %.1f frames/s (one subject per rank; PNG / GIF I/O and graph capture excluded)"
+                      % (int(total), launch.world_size, slowest, total / slowest if slowest > 0 else 0.0))
+        elif launch.is_main:
             print("wrote %d frames (%dx%d) to %s" % (res["frames"], seq.W, seq.H, args.out))
     finally:
         launch.close()

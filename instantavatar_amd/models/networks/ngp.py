@@ -192,25 +192,39 @@ class NeRFNGPNet(nn.Module):
         self._desc = None
 
     # -- fp16 shadow + C descriptor ------------------------------------------
-    def mark_updated(self):
+    def mark_updated(self, shadow_fresh=False):
         """Mark the fp16 shadow stale.  Call after an optimizer step: fused / foreach
-        optimizers update parameters without bumping Tensor._version."""
-        self._dirty = True
+        optimizers update parameters without bumping Tensor._version.
+        shadow_fresh: the step itself wrote the fp16 copy (optim.FusedAdam -> `half_shadow`): only the MFMA fragment image
+        (a re-arrangement of the fp16 MLP weights) is rebuilt on next use, the two fp32 -> fp16 casts are skipped."""
+        if shadow_fresh and self._half is not None and getattr(self, "_dirty", False) is not True:
+            self._dirty = "frags"
+        else:
+            self._dirty = True
+
+    def half_shadow(self, which):
+        """the fp16 copy of encoder.params (0) / color_net.params (1) that the kernels read, or None before its first use"""
+        h = self._half
+        if h is None or h[0].device != self.encoder.params.device or h[which].numel() != (self.encoder, self.color_net)[which].params.numel():
+            return None
+        return h[which]
 
     def _half_params(self):
         """fp16 shadow of the two parameter vectors.  It is refreshed IN PLACE (same device pointers) whenever the master
         weights changed, and so is the MFMA fragment image: a captured HIP graph (pipeline.GraphedRenderer) has these
         pointers baked in and sees new weights after the next eager `field_desc()` / `refresh()` call."""
         key = (self.encoder.params._version, self.color_net.params._version, self.encoder.params.data_ptr())
-        stale = getattr(self, "_dirty", False) or self._half_key != key
+        dirty = getattr(self, "_dirty", False)
+        stale = bool(dirty) or self._half_key != key
         if self._half is None or self._half[0].device != self.encoder.params.device:
             self._half = (self.encoder.params.detach().to(torch.float16).contiguous(),
                           self.color_net.params.detach().to(torch.float16).contiguous())
             self._desc = None
         elif stale:
-            with torch.no_grad():
-                self._half[0].copy_(self.encoder.params.detach())
-                self._half[1].copy_(self.color_net.params.detach())
+            if dirty != "frags" or self._half_key != key:   # ("frags": the optimiser step wrote the fp16 copy itself)
+                with torch.no_grad():
+                    self._half[0].copy_(self.encoder.params.detach())
+                    self._half[1].copy_(self.color_net.params.detach())
             if self._desc is not None and getattr(self, "_frags", None) is not None:
                 _lib.check(_lib.lib().ia_field_prepare(C.byref(self._desc), _lib.ptr(self._frags), _lib.stream()), "ia_field_prepare")
         self._half_key = key

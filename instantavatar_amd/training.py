@@ -218,19 +218,26 @@ def field_autograd(net, x, n_dev=None):
     return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net, n_dev)
 
 
+def _nerf_loss_kernel(rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg, poison=None):
+    """`ia_nerf_loss`: (out5 = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density}, d_rgb, d_alpha, d_weight), flat"""
+    r, a, w = (t.detach().reshape(-1).float().contiguous() for t in (rgb, alpha, weight))
+    tr, ta = tgt_rgb.detach().reshape(-1).float().contiguous(), tgt_alpha.detach().reshape(-1).float().contiguous()
+    out = torch.zeros(5, device=r.device)
+    d_r, d_a, d_w = torch.empty_like(r), torch.empty_like(a), torch.empty_like(w)
+    pz = poison.detach().reshape(()).float().contiguous() if poison is not None else None
+    _lib.check(_lib.lib().ia_nerf_loss(_lib.ptr(r), _lib.ptr(tr), _lib.ptr(a), _lib.ptr(ta), _lib.ptr(w), a.numel(),
+                                       w.numel(), w_rgb, w_alpha, w_reg, _lib.ptr(pz), _lib.ptr(out), _lib.ptr(d_r), _lib.ptr(d_a),
+                                       _lib.ptr(d_w), _lib.stream()), "ia_nerf_loss")
+    return out, d_r, d_a, d_w
+
+
 class _NeRFLossFn(torch.autograd.Function):
     """Value + gradient of NeRFLoss from one HIP kernel (`ia_nerf_loss`)."""
 
     @staticmethod
     def forward(ctx, rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg):
         shapes = rgb.shape, alpha.shape, weight.shape
-        r, a, w = (t.detach().reshape(-1).float().contiguous() for t in (rgb, alpha, weight))
-        tr, ta = tgt_rgb.detach().reshape(-1).float().contiguous(), tgt_alpha.detach().reshape(-1).float().contiguous()
-        out = torch.zeros(5, device=r.device)
-        d_r, d_a, d_w = torch.empty_like(r), torch.empty_like(a), torch.empty_like(w)
-        _lib.check(_lib.lib().ia_nerf_loss(_lib.ptr(r), _lib.ptr(tr), _lib.ptr(a), _lib.ptr(ta), _lib.ptr(w), a.numel(),
-                                           w.numel(), w_rgb, w_alpha, w_reg, _lib.ptr(out), _lib.ptr(d_r), _lib.ptr(d_a),
-                                           _lib.ptr(d_w), _lib.stream()), "ia_nerf_loss")
+        out, d_r, d_a, d_w = _nerf_loss_kernel(rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg)
         ctx.save_for_backward(d_r, d_a, d_w)
         ctx.shapes = shapes
         ctx.mark_non_differentiable(out)
@@ -258,6 +265,20 @@ class NeRFLoss(torch.nn.Module):
         self.w_alpha = _opt.get(opt, "w_alpha", 0.1)
         self.w_reg = _opt.get(opt, "w_reg", 0.1)
         self.fused = fused
+
+    def direct_backward_ok(self, predicts):
+        """the loss is exactly the kernel's five terms (no LPIPS / depth term active): `value_and_grads` may replace autograd"""
+        return bool(self.fused) and predicts["rgb_coarse"].is_cuda and type(self).forward is NeRFLoss.forward
+
+    def value_and_grads(self, predicts, targets, poison=None):
+        """The losses (detached) and d loss / d (rgb_coarse, alpha_coarse, weight_coarse) straight from the kernel: the caller
+        seeds autograd with them (`torch.autograd.backward(outputs, grads)`) instead of building loss -> mul -> backward out of
+        nine small launches.  poison: device scalar, > 0 = NaN loss and gradients (see `ia_nerf_loss`)."""
+        r, a, w = predicts["rgb_coarse"], predicts["alpha_coarse"], predicts["weight_coarse"]
+        out, d_r, d_a, d_w = _nerf_loss_kernel(r, a, w, targets["rgb"], targets["alpha"], float(self.w_rgb), float(self.w_alpha),
+                                               float(self.w_reg), poison=poison)
+        losses = {"mse_loss": out[1], "loss_alpha_coarse": out[2], "reg_alpha": out[3], "reg_density": out[4], "loss": out[0]}
+        return losses, (d_r.reshape(r.shape), d_a.reshape(a.shape), d_w.reshape(w.shape))
 
     def forward(self, predicts, targets):
         if self.fused and predicts["rgb_coarse"].is_cuda:
@@ -303,6 +324,11 @@ class NGPLoss(NeRFLoss):
             for p in self.lpips.parameters():
                 p.requires_grad = False                                            # loss.py:12
 
+    def direct_backward_ok(self, predicts):
+        patches = predicts["rgb_coarse"].dim() == 5
+        extra = patches and (self.w_lpips > 0 or self.w_depth_reg > 0)
+        return bool(self.fused) and predicts["rgb_coarse"].is_cuda and not extra and type(self).forward is NGPLoss.forward
+
     def forward(self, predicts, targets):
         losses = super().forward(predicts, targets)
         patches = predicts["rgb_coarse"].dim() == 5
@@ -336,7 +362,18 @@ def configure_optimizer(model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, smpl_lr=5e
     # always three groups, the SMPL one possibly empty: that is what DNeRF.py:46-50 builds, and an optimiser state saved
     # by the reference (Lightning's `optimizer_states`) only loads into an optimiser with the same number of groups
     groups = [{"params": enc}, {"params": rest}, {"params": body, "lr": smpl_lr}]
-    opt = torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps, fused=bool(enc and enc[0].is_cuda))
+    if enc and enc[0].is_cuda:
+        # one C-ABI call per step for all groups: non-finite check, Adam, fp16 copy of the field parameters, gradient zero-fill
+        # (optim.FusedAdam -> ia_adam_step; same state / state_dict layout as torch.optim.Adam)
+        from .optim import FusedAdam
+        opt = FusedAdam(groups, lr=lr, betas=betas, eps=eps)
+        net = getattr(model, "net_coarse", None)
+        if net is not None and hasattr(net, "half_shadow"):
+            opt.register_shadow(net.encoder.params, lambda: net.half_shadow(0))
+            opt.register_shadow(net.color_net.params, lambda: net.half_shadow(1))
+            opt._shadow_owner = net
+    else:   # (no GPU: the host-side tests of the training loop and of the multi-rank plumbing)
+        opt = torch.optim.Adam(groups, lr=lr, betas=betas, eps=eps)
     return opt
 
 
@@ -385,6 +422,10 @@ def optimizer_step_skip_non_finite(optimizer, params, extra_flag=None):
     52 MB table (the per-call gradient scale S = 1024 / amax turns a single NaN into NaN everywhere).
     Non-fused optimisers (CPU tests) fall back to a host check.  Returns the flag (device scalar), which also covers
     `extra_flag` (device scalar, optional): a step whose training render dropped candidates is skipped the same way."""
+    from .optim import FusedAdam
+    if isinstance(optimizer, FusedAdam):
+        optimizer.step(skip_flag=extra_flag)
+        return optimizer.found_inf
     flag = _non_finite_flag(params)
     if extra_flag is not None and flag is not None:
         # a second device-side reason to skip the update (a training render whose candidates overflowed their capacity)
@@ -478,19 +519,31 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
             predicts = model.forward(batch, eval_mode=False, noise=1 if use_noise else 0)
         finally:
             model.renderer.train_draws = None
-        losses = loss_fn(predicts, batch)
-        if reg is not None and not is_refine:
-            losses["reg"] = reg
-            losses["loss"] = losses["loss"] + reg
-        optimizer.zero_grad(set_to_none=True)
-        total = losses["loss"]
         overflow = getattr(model.renderer, "train_overflow_flag", None)
-        if overflow is not None:
-            # a render that dropped candidates (capacity overflow) must not update anything, on ANY rank: its loss is turned
-            # into NaN before the backward pass, so every gradient of this rank is NaN, the gradient average carries that to
-            # all ranks, and the ordinary non-finite check skips the step everywhere -- no extra collective, no host read
-            total = total * torch.where(overflow > 0, torch.full_like(overflow, float("nan")), torch.ones_like(overflow))
-        total.backward()
+        with_reg = reg is not None and not is_refine
+        direct = (not with_reg) and hasattr(loss_fn, "direct_backward_ok") and loss_fn.direct_backward_ok(predicts) and \
+            all(torch.is_tensor(predicts.get(k)) and predicts[k].requires_grad for k in ("rgb_coarse", "alpha_coarse", "weight_coarse"))
+        # a render that dropped candidates (capacity overflow) must not update anything, on ANY rank: its loss is turned
+        # into NaN before the backward pass, so every gradient of this rank is NaN, the gradient average carries that to
+        # all ranks, and the ordinary non-finite check skips the step everywhere -- no extra collective, no host read
+        if direct:
+            # the loss kernel already holds d loss / d (rgb, alpha, weights): seed autograd with them (and let the kernel do the
+            # NaN poisoning) instead of loss -> where -> mul -> backward -> foreach_mul: nine small launches less per step
+            losses, grads = loss_fn.value_and_grads(predicts, batch, poison=overflow)
+        else:
+            losses = loss_fn(predicts, batch)
+            if with_reg:
+                losses["reg"] = reg
+                losses["loss"] = losses["loss"] + reg
+        if not getattr(optimizer, "grads_zeroed", False):   # (a FusedAdam step with fused_zero_grad left every buffer zero-filled)
+            optimizer.zero_grad(set_to_none=True)
+        if direct:
+            torch.autograd.backward([predicts["rgb_coarse"], predicts["alpha_coarse"], predicts["weight_coarse"]], list(grads))
+        else:
+            total = losses["loss"]
+            if overflow is not None:
+                total = total * torch.where(overflow > 0, torch.full_like(overflow, float("nan")), torch.ones_like(overflow))
+            total.backward()
         all_reduce_grads(model, world_size, reducer)
     finally:
         parallel.set_current_reducer(None)
@@ -500,7 +553,12 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
     if overflow is not None:
         losses["skipped_overflow"] = overflow
     if hasattr(model.net_coarse, "mark_updated"):
-        model.net_coarse.mark_updated()  # refresh the fp16 shadow + MFMA fragments on next use
+        # refresh the fp16 shadow + MFMA fragments on next use (the fused optimiser step has already written the shadow of
+        # the network it was configured for: only the fragment image is rebuilt then)
+        if getattr(optimizer, "_shadow_owner", None) is model.net_coarse:
+            model.net_coarse.mark_updated(shadow_fresh=True)
+        else:
+            model.net_coarse.mark_updated()
     if not _capturing:
         model.global_step += 1
     # nothing the caller gets keeps the autograd graph of this step alive (see SNARFDeformer.release_graph)
@@ -547,6 +605,9 @@ class GraphedTrainStep:
             # query -- fit stage -- reads validity counts on the host and inverts 6 890 vertex transforms with the LU library)
             fused = getattr(model.deformer, "fused_train_route", None)
             self.enabled = self.enabled and fused is not None and getattr(model.deformer.deformer, "version", 1) == 1
+        from .optim import FusedAdam
+        if isinstance(optimizer, FusedAdam):
+            optimizer.fused_zero_grad = True    # the step leaves every gradient buffer zero-filled for the next one
         self.graphs = {}
         self.inputs = None
         self.replays = 0
@@ -563,6 +624,10 @@ class GraphedTrainStep:
         return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v) and v.is_cuda)
 
     def _make_capturable(self):
+        from .optim import FusedAdam
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.capturable_lr()
+            return
         for g in self.optimizer.param_groups:
             if not g.get("fused"):
                 raise RuntimeError("GraphedTrainStep needs the fused Adam of configure_optimizer")
@@ -577,7 +642,14 @@ class GraphedTrainStep:
         m, r = self.model, self.model.renderer
         self._make_capturable()
         if hasattr(m.net_coarse, "mark_updated"):
-            m.net_coarse.mark_updated()   # the fp16 shadow refresh belongs to every replay
+            # the refresh of the kernel-side weight copies belongs to every replay: the MFMA fragment image only when the
+            # optimiser step writes the fp16 shadow itself (FusedAdam), both fp32 -> fp16 casts otherwise
+            if getattr(m.net_coarse, "_dirty", False) is True:
+                m.net_coarse.refresh()          # (a pending FULL refresh -- checkpoint load, broadcast -- runs now, eagerly)
+            if getattr(self.optimizer, "_shadow_owner", None) is m.net_coarse:
+                m.net_coarse.mark_updated(shadow_fresh=True)
+            else:
+                m.net_coarse.mark_updated()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         r._graph_capture = True
@@ -672,11 +744,17 @@ class GraphedTrainStep:
                     torch.cuda.synchronize()
                 self.eager_steps += 1
                 return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
+        if getattr(m.net_coarse, "_dirty", False) is True and getattr(self.optimizer, "_shadow_owner", None) is m.net_coarse:
+            m.net_coarse.refresh()   # weights changed behind the optimiser's back (checkpoint load, broadcast): the captured step only
+                                     # rebuilds the fragment image, the fp16 copy is brought up to date here
         entry["graph"].replay()
         self.replays += 1
         for p, g in zip(entry["params"], entry["grads"]):
             p.grad = g
         if hasattr(m.net_coarse, "mark_updated"):
-            m.net_coarse.mark_updated()
+            if getattr(self.optimizer, "_shadow_owner", None) is m.net_coarse:
+                m.net_coarse.mark_updated(shadow_fresh=True)
+            else:
+                m.net_coarse.mark_updated()
         m.global_step += 1
         return entry["out"]

@@ -610,3 +610,38 @@ def pack_rgba8(rgb, alpha):
     undefined; the reference's images stay inside but for an ulp).  rgb [...,3], alpha [...] -> uint8 [...,4]."""
     img = np.concatenate([_f32(rgb), _f32(alpha)[..., None]], axis=-1)
     return (np.clip(img, np.float32(0), np.float32(1)) * np.float32(255)).astype(np.uint8)
+
+
+# ---- optimiser step (DNeRF.py:46-50, :151-159) -----------------------------------------------------------------------
+def _fma32(a, b, c):
+    """fused multiply-add of float32 arrays: the product of two float32 values is exact in float64; the sum is rounded to
+    float64 and then to float32 (a double rounding that can differ from a true FMA only when the float64 sum lands exactly on a
+    float32 tie: not observed on the test vectors)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def adam_step(params, grads, state, lrs, betas=(0.9, 0.99), eps=1e-15, skip=False):
+    """`self.scaler.step(optimizer)` of DNeRFModel.training_step (DNeRF.py:151-159) for `torch.optim.Adam` (DNeRF.py:46-50),
+    restated from torch/optim/adam.py `_single_tensor_adam` (no weight decay, no amsgrad) in float32 with IEEE sqrt / division
+    and the two fused multiply-adds of torch's vectorised CPU kernels (lerp, addcmul):
+        any gradient element inf / NaN (GradScaler's check)  or  skip  ->  nothing changes, returns True
+        step += 1;  m = fma(g - m, 1 - b1, m);  v = fma((1 - b2) g, g, b2 v)
+        denom = sqrt(v) / sqrt(1 - b2^step) + eps;   p = p + (-(lr / (1 - b1^step)) m) / denom
+    params / grads: lists of float32 arrays (updated in place); state: list of dicts {step, exp_avg, exp_avg_sq}; lrs: one
+    learning rate per tensor (the parameter groups).  Returns found_inf."""
+    f32 = np.float32
+    found = bool(skip) or any(not np.isfinite(g).all() for g in grads)
+    if found:
+        return True
+    b1, b2 = betas
+    for p, g, st, lr in zip(params, grads, state, lrs):
+        st["step"] = float(st["step"]) + 1.0
+        t = st["step"]
+        m, v = st["exp_avg"], st["exp_avg_sq"]
+        m[...] = _fma32(g - m, f32(1 - b1), m)
+        v[...] = _fma32((f32(1 - b2) * g).astype(f32), g, (f32(b2) * v).astype(f32))
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        neg_step = f32(-(float(lr) / bc1))
+        denom = ((np.sqrt(v) / f32(bc2 ** 0.5)).astype(f32) + f32(eps)).astype(f32)
+        p[...] = (p + ((neg_step * m).astype(f32) / denom).astype(f32)).astype(f32)
+    return False

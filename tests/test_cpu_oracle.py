@@ -468,6 +468,17 @@ def test_driver_config_and_checkpoint_io(tmp_path):
     d = cfg.load_group(confs, "deformer", "fast_snarf", {"dataset": {"gender": "female"}, "train": {"precision": 32}})
     assert d["gender"] == "female" and d["opt"]["precision"] == 32 and d["opt"]["resolution"] == 128
     assert cfg.resolve("out/${a.b}/x${a.c}", {"a": {"b": "s", "c": 3}}) == "out/s/x3"
+    # every deformer group the reference ships (confs/deformer/{fast_snarf,fast_snarf_debug,smpl}.yaml), re-pointed `_target_`
+    body_model = None
+    from instantavatar_amd.deformers.smplx import SMPL
+    body_model = SMPL.from_dict(syn.make_body())
+    for name, cls, version in (("fast_snarf", "SNARFDeformer", 1), ("fast_snarf_debug", "SNARFDeformer", 2), ("smpl", "SMPLDeformer", None)):
+        dd = cfg.load_group(confs, "deformer", name, {"dataset": {"gender": "male"}, "train": {"precision": 32}})
+        assert dd["_target_"].startswith("instantavatar_amd.deformers.") and dd["gender"] == "male"
+        obj = cfg.instantiate(dd, body_model=body_model)            # (a pre-built body model: the SMPL pickles are not shipped)
+        assert type(obj).__name__ == cls
+        if version is not None:
+            assert dd["opt"].get("version", 1) == version and obj.deformer.version == version      # deformer_torch.py:32 `opt.get("version", 1)`
     net = cfg.instantiate(cfg.load_group(confs, "network", "ngp", {}))
     ren = cfg.instantiate(cfg.load_group(confs, "renderer", "raymarcher_acc", {}))
     assert type(net).__name__ == "NeRFNGPNet" and ren.MAX_BATCH_SIZE == 291600
@@ -1487,3 +1498,38 @@ def test_search_kernel_isa_has_no_dpp_read_after_valu_write_hazard():
     n_dpp = sum(1 for l in isa if "_dpp" in l or "quad_perm:" in l)
     assert n_dpp >= 72, n_dpp                                                                                 # 3 kernels x 24 DPP adds at least
     assert A.dpp_hazards(isa) == []
+
+
+def test_adam_oracle_matches_torch_adam_over_twenty_steps_with_a_skipped_one(oracle):
+    """oracle.adam_step (what `ia_adam_step` is checked against on the GPU) vs `torch.optim.Adam` on the CPU -- the optimiser of
+    DNeRF.py:46-50 with the reference's three parameter groups and hyper-parameters -- over 20 steps of which one carries an inf
+    gradient (GradScaler's skip, DNeRF.py:151-154: parameters, moments and step counters untouched).  Moments are bit-equal;
+    parameters agree to the rounding of torch's CPU sqrt (Sleef's, not correctly rounded: ~0.5 % of the elements differ in the
+    last bit of one step's update)."""
+    rs = np.random.RandomState(0)
+    shapes, lrs = [(40003,), (64, 16), (7, 72)], [1e-2, 1e-2, 1e-5]
+    P = [torch.nn.Parameter(torch.as_tensor(rs.randn(*s).astype(np.float32) * 0.1)) for s in shapes]
+    opt = torch.optim.Adam([{"params": [P[0]]}, {"params": [P[1]]}, {"params": [P[2]], "lr": lrs[2]}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    p = [q.detach().numpy().copy() for q in P]
+    st = [dict(step=0.0, exp_avg=np.zeros(s, np.float32), exp_avg_sq=np.zeros(s, np.float32)) for s in shapes]
+    n_steps = 20
+    for k in range(n_steps):
+        g = [(rs.randn(*s) * 10.0 ** rs.uniform(-7, 0)).astype(np.float32) for s in shapes]
+        for a in g:
+            a.reshape(-1)[::5] = 0
+        bad = k == 7
+        if bad:
+            g[1].reshape(-1)[3] = np.inf
+        before = [a.copy() for a in p]
+        assert oracle.adam_step(p, [a.copy() for a in g], st, lrs) == bad
+        if bad:
+            assert all(np.array_equal(a, b) for a, b in zip(p, before)) and st[0]["step"] == 7.0
+            continue
+        for q, a in zip(P, g):
+            q.grad = torch.as_tensor(a.copy())
+        opt.step()
+    for q, a, s, lr in zip(P, p, st, lrs):
+        assert float(opt.state[q]["step"]) == s["step"] == n_steps - 1
+        assert np.array_equal(opt.state[q]["exp_avg"].numpy(), s["exp_avg"]) and np.array_equal(opt.state[q]["exp_avg_sq"].numpy(), s["exp_avg_sq"])
+        d = np.abs(q.detach().numpy() - a)
+        assert (d <= n_steps * lr * 2.4e-7 + 1.2e-7 * np.abs(a)).all() and (d > 0).mean() < 0.02, (float(d.max()), float((d > 0).mean()))

@@ -164,12 +164,18 @@ def test_smpl_deformer_prepare_small_ops_equals_library_route_values_and_gradien
                           {k: v.grad.detach().cpu().numpy().copy() for k, v in leaf.items()})
     (T1, v1, w1_, g1), (T0, v0, w0_, g0) = res[True], res[False]
     assert np.abs(T1 - T0).max() < 5e-5 and np.abs(v1 - v0).max() < 2e-5 and np.abs(w1_ - w0_).max() < 1e-5
+    scale = max(np.linalg.norm(v) for v in g0.values())
     for k in g0:
         a, b = g1[k].astype(np.float64).reshape(-1), g0[k].astype(np.float64).reshape(-1)
         cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
         rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
         print("d %-13s |g| %.3e  cos %.8f  rel %.2e" % (k, np.linalg.norm(b), cos, rel))
-        assert np.linalg.norm(b) > 1e-3 and cos > 0.999999 and rel < 1e-3, (k, cos, rel)
+        if k in ("global_orient", "transl"):
+            # T_inv and the vertices live in the SMPL-root frame: analytically independent of the root orientation and the
+            # translation -- both routes return rounding noise (measured 1.4e-4 against |d body_pose| = 360)
+            assert np.linalg.norm(a) < 1e-5 * scale and np.linalg.norm(b) < 1e-5 * scale, (k, np.linalg.norm(a), np.linalg.norm(b))
+        else:
+            assert np.linalg.norm(b) > 1e-3 and cos > 0.999999 and rel < 1e-4, (k, cos, rel)
 
 
 def test_fit_step_on_a_blend_shape_subject_moves_betas():

@@ -119,3 +119,45 @@ def test_train_and_fit_drivers_under_a_two_rank_launch(tmp_path):
     out = str(tmp_path / "fit")
     text = _run("instantavatar_amd.drivers.fit", ["--synthetic", "--steps", "24", "--res", "96", "--out", out], ranks=2)
     assert "2 rank(s)" in text and os.path.exists(os.path.join(out, "poses", "train.npz"))
+
+
+def test_animate_driver_renders_a_batch_of_subjects_one_per_rank(tmp_path):
+    """BASELINE config 5 ("batch of subjects, one per GPU"): `--subjects` hands rank r the r-th subject -- its own weights /
+    betas / output directory -- and every rank renders the WHOLE sequence as an independent replica (no frame sharding, no
+    data-path collective).  Two synthetic subjects (two seeds) under a 2-rank launch: each directory holds all frames, the two
+    subjects differ, and subject 0's files equal a 1-rank run of that subject alone."""
+    import json
+    subj = str(tmp_path / "subjects.json")
+    outs = [str(tmp_path / "s0"), str(tmp_path / "s1")]
+    json.dump([{"seed": 42, "out": outs[0]}, {"seed": 43, "out": outs[1]}], open(subj, "w"))
+    common = ["--synthetic", "--max-frames", "4", "--downscale", "8", "--jitter-seed", "5", "--no-gif"]
+    text = _run("instantavatar_amd.drivers.animate", common + ["--subjects", subj, "--out", str(tmp_path / "unused")], ranks=2)
+    assert "rendered 8 frames of 2 subject replica(s)" in text, text
+    alone = str(tmp_path / "alone")
+    _run("instantavatar_amd.drivers.animate", common + ["--seed", "42", "--out", alone])
+    names = sorted("%d.png" % i for i in range(4))
+    assert sorted(os.listdir(outs[0])) == sorted(os.listdir(outs[1])) == sorted(os.listdir(alone)) == names
+    for f in names:
+        a, b, c = (open(os.path.join(d, f), "rb").read() for d in (outs[0], outs[1], alone))
+        assert a == c and a != b, f
+
+
+def test_train_driver_takes_a_pre_decoded_sequence(tmp_path):
+    """`drivers.train --frames seq.npz`: the arrays peoplesnapshot.py:99-151 reads from image files (uint8 images, masks, K, the
+    SMPL parameters of anim_nerf_train.npz) as one npz -> DeviceFrames + the confs/sampler group + the plugins from confs/ (the
+    reference's Hydra run without Hydra); it trains (the loss falls), validates on a whole frame and writes a checkpoint."""
+    from instantavatar_amd.drivers import fit as fit_driver
+    frames, body_model, true = fit_driver.synthetic_frames(torch.device(DEV), res=128, n_frames=4, noise=0.0, patch=32)
+    K = np.array([[2000.0 * 128 / 1080, 0, 64], [0, 2000.0 * 128 / 1080, 64], [0, 0, 1]])
+    seq = str(tmp_path / "seq.npz")
+    np.savez(seq, images=frames.images.cpu().numpy(), masks=frames.masks.cpu().numpy(), K=K, **{k: v for k, v in true.items()})
+    ckpt = str(tmp_path / "ck" / "last.ckpt")
+    text = _run("instantavatar_amd.drivers.train", ["--frames", seq, "--synthetic-body", "--sampler", "patch", "--steps", "120", "--ckpt", ckpt])
+    assert "4 frames 128x128" in text and "PatchSampler" in text and "saved " in text, text
+    mse = [float(x) for x in re.findall(r"mse ([0-9.]+)", text)]
+    val = [float(x) for x in re.findall(r"val/rgb_loss ([0-9.]+)", text)]
+    print("train --frames: mse", mse, "val", val)
+    assert len(mse) >= 2 and np.isfinite(mse).all() and mse[-1] < mse[0] and val and np.isfinite(val).all(), text
+    assert torch.load(ckpt, weights_only=False)["global_step"] == 120
+    with pytest.raises(AssertionError):
+        _run("instantavatar_amd.drivers.train", ["--steps", "1"])          # neither --synthetic nor --frames

@@ -16,6 +16,6 @@ print("wall per step %.3f ms, gpu busy per step %.3f ms, launches per step %.1f"
 d=collections.defaultdict(lambda:[0,0.0])
 for r in rows[a:b]:
     n=r['Kernel_Name'].split('(')[0][:70]; d[n][0]+=1; d[n][1]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-for k,v in sorted(d.items(),key=lambda x:-x[1][1])[:22]:
+for k,v in sorted(d.items(),key=lambda x:-x[1][1])[:48]:
     print(f"{k:70s} {v[0]/20:6.1f}/step {v[1]/20:8.1f} us/step")
 PY
