@@ -53,8 +53,12 @@ class _CompositeTrainFn(torch.autograd.Function):
         n, S = st["n"], st["S"]
         cand_rgb, cand_sigma = cand_rgb.contiguous(), cand_sigma.contiguous()
         cap = st["s_z"].shape[0]
+        from ..training import pooled_zeros
         color, depth, alpha = torch.empty((n, 3), device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
-        weights = torch.zeros((n, S), device=dev)  # the kernel writes the occupied slots only
+        weights = pooled_zeros((n, S), dev)  # the kernel writes the occupied slots only
+        # the zero-initialised gradient buffers of the backward pass, taken now from the step's zero pool (one fill launch for all)
+        ctx.d_bufs = (pooled_zeros((cand_sigma.shape[0], 3), dev), pooled_zeros((cand_sigma.shape[0],), dev))
+        ctx.set_materialize_grads(False)   # an unused output (depth) arrives as None, not as a freshly filled zero tensor
         sv = dict(arg=torch.empty(cap, dtype=torch.int32, device=dev), sigma=torch.empty(cap, device=dev),
                   alpha=torch.empty(cap, device=dev), T=torch.empty(cap, device=dev))
         _lib.check(L.ia_composite_train_fwd(_lib.ptr(cand_rgb), _lib.ptr(cand_sigma), cand_sigma.shape[0],
@@ -77,8 +81,10 @@ class _CompositeTrainFn(torch.autograd.Function):
         dev = cand_rgb.device
         c = lambda t: None if t is None else t.float().contiguous()
         d_color, d_depth, d_alpha, d_weights = c(d_color), c(d_depth), c(d_alpha), c(d_weights)
-        d_rgb = torch.zeros((ctx.n_cand, 3), device=dev)
-        d_sig = torch.zeros(ctx.n_cand, device=dev)
+        bufs, ctx.d_bufs = getattr(ctx, "d_bufs", None), None
+        if bufs is None:       # (a second backward through the same graph: fresh buffers)
+            bufs = (torch.zeros((ctx.n_cand, 3), device=dev), torch.zeros(ctx.n_cand, device=dev))
+        d_rgb, d_sig = bufs
         _lib.check(L.ia_composite_train_bwd(_lib.ptr(d_color), _lib.ptr(d_depth), _lib.ptr(d_alpha), _lib.ptr(d_weights),
                                             _lib.ptr(cand_rgb), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]), _lib.ptr(st["s_z"]),
                                             _lib.ptr(st["near"]), _lib.ptr(st["far"]), st["n"], st["S"], _lib.ptr(st["bg"]),
@@ -244,7 +250,11 @@ class Raymarcher(torch.nn.Module):
                   bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
                   noise=(draws["noise"].to(dev).float().reshape(n, S).contiguous() if "noise" in draws else torch.randn((n, S), device=dev))
                   if noise > 0 else None, noise_scale=float(noise))                # :167
-        from ..training import field_autograd
+        from ..training import ZeroPool, field_autograd
+        if torch.is_grad_enabled():
+            # ONE zero-fill for the step's zero-initialised work tensors (closed by training_step): field outputs [V,3] + [V],
+            # dense weights [n,S], the compositor's candidate gradients [V,3] + [V], the loss values, + alignment slack
+            ZeroPool.current = ZeroPool(8 * cand_cap + n * S + 1024, dev)
         # (SMPL refinement: the candidates carry the implicit-differentiation gradient to tfs, deformer_torch.py:50-67)
         rgb_c, sig_c = field_autograd(net, deformer.candidates_with_grad(sc), n_dev=sc["n_cand"])
         self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)

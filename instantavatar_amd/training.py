@@ -27,6 +27,39 @@ from .deformers import _opt
 _MM_OUT_DTYPE = [None]
 
 
+class ZeroPool:
+    """The zero-initialised fp32 work tensors of ONE training step (field outputs past the live count, the dense weight
+    tensor the compositor fills sparsely, the candidate-gradient buffers of its backward, the five loss values) as slices of
+    ONE buffer zero-filled by ONE launch: each of these was its own ~5 us fill kernel in a 2 ms step.  `Raymarcher.
+    render_train_fused` opens the pool (it knows the sizes), `training_step` closes it; outside a pool -- and for requests
+    the pool cannot serve -- `pooled_zeros` is `torch.zeros`."""
+    current = None
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(int(numel), device=device)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        if self.off + n > self.buf.numel():
+            return None
+        out = self.buf[self.off:self.off + n].view(*shape)
+        self.off += (n + 63) // 64 * 64          # 256-byte aligned slices
+        return out
+
+
+def pooled_zeros(shape, device):
+    shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+    pool = ZeroPool.current
+    if pool is not None and pool.buf.device == torch.device(device):
+        t = pool.take(shape)
+        if t is not None:
+            return t
+    return torch.zeros(shape, device=device)
+
+
 def _mm_f32(a, b):
     """fp16 x fp16 -> fp32 GEMM (MFMA, fp32 accumulate and output): aten::mm.dtype where the
     backend provides it, fp32 GEMM otherwise."""
@@ -51,9 +84,9 @@ class _FieldFn(torch.autograd.Function):
         V = xc.shape[0]
         stride = L.ia_field_act_stride(net.n_levels)
         acts = torch.empty((V, stride), device=x.device, dtype=torch.float16)
-        alloc = torch.zeros if n_dev is not None else torch.empty
+        alloc = pooled_zeros if n_dev is not None else (lambda shp, device: torch.empty(shp, device=device))
         rgb = alloc((V, 3), device=x.device)
-        sigma = alloc(V, device=x.device)
+        sigma = alloc((V,), device=x.device)
         _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, _lib.ptr(n_dev), C.byref(net.field_desc(V)), _lib.ptr(rgb),
                                         _lib.ptr(sigma), _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
         ctx.net = net
@@ -222,7 +255,7 @@ def _nerf_loss_kernel(rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_
     """`ia_nerf_loss`: (out5 = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density}, d_rgb, d_alpha, d_weight), flat"""
     r, a, w = (t.detach().reshape(-1).float().contiguous() for t in (rgb, alpha, weight))
     tr, ta = tgt_rgb.detach().reshape(-1).float().contiguous(), tgt_alpha.detach().reshape(-1).float().contiguous()
-    out = torch.zeros(5, device=r.device)
+    out = pooled_zeros((5,), r.device)
     d_r, d_a, d_w = torch.empty_like(r), torch.empty_like(a), torch.empty_like(w)
     pz = poison.detach().reshape(()).float().contiguous() if poison is not None else None
     _lib.check(_lib.lib().ia_nerf_loss(_lib.ptr(r), _lib.ptr(tr), _lib.ptr(a), _lib.ptr(ta), _lib.ptr(w), a.numel(),
@@ -547,6 +580,7 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         all_reduce_grads(model, world_size, reducer)
     finally:
         parallel.set_current_reducer(None)
+        ZeroPool.current = None
     params = [p for g in optimizer.param_groups for p in g["params"]]
     model.renderer.train_overflow_flag = None
     losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params, extra_flag=overflow)
@@ -606,7 +640,7 @@ class GraphedTrainStep:
             fused = getattr(model.deformer, "fused_train_route", None)
             self.enabled = self.enabled and fused is not None and getattr(model.deformer.deformer, "version", 1) == 1
         from .optim import FusedAdam
-        if isinstance(optimizer, FusedAdam):
+        if isinstance(optimizer, FusedAdam) and self.enabled:
             optimizer.fused_zero_grad = True    # the step leaves every gradient buffer zero-filled for the next one
         self.graphs = {}
         self.inputs = None

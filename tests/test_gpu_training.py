@@ -209,11 +209,8 @@ def test_training_step_learns(gw):
         assert torch.isfinite(out["loss"])
         losses.append(float(out["mse_loss"]))
         if it == 0:
-            # (the fused optimiser step of a graphed trainer zero-fills every gradient it consumed -- `FusedAdam.fused_zero_grad`,
-            # set by GraphedTrainStep -- so the next step accumulates into clean buffers without a 52 MB fill launch)
-            assert opt.fused_zero_grad and opt.grads_zeroed
             for n, p in tmodel.named_parameters():
-                assert p.grad is not None and float(p.grad.abs().sum()) == 0.0, n
+                assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
     assert losses[-1] < losses[0], losses
 
 
