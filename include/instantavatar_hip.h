@@ -581,6 +581,36 @@ int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int
                             uint8_t *took_shared, void *stream);
 
 
+/* ---- SMPLDeformer's body model, forward and backward (deformers/smpl_deformer.py:32-77) ---------------------------
+ * Replaces, per frame / per fit step, the two smplx `SMPL.forward` evaluations of `SMPLDeformer.initialize` +
+ * `prepare_deformer` (body_models.py:289-372 -> lbs.py:152-250) and their two batched `torch.inverse` calls, and -- in the
+ * fit stage, where betas / pose / translation are optimised (DNeRF.py:113-128) -- their autograd:
+ *   fwd: betas [10], pose [72] (global_orient + body_pose, axis-angle), transl [3] (or NULL), pose_t [72] (the template pose
+ *        of :33-35), po_t [V,3] (pose-corrective offsets of the template pose: constant per subject)
+ *        -> T_inv [V,4,4] (:66-75), verts [V,3] posed vertices in the SMPL-root frame (:76), verts_t [V,3] template-pose
+ *        vertices (optional: `initialize`'s bounding box), w2s [4,4] (optional)
+ *   bwd: d_T_inv [V,4,4] (rows 0..2 are read), d_w2s [4,4] or NULL -> d_betas [10] (optional), d_pose [72], d_transl [3] (optional)
+ * ia_smpl_body: device pointers, constant per subject; J0 = J_regressor @ v_template [24,3] and JS = J_regressor @ shapedirs
+ * [24,3,10] fold the joint regression of lbs.py:190.  ws: ia_smpl_lbs_workspace_bytes(n_verts) bytes (scratch; the backward
+ * recomputes what it needs, nothing has to survive from the forward call).                                             */
+typedef struct ia_smpl_body {
+  const float *v_template;   /* [V,3]        */
+  const float *shapedirs;    /* [V,3,10]     */
+  const float *posedirs;     /* [207, V*3]   */
+  const float *lbs_weights;  /* [V,24]       */
+  const float *J0;           /* [24,3]       */
+  const float *JS;           /* [24,3,10]    */
+  const int32_t *parents;    /* [24]         */
+  int n_verts;
+} ia_smpl_body;
+size_t ia_smpl_lbs_workspace_bytes(int n_verts);
+int ia_smpl_lbs_fwd(const ia_smpl_body *body, const float *betas, const float *pose, const float *transl,
+                    const float *pose_t, const float *po_t, float *T_inv, float *verts, float *verts_t, float *w2s,
+                    void *ws, size_t ws_bytes, void *stream);
+int ia_smpl_lbs_bwd(const ia_smpl_body *body, const float *betas, const float *pose, const float *transl,
+                    const float *pose_t, const float *po_t, const float *d_T_inv, const float *d_w2s, float *d_betas,
+                    float *d_pose, float *d_transl, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- optimiser step (DNeRF.py:46-50, :151-159) ---------------------------------------------------------------------
  * One call replaces what the reference's `self.scaler.unscale_(optimizer); self.scaler.step(optimizer);
  * optimizer.zero_grad()` launch per step through torch: GradScaler's inf / NaN check over ALL gradients (any non-finite

@@ -44,6 +44,11 @@ class AdamTensor(C.Structure):
 
 IA_ADAM_MAX_TENSORS = 8
 
+
+class SmplBody(C.Structure):
+    _fields_ = [("v_template", C.c_void_p), ("shapedirs", C.c_void_p), ("posedirs", C.c_void_p), ("lbs_weights", C.c_void_p),
+                ("J0", C.c_void_p), ("JS", C.c_void_p), ("parents", C.c_void_p), ("n_verts", C.c_int)]
+
 _lib = None
 
 _VP = C.c_void_p
@@ -141,6 +146,9 @@ _SIGS = {
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "ia_pack_rgba8": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "ia_smpl_lbs_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ia_smpl_lbs_fwd": (C.c_int, [C.POINTER(SmplBody)] + [_VP] * 9 + [_VP, C.c_size_t, _VP]),
+    "ia_smpl_lbs_bwd": (C.c_int, [C.POINTER(SmplBody)] + [_VP] * 10 + [_VP, C.c_size_t, _VP]),
     "ia_adam_workspace_bytes": (C.c_size_t, []),
     "ia_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int, _VP, _VP, C.c_int, _VP, C.c_size_t, _VP]),
     "ia_selftest_shared_rcp": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),

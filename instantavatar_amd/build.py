@@ -22,7 +22,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libinstantavatar_hip.so")
-SOURCES = ["ia_error.cpp", "ia_snarf.hip", "ia_search.hip", "ia_field.hip", "ia_render.hip", "ia_prof.hip", "ia_voxelise.hip", "ia_loss.hip", "ia_smpl_nn.hip", "ia_data.hip", "ia_mesh.hip", "ia_optim.hip"]
+SOURCES = ["ia_error.cpp", "ia_snarf.hip", "ia_search.hip", "ia_field.hip", "ia_render.hip", "ia_prof.hip", "ia_voxelise.hip", "ia_loss.hip", "ia_smpl_nn.hip", "ia_data.hip", "ia_mesh.hip", "ia_optim.hip", "ia_smpl_lbs.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: fused multiply-adds appear only where the sources spell them
 # (IA_DOT3 / __builtin_fmaf), the same sequence the CPU checker uses

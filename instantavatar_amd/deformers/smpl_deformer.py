@@ -25,6 +25,64 @@ from .smplx import SMPL
 from .snarf_deformer import _abs_path, get_bbox_from_smpl
 
 
+#: the body model of `prepare_deformer` as the fused kernels `ia_smpl_lbs_fwd / _bwd` (csrc/ia_smpl_lbs.hip); False = the
+#: lbs.py-style torch ops under autograd (the checker of the kernels: tests/test_gpu_smpl_deformer.py)
+FUSED_LBS = True
+
+
+class _SmplLbsFn(torch.autograd.Function):
+    """`SMPLDeformer.initialize` + `prepare_deformer` (smpl_deformer.py:32-77) as two launches, differentiable w.r.t. betas, pose and
+    translation through four more -- what the reference obtains by running smplx's SMPL.forward twice under autograd (fit stage:
+    DNeRF.py:113-128).  Outputs: T_inv [1,V,4,4], vertices [1,V,3] (SMPL-root frame), w2s [1,4,4], template vertices [1,V,3]."""
+
+    @staticmethod
+    def forward(ctx, betas, body_pose, global_orient, transl, deformer):
+        smpl = deformer.body_model
+        body, keep = smpl.lbs_constants()
+        dev = keep["v_template"].device
+        V = body.n_verts
+        L = _lib.lib()
+        b = betas.detach().reshape(-1)[:10].float().contiguous()
+        pose = torch.cat([global_orient.detach().reshape(3), body_pose.detach().reshape(69)]).float().contiguous()
+        tr = transl.detach().reshape(3).float().contiguous() if transl is not None else None
+        pose_t, po_t = deformer._template_constants(dev)
+        ws = _lib.scratch(deformer, "_lbs_ws", L.ia_smpl_lbs_workspace_bytes(V), dev)
+        T_inv, verts = torch.empty((1, V, 4, 4), device=dev), torch.empty((1, V, 3), device=dev)
+        verts_t, w2s = torch.empty((1, V, 3), device=dev), torch.empty((1, 4, 4), device=dev)
+        _lib.check(L.ia_smpl_lbs_fwd(C.byref(body), _lib.ptr(b), _lib.ptr(pose), _lib.ptr(tr), _lib.ptr(pose_t), _lib.ptr(po_t), _lib.ptr(T_inv),
+                                     _lib.ptr(verts), _lib.ptr(verts_t), _lib.ptr(w2s), _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_smpl_lbs_fwd")
+        ctx.deformer = deformer
+        ctx.shapes = (betas.shape, body_pose.shape, global_orient.shape, None if transl is None else transl.shape)
+        ctx.save_for_backward(b, pose, tr if tr is not None else torch.empty(0, device=dev))
+        ctx.has_tr = tr is not None
+        ctx.mark_non_differentiable(verts, verts_t)     # nearest-vertex search and bounding boxes only (smpl_deformer.py:45-48,90)
+        ctx.set_materialize_grads(False)
+        return T_inv, verts, w2s, verts_t
+
+    @staticmethod
+    def backward(ctx, d_T_inv, _d_verts, d_w2s, _d_verts_t):
+        b, pose, tr = ctx.saved_tensors
+        d = ctx.deformer
+        body, keep = d.body_model.lbs_constants()
+        dev = b.device
+        V = body.n_verts
+        L = _lib.lib()
+        s_b, s_bp, s_go, s_tr = ctx.shapes
+        if d_T_inv is None and d_w2s is None:
+            return None, None, None, None, None
+        g = d_T_inv.reshape(V, 4, 4).float().contiguous() if d_T_inv is not None else torch.zeros((V, 4, 4), device=dev)
+        gw = d_w2s.reshape(4, 4).float().contiguous() if d_w2s is not None else None
+        pose_t, po_t = d._template_constants(dev)
+        ws = _lib.scratch(d, "_lbs_ws", L.ia_smpl_lbs_workspace_bytes(V), dev)
+        d_b, d_pose, d_tr = torch.empty(10, device=dev), torch.empty(72, device=dev), torch.empty(3, device=dev)
+        _lib.check(L.ia_smpl_lbs_bwd(C.byref(body), _lib.ptr(b), _lib.ptr(pose), _lib.ptr(tr) if ctx.has_tr else None, _lib.ptr(pose_t), _lib.ptr(po_t),
+                                     _lib.ptr(g), _lib.ptr(gw), _lib.ptr(d_b), _lib.ptr(d_pose), _lib.ptr(d_tr), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream()), "ia_smpl_lbs_bwd")
+        gb = torch.zeros(s_b, device=dev)
+        gb.reshape(-1)[:10] = d_b      # (betas [1,10]: the row in use)
+        return gb, d_pose[3:].reshape(s_bp), d_pose[:3].reshape(s_go), (d_tr.reshape(s_tr) if ctx.has_tr else None), None
+
+
 class SMPLDeformer():
     def __init__(self, model_path, gender, threshold=0.05, k=1, body_model=None) -> None:
         # body_model: optional pre-built SMPL (e.g. SMPL.from_dict(synthetic.make_body()))
@@ -49,6 +107,38 @@ class SMPLDeformer():
         self.vs_template = out.vertices
         self.pose_offset_t = out.pose_offsets
         self.shape_offset_t = out.shape_offsets
+        self._init_betas = betas.detach()
+
+    def _template_constants(self, device):
+        """(template pose [72], its pose-corrective offsets po_t [V,3]) on `device`: the template pose of :33-35 is a constant, so
+        its pose blend (pose_feature_t x posedirs) is one per subject"""
+        c = getattr(self, "_tmpl_const", None)
+        if c is None or c[0].device != torch.device(device):
+            from .smplx import batch_rodrigues
+            with torch.no_grad():
+                pose_t = torch.zeros(72, device=device)
+                pose_t[3 + 2], pose_t[3 + 5] = torch.pi / 6, -torch.pi / 6
+                rot = batch_rodrigues(pose_t.view(-1, 3))
+                pf = (rot[1:] - torch.eye(3, device=device)).reshape(1, -1)
+                po_t = torch.matmul(pf, self.body_model.posedirs.to(device)).view(-1, 3).float().contiguous()      # lbs.py:216-219
+            c = self._tmpl_const = (pose_t.contiguous(), po_t)
+        return c
+
+    def _fused_lbs_ok(self, betas):
+        """the fused kernels evaluate template and posed body with the SAME betas -- what the reference does (it re-initialises every
+        frame, smpl_deformer.py:57-61).  A caller who froze a template (`initialized = True`) with other betas gets the torch route."""
+        if not (FUSED_LBS and betas.is_cuda):
+            return False
+        if not self.initialized:
+            return True
+        ib = getattr(self, "_init_betas", None)
+        if ib is None:
+            return False
+        key = (betas.data_ptr(), betas._version, ib.data_ptr())
+        if getattr(self, "_betas_ok_key", None) != key:
+            self._betas_ok = bool(ib.shape == betas.shape and torch.equal(ib, betas.detach()))   # (host read: once per betas tensor)
+            self._betas_ok_key = key
+        return self._betas_ok
 
     def get_bbox_deformed(self):
         return get_bbox_from_smpl(self.vertices[0:1].detach())
@@ -58,6 +148,14 @@ class SMPLDeformer():
         device = smpl_params["betas"].device
         if next(self.body_model.buffers()).device != device:
             self.body_model = self.body_model.to(device)
+        if self._fused_lbs_ok(smpl_params["betas"]):
+            _lib.require_cuda(smpl_params["body_pose"])
+            T_inv, verts, w2s, verts_t = _SmplLbsFn.apply(smpl_params["betas"], smpl_params["body_pose"], smpl_params["global_orient"],
+                                                          smpl_params["transl"], self)
+            if not self.initialized:     # `initialize` (the reference re-runs it every frame: betas may change)
+                self.bbox = get_bbox_from_smpl(verts_t.detach())
+            self.T_inv, self.vertices, self.w2s = T_inv, verts, w2s
+            return
         if not self.initialized:
             self.initialize(smpl_params["betas"], device)  # the reference re-initialises every frame (betas may change)
         out = self.body_model(betas=smpl_params["betas"], body_pose=smpl_params["body_pose"],

@@ -142,6 +142,25 @@ class SMPL(nn.Module):
             "SMPL model not found (looked for %s). The SMPL pickles are licensed and not shipped; "
             "use SMPL.from_dict(instantavatar_amd.synthetic.make_body()) for synthetic runs." % cands)
 
+    # -- constants of the fused body-model kernels (`ia_smpl_lbs_fwd / _bwd`): per subject, per device -------------
+    def lbs_constants(self):
+        """(ia_smpl_body descriptor, tensors it points into): contiguous fp32 copies of the blend-shape arrays and the joint
+        regression folded into J0 = J_regressor v_template [24,3] and JS = J_regressor shapedirs [24,3,10] (lbs.py:190 applied to
+        v_template + shapedirs beta).  Cached; rebuilt when the module moved to another device."""
+        from .. import _lib
+        dev = self.v_template.device
+        c = getattr(self, "_lbs_const", None)
+        if c is None or c[1]["v_template"].device != dev:
+            with torch.no_grad():
+                keep = dict(v_template=self.v_template.float().contiguous(), shapedirs=self.shapedirs.float().contiguous(),
+                            posedirs=self.posedirs.float().contiguous(), lbs_weights=self.lbs_weights.float().contiguous(),
+                            J0=torch.matmul(self.J_regressor, self.v_template).float().contiguous(),
+                            JS=torch.einsum("ji,ikl->jkl", self.J_regressor, self.shapedirs).float().contiguous(),
+                            parents=self.parents.to(torch.int32).contiguous())
+            body = _lib.SmplBody(**{k: v.data_ptr() for k, v in keep.items()}, n_verts=int(self.v_template.shape[0]))
+            c = self._lbs_const = (body, keep)
+        return c
+
     # -- shaped rest joints: constant per subject, input of ia_smpl_tfs --------
     def rest_joints(self, betas):
         v_shaped = self.v_template + torch.einsum("bl,mkl->bmk", betas, self.shapedirs)[0]

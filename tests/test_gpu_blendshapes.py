@@ -135,47 +135,61 @@ def test_initialize_with_betas_matches_oracle_and_reference_python(oracle):
     assert (d > 1e-4).mean() < 4e-3 and np.median(d) < 1e-6, ((d > 1e-4).mean(), d.max())
 
 
-def test_smpl_deformer_prepare_small_ops_equals_library_route_values_and_gradients():
-    """SMPLDeformer.prepare_deformer under autograd (the fit stage's per-step path, smpl_deformer.py:50-77) on the blend-shape body:
-    the multiply + sum route (`small_ops=True`, what the product runs) against the library-GEMM route the reference's lbs.py
-    takes -- T_inv, posed vertices, w2s and the gradients of a random functional of them w.r.t. betas, body pose, orientation
-    and translation.  With zero blend shapes the betas / pose-offset terms of these gradients vanish; here they do not."""
+@pytest.mark.parametrize("blend", [True, False], ids=["blendshapes", "zero-blendshapes"])
+def test_smpl_deformer_prepare_three_routes_values_and_gradients(blend):
+    """SMPLDeformer.prepare_deformer under autograd (the fit stage's per-step path, smpl_deformer.py:32-77), three routes:
+      fused      `ia_smpl_lbs_fwd / _bwd` (what the product runs: 2 + 4 launches, csrc/ia_smpl_lbs.hip)
+      small_ops  SMPL.forward with its tiny GEMMs as multiply + sum, under autograd (round 5's route)
+      library    SMPL.forward with the library GEMMs / einsum of the reference's lbs.py, under autograd
+    T_inv, posed vertices, w2s, the template bounding box, and the gradients of a random functional of T_inv AND w2s (the ray
+    frame: transform_rays_w2s is differentiable in the reference) w.r.t. betas, body pose, root orientation and translation.
+    With zero blend shapes the betas / pose-offset terms of these gradients vanish; on the blend-shape body they do not."""
+    from instantavatar_amd.deformers import smpl_deformer as sdm
     from instantavatar_amd.deformers.smpl_deformer import SMPLDeformer
-    body = syn.make_body(blendshapes=True)
+    body = syn.make_body(blendshapes=blend)
+    betas0 = syn.BLEND_BETAS if blend else np.zeros(10, np.float32)
     poses, tr = W.poses()
     res = {}
-    for small_ops in (True, False):
+    for route in ("fused", "small_ops", "library"):
         smpl = SMPL.from_dict(body).to(DEV)
-        if not small_ops:   # the library route: SMPL.forward's default
+        if route == "library":   # SMPL.forward's default
             fwd = smpl.forward
             smpl.forward = lambda *a, **k: fwd(*a, **{**k, "small_ops": False})
         d = SMPLDeformer(None, "neutral", threshold=0.05, k=1, body_model=smpl)
-        leaf = {"betas": torch.tensor(syn.BLEND_BETAS[None], device=DEV, requires_grad=True),
+        leaf = {"betas": torch.tensor(betas0[None], device=DEV, requires_grad=True),
                 "body_pose": torch.tensor(poses[2][None, 3:], device=DEV, requires_grad=True),
                 "global_orient": torch.tensor(poses[2][None, :3], device=DEV, requires_grad=True),
                 "transl": torch.tensor(tr[2][None], device=DEV, requires_grad=True)}
-        d.prepare_deformer(leaf)                      # (not `initialized`: the template is rebuilt from these betas, as in the reference)
+        old = sdm.FUSED_LBS
+        sdm.FUSED_LBS = route == "fused"
+        try:
+            d.prepare_deformer(leaf)                      # (not `initialized`: the template is rebuilt from these betas, as in the reference)
+        finally:
+            sdm.FUSED_LBS = old
         gen = torch.Generator(device=DEV).manual_seed(3)
         w1 = torch.randn(d.T_inv.shape, device=DEV, generator=gen)
         w1[..., 3, :] = 0
-        w2 = torch.randn(d.vertices.shape, device=DEV, generator=gen)
-        ((d.T_inv * w1).sum() + (d.vertices * w2).sum()).backward()
-        res[small_ops] = (d.T_inv.detach().cpu().numpy(), d.vertices.detach().cpu().numpy(), d.w2s.detach().cpu().numpy(),
-                          {k: v.grad.detach().cpu().numpy().copy() for k, v in leaf.items()})
-    (T1, v1, w1_, g1), (T0, v0, w0_, g0) = res[True], res[False]
-    assert np.abs(T1 - T0).max() < 5e-5 and np.abs(v1 - v0).max() < 2e-5 and np.abs(w1_ - w0_).max() < 1e-5
-    scale = max(np.linalg.norm(v) for v in g0.values())
-    for k in g0:
-        a, b = g1[k].astype(np.float64).reshape(-1), g0[k].astype(np.float64).reshape(-1)
-        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
-        rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
-        print("d %-13s |g| %.3e  cos %.8f  rel %.2e" % (k, np.linalg.norm(b), cos, rel))
-        if k in ("global_orient", "transl"):
-            # T_inv and the vertices live in the SMPL-root frame: analytically independent of the root orientation and the
-            # translation -- both routes return rounding noise (measured 1.4e-4 against |d body_pose| = 360)
-            assert np.linalg.norm(a) < 1e-5 * scale and np.linalg.norm(b) < 1e-5 * scale, (k, np.linalg.norm(a), np.linalg.norm(b))
-        else:
-            assert np.linalg.norm(b) > 1e-3 and cos > 0.999999 and rel < 1e-4, (k, cos, rel)
+        w3 = torch.randn(d.w2s.shape, device=DEV, generator=gen) * 50.0
+        w3[..., 3, :] = 0
+        ((d.T_inv * w1).sum() + (d.w2s * w3).sum()).backward()
+        res[route] = (d.T_inv.detach().cpu().numpy(), d.vertices.detach().cpu().numpy(), d.w2s.detach().cpu().numpy(), d.bbox.cpu().numpy(),
+                      {k: v.grad.detach().cpu().numpy().copy() for k, v in leaf.items()})
+    T0, v0, w0_, bb0, g0 = res["library"]
+    for route in ("fused", "small_ops"):
+        T1, v1, w1_, bb1, g1 = res[route]
+        assert np.abs(T1 - T0).max() < 5e-5 and np.abs(v1 - v0).max() < 2e-5 and np.abs(w1_ - w0_).max() < 1e-5 and np.abs(bb1 - bb0).max() < 2e-5, route
+        for k in g0:
+            a, b = g1[k].astype(np.float64).reshape(-1), g0[k].astype(np.float64).reshape(-1)
+            nb = np.linalg.norm(b)
+            if nb == 0:
+                assert np.linalg.norm(a) == 0, (route, k)      # (betas on the zero-blendshape body: J does not depend on them)
+                continue
+            cos = float((a * b).sum() / (np.linalg.norm(a) * nb))
+            rel = float(np.linalg.norm(a - b) / nb)
+            print("%-9s d %-13s |g| %.3e  cos %.8f  rel %.2e" % (route, k, nb, cos, rel))
+            assert cos > 0.99999 and rel < 2e-3, (route, k, cos, rel)
+    if blend:
+        assert np.linalg.norm(res["fused"][4]["betas"]) > 1e-2
 
 
 def test_fit_step_on_a_blend_shape_subject_moves_betas():
