@@ -581,6 +581,24 @@ int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int
                             uint8_t *took_shared, void *stream);
 
 
+/* ---- SMPLDeformer training query on compact samples (smpl_deformer.py:88-120 under autograd; fit stage) ----------------
+ * ia_smpl_nn_compact:     nearest posed vertex of every sample point (K = 1 knn_points), pts_cano = T_inv[nearest] [pts, 1],
+ *                         valid = dist^2 < threshold^2; the valid points compacted: cand_xc [<= P,3], cand_pt [<= P] (the point of
+ *                         a candidate), idx [P] (vertex of every point), pt_off [P] / pt_cnt [P] (0 | 1: the compositor's
+ *                         candidate lists with n_init = 1), *n_cand (device counter, zeroed by the call).
+ * ia_smpl_nn_compact_bwd: d_cand_xc [cap,3] -> d_T_inv [V,4,4] (zero-filled by the call; d T_inv[idx] += g [x, 1]^T, rows 0..2)
+ *                         and d_pts [P,3] (zero-filled; R(T_inv[idx])^T g for the points that have a candidate).  Either may be NULL.
+ * ia_ray_samples_bwd:     the sample points are pts = o + z d (raymarcher_acc.py:158, z from the marcher: not differentiated):
+ *                         d_o [n_rays,3] = sum over the ray's compact samples of d_pts, d_d = the same weighted with z.    */
+int ia_smpl_nn_compact(const float *pts, int P, const int32_t *n_pts_dev, const float *verts, const float *T_inv,
+                       int n_verts, float threshold, float *cand_xc, int32_t *cand_pt, int32_t *idx, int32_t *pt_off,
+                       uint8_t *pt_cnt, int32_t *n_cand, void *stream);
+int ia_smpl_nn_compact_bwd(const float *pts, int P, const int32_t *cand_pt, const int32_t *idx, const int32_t *n_cand, int cap,
+                           const float *T_inv, int n_verts, const float *d_cand_xc, float *d_T_inv, float *d_pts,
+                           void *stream);
+int ia_ray_samples_bwd(const int32_t *ray_off, const int32_t *ray_cnt, const float *s_z, const float *d_pts, int n_rays,
+                       float *d_o, float *d_d, void *stream);
+
 /* ---- SMPLDeformer's body model, forward and backward (deformers/smpl_deformer.py:32-77) ---------------------------
  * Replaces, per frame / per fit step, the two smplx `SMPL.forward` evaluations of `SMPLDeformer.initialize` +
  * `prepare_deformer` (body_models.py:289-372 -> lbs.py:152-250) and their two batched `torch.inverse` calls, and -- in the

@@ -146,6 +146,9 @@ _SIGS = {
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "ia_pack_rgba8": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "ia_smpl_nn_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ia_smpl_nn_compact_bwd": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
+    "ia_ray_samples_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ia_smpl_lbs_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ia_smpl_lbs_fwd": (C.c_int, [C.POINTER(SmplBody)] + [_VP] * 9 + [_VP, C.c_size_t, _VP]),
     "ia_smpl_lbs_bwd": (C.c_int, [C.POINTER(SmplBody)] + [_VP] * 10 + [_VP, C.c_size_t, _VP]),

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(IA_NN_THREADS) void k_smpl_nn(
     int32_t *__restrict__ idx_out,
     // compaction (optional): canonical positions of the valid points, per-point offset / count (0|1)
     float *__restrict__ cand_xc, int32_t *__restrict__ pt_off, uint8_t *__restrict__ pt_cnt,
-    int32_t *__restrict__ n_cand) {
+    int32_t *__restrict__ n_cand, int32_t *__restrict__ cand_pt) {
   extern __shared__ __attribute__((aligned(16))) float s_v[];  // [NV][3]
   __shared__ int s_wtot[IA_NN_THREADS / 64];
   __shared__ int s_base;
@@ -63,12 +63,15 @@ __global__ __launch_bounds__(IA_NN_THREADS) void k_smpl_nn(
   const int o = s_base + s_wtot[wave] + __popcll(m & ((1ull << lane) - 1ull));
   pt_off[i] = o;
   pt_cnt[i] = ok ? 1 : 0;
-  if (ok) { cand_xc[(size_t)o * 3] = c[0]; cand_xc[(size_t)o * 3 + 1] = c[1]; cand_xc[(size_t)o * 3 + 2] = c[2]; }
+  if (ok) {
+    cand_xc[(size_t)o * 3] = c[0]; cand_xc[(size_t)o * 3 + 1] = c[1]; cand_xc[(size_t)o * 3 + 2] = c[2];
+    if (cand_pt) cand_pt[o] = i;     // the point a compact candidate belongs to (the training route's backward)
+  }
 }
 
 static int launch_nn(const float *pts, int P, const int32_t *n_pts_dev, const float *verts, const float *T_inv, int NV,
                      float threshold, float *pts_cano, uint8_t *valid, int32_t *idx, float *cand_xc, int32_t *pt_off,
-                     uint8_t *pt_cnt, int32_t *n_cand, hipStream_t s) {
+                     uint8_t *pt_cnt, int32_t *n_cand, hipStream_t s, int32_t *cand_pt = nullptr) {
   const size_t shmem = (size_t)NV * 12;
   static bool attr_done = false;
   if (!attr_done) {
@@ -76,7 +79,7 @@ static int launch_nn(const float *pts, int P, const int32_t *n_pts_dev, const fl
     attr_done = true;
   }
   hipLaunchKernelGGL(k_smpl_nn, dim3(ia_div_up(P, IA_NN_THREADS)), dim3(IA_NN_THREADS), shmem, s, pts, P, n_pts_dev, verts,
-                     T_inv, NV, threshold * threshold, pts_cano, valid, idx, cand_xc, pt_off, pt_cnt, n_cand);
+                     T_inv, NV, threshold * threshold, pts_cano, valid, idx, cand_xc, pt_off, pt_cnt, n_cand, cand_pt);
   IA_LAUNCH_CHECK("k_smpl_nn");
   return IA_OK;
 }
@@ -126,4 +129,104 @@ extern "C" int ia_smpl_deform_query(const float *pts, int P, const int32_t *n_pt
   rc = ia_launch_field(cand_xc, P, n_cand, F, cand_rgb, cand_sigma, s, nullptr);
   if (rc) return rc;
   return ia_candidate_max(cand_rgb, cand_sigma, pt_off, pt_cnt, P, n_pts_dev, 1, fill, nan_to_num, rgb, sigma, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The TRAINING query of the SMPLDeformer on compact samples (fit stage: fit.py, DNeRF.py:112-161 with deformer=smpl).
+// Reference: smpl_deformer.py:88-120 -- knn_points(K = 1), `pts_cano = T_inv[idx] @ [pts, 1]`, the field on the valid points,
+// (rgb, sigma) = (0, -1e5) elsewhere -- under autograd: the gradient reaches the per-vertex transforms (-> betas, pose,
+// translation through `ia_smpl_lbs_bwd`) and, through the sample points, the rays (-> w2s: transform_rays_w2s is differentiable).
+//   ia_smpl_nn_compact      nearest vertex + transform + compaction of the valid points: cand_xc, cand_pt (the point of every
+//                           candidate), idx (the vertex of every point), pt_off / pt_cnt (0 | 1) for the compositor (n_init = 1)
+//   ia_smpl_nn_compact_bwd  d cand_xc -> d T_inv[idx] += g [x, 1]^T (fp32 atomics: ~10^5 candidates onto 6 890 vertices),
+//                           d pts = R^T g (zero for points without a candidate)
+//   ia_ray_samples_bwd      pts = o + z d per compact sample (raymarcher_acc.py:158; z is not differentiated):
+//                           d o[r] = sum_s d pts[s],  d d[r] = sum_s z[s] d pts[s]  -- one wave per ray, fixed order
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int ia_smpl_nn_compact(const float *pts, int P, const int32_t *n_pts_dev, const float *verts, const float *T_inv,
+                                  int n_verts, float threshold, float *cand_xc, int32_t *cand_pt, int32_t *idx, int32_t *pt_off,
+                                  uint8_t *pt_cnt, int32_t *n_cand, void *stream) {
+  IA_CHECK_ARG(P >= 0, "ia_smpl_nn_compact: P < 0");
+  IA_CHECK_ARG(n_cand, "ia_smpl_nn_compact: null counter");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(n_cand, 0, 4, s);
+  if (P == 0) return IA_OK;
+  IA_CHECK_ARG(pts && verts && T_inv && cand_xc && cand_pt && idx && pt_off && pt_cnt, "ia_smpl_nn_compact: null pointer");
+  IA_CHECK_ARG(n_verts > 0 && (size_t)n_verts * 12 <= 160 * 1024 - 4096, "ia_smpl_nn_compact: %d vertices do not fit LDS", n_verts);
+  return launch_nn(pts, P, n_pts_dev, verts, T_inv, n_verts, threshold, nullptr, nullptr, idx, cand_xc, pt_off, pt_cnt, n_cand, s, cand_pt);
+}
+
+__global__ __launch_bounds__(256) void k_smpl_nn_bwd(const float *__restrict__ pts, const int32_t *__restrict__ cand_pt,
+                                                     const int32_t *__restrict__ idx, const int32_t *__restrict__ n_cand, int cap,
+                                                     const float *__restrict__ T_inv, const float *__restrict__ d_cand_xc,
+                                                     float *__restrict__ d_T_inv, float *__restrict__ d_pts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= min(cap, *n_cand)) return;
+  const int i = cand_pt[c], v = idx[i];
+  const float g[3] = {d_cand_xc[(size_t)c * 3], d_cand_xc[(size_t)c * 3 + 1], d_cand_xc[(size_t)c * 3 + 2]};
+  const float x[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+  const float *T = T_inv + (size_t)v * 16;
+  if (d_T_inv) {
+    float *D = d_T_inv + (size_t)v * 16;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (g[r] != 0.f) {
+        atomicAdd(D + r * 4, g[r] * x[0]); atomicAdd(D + r * 4 + 1, g[r] * x[1]); atomicAdd(D + r * 4 + 2, g[r] * x[2]);
+        atomicAdd(D + r * 4 + 3, g[r]);
+      }
+    }
+  }
+  if (d_pts)
+#pragma unroll
+    for (int b = 0; b < 3; b++) d_pts[(size_t)i * 3 + b] = T[b] * g[0] + T[4 + b] * g[1] + T[8 + b] * g[2];
+}
+
+extern "C" int ia_smpl_nn_compact_bwd(const float *pts, int P, const int32_t *cand_pt, const int32_t *idx, const int32_t *n_cand, int cap,
+                                      const float *T_inv, int n_verts, const float *d_cand_xc, float *d_T_inv, float *d_pts,
+                                      void *stream) {
+  IA_CHECK_ARG(P >= 0 && cap >= 0 && n_verts > 0, "ia_smpl_nn_compact_bwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (d_T_inv) (void)hipMemsetAsync(d_T_inv, 0, (size_t)n_verts * 64, s);
+  if (d_pts && P > 0) (void)hipMemsetAsync(d_pts, 0, (size_t)P * 12, s);
+  if (cap == 0 || P == 0) return IA_OK;
+  IA_CHECK_ARG(pts && cand_pt && idx && n_cand && T_inv && d_cand_xc, "ia_smpl_nn_compact_bwd: null pointer");
+  hipLaunchKernelGGL(k_smpl_nn_bwd, dim3(ia_div_up(cap, 256)), dim3(256), 0, s, pts, cand_pt, idx, n_cand, cap, T_inv, d_cand_xc, d_T_inv, d_pts);
+  IA_LAUNCH_CHECK("k_smpl_nn_bwd");
+  return IA_OK;
+}
+
+#define IA_RS_RAYS 4
+__global__ __launch_bounds__(64 * IA_RS_RAYS) void k_ray_samples_bwd(const int32_t *__restrict__ ray_off, const int32_t *__restrict__ ray_cnt,
+                                                                     const float *__restrict__ s_z, const float *__restrict__ d_pts, int n_rays,
+                                                                     float *__restrict__ d_o, float *__restrict__ d_d) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * IA_RS_RAYS + (threadIdx.x >> 6);
+  if (n >= n_rays) return;   // uniform per wave
+  const int off = ray_off[n], cnt = ray_cnt[n];
+  float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+  for (int k = lane; k < cnt; k += 64) {
+    const int s = off + k;
+    const float z = s_z[s];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float g = d_pts[(size_t)s * 3 + c]; a[c] += g; b[c] += z * g; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { a[c] += __shfl_xor(a[c], o, 64); b[c] += __shfl_xor(b[c], o, 64); }
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { d_o[(size_t)n * 3 + c] = a[c]; d_d[(size_t)n * 3 + c] = b[c]; }
+}
+
+extern "C" int ia_ray_samples_bwd(const int32_t *ray_off, const int32_t *ray_cnt, const float *s_z, const float *d_pts, int n_rays,
+                                  float *d_o, float *d_d, void *stream) {
+  IA_CHECK_ARG(n_rays >= 0, "ia_ray_samples_bwd: n_rays < 0");
+  if (n_rays == 0) return IA_OK;
+  IA_CHECK_ARG(ray_off && ray_cnt && s_z && d_pts && d_o && d_d, "ia_ray_samples_bwd: null pointer");
+  hipLaunchKernelGGL(k_ray_samples_bwd, dim3(ia_div_up(n_rays, IA_RS_RAYS)), dim3(64 * IA_RS_RAYS), 0, (hipStream_t)stream, ray_off, ray_cnt,
+                     s_z, d_pts, n_rays, d_o, d_d);
+  IA_LAUNCH_CHECK("k_ray_samples_bwd");
+  return IA_OK;
 }

@@ -143,6 +143,13 @@ class SMPLDeformer():
     def get_bbox_deformed(self):
         return get_bbox_from_smpl(self.vertices[0:1].detach())
 
+    #: tests: keep the reference's dense structure for the training render (dense_routes.render_train + deform_train)
+    force_dense_train = False
+
+    def fused_train_route(self):
+        """the training render over compact samples (Raymarcher.render_train_fused_smpl): one frame per step, on the GPU"""
+        return not self.force_dense_train and torch.is_tensor(getattr(self, "vertices", None)) and self.vertices.is_cuda and self.vertices.shape[0] == 1
+
     def prepare_deformer(self, smpl_params):
         """smpl_deformer.py:50-77"""
         device = smpl_params["betas"].device

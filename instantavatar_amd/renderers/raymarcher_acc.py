@@ -37,9 +37,73 @@ def _find_native_pair(model):
             pass
     for o in list(objs):
         objs.extend(v for v in (getattr(o, "deformer", None), getattr(o, "net_coarse", None)) if v is not None)
-    d = next((o for o in objs if isinstance(o, SNARFDeformer)), None)
+    from ..deformers.smpl_deformer import SMPLDeformer
+    d = next((o for o in objs if isinstance(o, (SNARFDeformer, SMPLDeformer))), None)
     n = next((o for o in objs if isinstance(o, NeRFNGPNet)), None)
     return (d, n) if d is not None and n is not None else None
+
+
+class _RaySamplesFn(torch.autograd.Function):
+    """The compact sample points of a training render as a function of the rays: pts = o + z d (raymarcher_acc.py:158; the depths
+    z come from the marcher and are not differentiated).  Forward: the points the march kernel already wrote; backward:
+    `ia_ray_samples_bwd` (per-ray sums, one wave per ray).  Only the SMPLDeformer's fit stage needs it: there the ray frame w2s is
+    under optimisation and the reference's autograd runs through transform_rays_w2s (smpl_deformer.py:79-86)."""
+
+    @staticmethod
+    def forward(ctx, o, d, st):
+        ctx.st = st
+        ctx.shapes = (o.shape, d.shape)
+        return st["s_pts"]          # (written by the march kernel from the same o, d)
+
+    @staticmethod
+    def backward(ctx, d_pts):
+        st = ctx.st
+        n = st["n"]
+        dev = d_pts.device
+        d_o, d_d = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
+        g = d_pts.float().contiguous()
+        _lib.check(_lib.lib().ia_ray_samples_bwd(_lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]), _lib.ptr(st["s_z"]), _lib.ptr(g), n,
+                                                 _lib.ptr(d_o), _lib.ptr(d_d), _lib.stream()), "ia_ray_samples_bwd")
+        return d_o.reshape(ctx.shapes[0]), d_d.reshape(ctx.shapes[1]), None
+
+
+class _SmplDeformCompactFn(torch.autograd.Function):
+    """SMPLDeformer.deform on compact samples (smpl_deformer.py:88-110) with the valid points compacted: `ia_smpl_nn_compact` /
+    `ia_smpl_nn_compact_bwd`.  Inputs: sample points [cap,3] (gradient -> rays), T_inv [1,V,4,4] (gradient -> body model)."""
+
+    @staticmethod
+    def forward(ctx, pts, T_inv, deformer, n_pts_dev, out):
+        L = _lib.lib()
+        x = pts.detach().reshape(-1, 3).float().contiguous()
+        P = x.shape[0]
+        V = deformer.vertices.shape[1]
+        Ti = T_inv.detach().reshape(V, 4, 4).float().contiguous()
+        dev = x.device
+        cand_xc = torch.empty((P, 3), device=dev)
+        cand_pt, idx = torch.empty(P, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int32, device=dev)
+        pt_off, pt_cnt = torch.empty(P, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.uint8, device=dev)
+        n_cand = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(L.ia_smpl_nn_compact(_lib.ptr(x), P, _lib.ptr(n_pts_dev), _lib.ptr(deformer.vertices.detach()), _lib.ptr(Ti), V,
+                                        float(deformer.threshold), _lib.ptr(cand_xc), _lib.ptr(cand_pt), _lib.ptr(idx), _lib.ptr(pt_off),
+                                        _lib.ptr(pt_cnt), _lib.ptr(n_cand), _lib.stream()), "ia_smpl_nn_compact")
+        out.update(pt_off=pt_off, pt_cnt=pt_cnt, n_cand=n_cand)
+        ctx.save_for_backward(x, Ti, cand_pt, idx, n_cand)
+        ctx.shapes = (pts.shape, T_inv.shape)
+        ctx.need = (pts.requires_grad, T_inv.requires_grad)
+        return cand_xc
+
+    @staticmethod
+    def backward(ctx, d_cand):
+        x, Ti, cand_pt, idx, n_cand = ctx.saved_tensors
+        P, V = x.shape[0], Ti.shape[0]
+        dev = x.device
+        need_p, need_T = ctx.need
+        d_pts = torch.empty((P, 3), device=dev) if need_p else None
+        d_T = torch.empty((V, 4, 4), device=dev) if need_T else None
+        g = d_cand.float().contiguous()
+        _lib.check(_lib.lib().ia_smpl_nn_compact_bwd(_lib.ptr(x), P, _lib.ptr(cand_pt), _lib.ptr(idx), _lib.ptr(n_cand), P, _lib.ptr(Ti), V,
+                                                     _lib.ptr(g), _lib.ptr(d_T), _lib.ptr(d_pts), _lib.stream()), "ia_smpl_nn_compact_bwd")
+        return (d_pts.reshape(ctx.shapes[0]) if need_p else None), (d_T.reshape(ctx.shapes[1]) if need_T else None), None, None, None
 
 
 class _CompositeTrainFn(torch.autograd.Function):
@@ -152,7 +216,8 @@ class Raymarcher(torch.nn.Module):
     @torch.no_grad()
     def render_test(self, rays, model, bg_color):
         pair = self._fused or _find_native_pair(model)
-        if pair is not None and rays.o.is_cuda:
+        from ..deformers.snarf_deformer import SNARFDeformer
+        if pair is not None and rays.o.is_cuda and isinstance(pair[0], SNARFDeformer):
             return self.render_test_fused(rays, pair[0], pair[1], bg_color)
         from .. import dense_routes
         return dense_routes.render_test(self, rays, model, bg_color)     # any other callable: host-driven loop, dense blocks
@@ -211,6 +276,57 @@ class Raymarcher(torch.nn.Module):
         }
 
     # ----------------------------------------------------------------- train
+    def render_train_fused_smpl(self, rays, deformer, net, noise, bg_color):
+        """render_train (raymarcher_acc.py:140-186) with the SMPLDeformer plugin (fit stage) over COMPACT samples: march + jitter +
+        compaction, nearest-vertex deformation + compaction of the valid samples (`ia_smpl_nn_compact`), the field under autograd
+        on them, compositing forward / backward as two kernels.  With the SMPL parameters under optimisation the gradient reaches
+        the per-vertex transforms (`ia_smpl_nn_compact_bwd` -> `ia_smpl_lbs_bwd`) and, through the sample points, the rays
+        (`ia_ray_samples_bwd` -> transform_rays_w2s's autograd -> w2s).  No host synchronisation."""
+        L = _lib.lib()
+        dev = rays.o.device
+        o = rays.o.reshape(-1, 3).float().contiguous()
+        d = rays.d.reshape(-1, 3).float().contiguous()
+        near = rays.near.detach().reshape(-1).float().contiguous()
+        far = rays.far.detach().reshape(-1).float().contiguous()
+        n, S = o.shape[0], self.MAX_SAMPLES
+        cap = n * S
+        grid = self.density_grid_train
+        occ = self._occ_desc_cached(grid)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        st = dict(s_pts=torch.empty((cap, 3), device=dev), s_z=torch.empty(cap, device=dev), s_slot=i32(cap),
+                  ray_off=i32(n), ray_cnt=i32(n), n_samples=i32(1), near=near, far=far, n=n, S=S)
+        draws = getattr(self, "train_draws", None) or {}
+        jitter = draws["ray_jitter"].to(dev).float().reshape(n, S).contiguous() if "ray_jitter" in draws else torch.rand((n, S), device=dev)  # :156
+        with torch.no_grad():
+            _lib.check(L.ia_march_train_compact(_lib.ptr(o.detach()), _lib.ptr(d.detach()), _lib.ptr(near), _lib.ptr(far), n, _lib.ptr(grid.occ_bits),
+                                                C.byref(occ), S, _lib.ptr(jitter), _lib.ptr(st["s_pts"]), _lib.ptr(st["s_z"]),
+                                                _lib.ptr(st["s_slot"]), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]),
+                                                _lib.ptr(st["n_samples"]), cap, _lib.stream()), "ia_march_train_compact")
+        pts = st["s_pts"]
+        if torch.is_grad_enabled() and (o.requires_grad or d.requires_grad):
+            pts = _RaySamplesFn.apply(o, d, st)
+        T_inv = deformer.T_inv
+        from ..training import ZeroPool, field_autograd
+        if torch.is_grad_enabled():
+            ZeroPool.current = ZeroPool(8 * cap + n * S + 1024, dev)
+        if torch.is_grad_enabled() and (pts.requires_grad or T_inv.requires_grad):
+            cand = _SmplDeformCompactFn.apply(pts, T_inv, deformer, st["n_samples"], st)
+        else:
+            with torch.no_grad():
+                cand = _SmplDeformCompactFn.apply(pts, T_inv, deformer, st["n_samples"], st)
+        st.update(n_init=1, bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
+                  noise=(draws["noise"].to(dev).float().reshape(n, S).contiguous() if "noise" in draws else torch.randn((n, S), device=dev))
+                  if noise > 0 else None, noise_scale=float(noise))                # :167
+        rgb_c, sig_c = field_autograd(net, cand, n_dev=st["n_cand"])
+        self.train_overflow_flag = None      # one candidate per sample at most: the sample capacity bounds the candidates
+        color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
+        return {
+            "rgb_coarse": color.reshape(rays.o.shape),
+            "depth_coarse": depth.reshape(rays.near.shape),
+            "alpha_coarse": alpha.reshape(rays.near.shape),
+            "weight_coarse": weights.reshape(*rays.near.shape, -1),
+        }
+
     def render_train_fused(self, rays, deformer, net, noise, bg_color):
         """render_train (raymarcher_acc.py:140-186) over COMPACT samples: march + jitter +
         compaction, candidate search + compaction, field under autograd on the surviving
@@ -324,6 +440,9 @@ class Raymarcher(torch.nn.Module):
         """raymarcher_acc.py:140-186."""
         pair = self._fused or _find_native_pair(model)
         if pair is not None and rays.o.is_cuda and pair[0].fused_train_route():
+            from ..deformers.smpl_deformer import SMPLDeformer
+            if isinstance(pair[0], SMPLDeformer):
+                return self.render_train_fused_smpl(rays, pair[0], pair[1], noise, bg_color)
             return self.render_train_fused(rays, pair[0], pair[1], noise, bg_color)
         from .. import dense_routes
         return dense_routes.render_train(self, rays, model, noise, bg_color)   # any other callable / the dense deformer route

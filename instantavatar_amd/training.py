@@ -638,7 +638,8 @@ class GraphedTrainStep:
             # SMPL parameters under optimisation: capturable on the fused SNARF route only (the SMPLDeformer's training
             # query -- fit stage -- reads validity counts on the host and inverts 6 890 vertex transforms with the LU library)
             fused = getattr(model.deformer, "fused_train_route", None)
-            self.enabled = self.enabled and fused is not None and getattr(model.deformer.deformer, "version", 1) == 1
+            inner = getattr(model.deformer, "deformer", None)      # (SNARFDeformer; the SMPLDeformer's fit stage steps eagerly)
+            self.enabled = self.enabled and fused is not None and inner is not None and getattr(inner, "version", 1) == 1
         from .optim import FusedAdam
         if isinstance(optimizer, FusedAdam) and self.enabled:
             optimizer.fused_zero_grad = True    # the step leaves every gradient buffer zero-filled for the next one

@@ -46,6 +46,76 @@ def test_fit_stage_optimises_smpl_parameters_and_exports(tmp_path):
     assert z["body_pose"].shape == (3, 69) and z["betas"].shape == (1, 10)
 
 
+@pytest.mark.parametrize("blend", [False, True], ids=["zero-blendshapes", "blendshapes"])
+def test_fit_fused_route_equals_dense_route(blend):
+    """The fit step's fused route -- `ia_smpl_lbs_fwd/_bwd` for the body model, `Raymarcher.render_train_fused_smpl` (compact
+    samples, `ia_smpl_nn_compact[_bwd]`, `ia_ray_samples_bwd`) for the render -- against the route that keeps the reference's
+    structure: SMPL.forward as lbs.py-style torch ops under autograd, dense [n_rays, 256] sample blocks, boolean-mask gathers
+    (dense_routes.render_train + SMPLDeformer.deform_train).  Same state, same injected draws -> same losses, same gradients of
+    the four SMPL tables (betas included on the blend-shape subject) and of the MLP weights, up to summation order."""
+    from instantavatar_amd.deformers import smpl_deformer as sdm
+    import copy
+    torch.manual_seed(0)
+    frames, body_model, true = fit_driver.synthetic_frames(torch.device(DEV), res=96, n_frames=2, noise=0.03, patch=16, blendshapes=blend)
+    # a formed field first (a freshly initialised one is transparent: every gradient of the SMPL tables would be rounding noise)
+    base = fit_driver.build_fit_model(frames, body_model, torch.device(DEV))
+    opt = configure_optimizer(base, lr=1e-2, smpl_lr=1e-4)
+    loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
+    base.train()
+    for it in range(40):
+        training_step(base, frames.batch(it % 2), opt, loss_fn)
+    state = copy.deepcopy(base.state_dict())
+    grids = [(g.density_cached.clone(), g.density_field.clone(), g.occ_bits.clone()) for g in base.renderer.density_grid_train_all]
+    res = {}
+    for fused in (True, False):
+        model = fit_driver.build_fit_model(frames, body_model, torch.device(DEV))
+        model.load_state_dict(state)
+        model.net_coarse.mark_updated()
+        model.net_coarse.initialize(base.net_coarse.bbox)
+        for g, (c, f, b) in zip(model.renderer.density_grid_train_all, grids):
+            g.density_cached.copy_(c); g.density_field.copy_(f); g.occ_bits.copy_(b)
+        model.global_step = 41              # not an occupancy-update step
+        opt = configure_optimizer(model, lr=1e-3, smpl_lr=1e-4)
+        model.train()
+        model.deformer.force_dense_train = not fused
+        old = sdm.FUSED_LBS
+        sdm.FUSED_LBS = fused
+        try:
+            batch = frames.batch(0, generator=torch.Generator(device=DEV).manual_seed(5))
+            n_rays = batch["rays_o"].numel() // 3
+            g = torch.Generator(device=DEV).manual_seed(6)
+            draws = dict(ray_jitter=torch.rand((n_rays, 256), device=DEV, generator=g), noise=torch.randn((n_rays, 256), device=DEV, generator=g))
+            out = training_step(model, batch, opt, loss_fn, draws=draws)
+        finally:
+            sdm.FUSED_LBS = old
+        grads = {k: getattr(model.SMPL_param, k).weight.grad.detach().cpu().numpy().copy() for k in ("betas", "body_pose", "global_orient", "transl")}
+        grads["mlp_color"] = model.net_coarse.color_net.params.grad.detach().cpu().numpy().copy()
+        n1 = model.net_coarse.sig_w1_size + 1024
+        grads["mlp_sigma"] = model.net_coarse.encoder.params.grad.detach().cpu().numpy()[:n1].copy()
+        res[fused] = ({k: float(v) for k, v in out.items() if torch.is_tensor(v) and v.numel() == 1}, grads)
+    (l1, g1), (l0, g0) = res[True], res[False]
+    bad = []
+    for k in ("loss", "mse_loss", "loss_alpha_coarse", "reg_alpha", "reg_density", "loss_depth_reg"):
+        # (the two body-model routes agree to ~5e-5 on T_inv: a handful of samples change their nearest vertex / validity)
+        assert abs(l1[k] - l0[k]) <= 1e-3 * abs(l0[k]) + 1e-9, (k, l1[k], l0[k])
+    for k, b in g0.items():
+        a = g1[k].astype(np.float64).reshape(-1)
+        b = b.astype(np.float64).reshape(-1)
+        nb = np.linalg.norm(b)
+        if nb == 0:
+            assert np.linalg.norm(a) == 0, k
+            continue
+        cos, rel = float((a * b).sum() / (np.linalg.norm(a) * nb)), float(np.linalg.norm(a - b) / nb)
+        print("fit step d %-13s |g| %.3e cos %.7f rel %.2e" % (k, nb, cos, rel))
+        # (measured: cos >= 0.9999, rel <= 2e-2 -- the two body-model routes agree to ~5e-5 on T_inv and the vertices, so a handful
+        # of samples change their nearest vertex or their validity, and with them their gradient contributions: the tolerance of
+        # the refine tests, tests/test_gpu_refine.py; the body model alone agrees to 4e-7: test_smpl_deformer_prepare_three_routes...)
+        bad = bad + [(k, cos, rel)] if not (cos > 0.9995 and rel < 4e-2) else bad
+    assert not bad, bad
+    if blend:
+        assert np.linalg.norm(g1["betas"]) > 0
+
+
 def test_ngp_loss_with_lpips_term_trains_on_the_device():
     """The refine configuration's loss (confs/SNARF_NGP_refine.yaml: NGPLoss with w_lpips) on the device: the LPIPS term is
     present for patch batches, differentiable through the renderer, and its module equals its CPU evaluation.  (Random trunk
