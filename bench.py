@@ -524,7 +524,7 @@ def _device_code():
 
 
 _DEV_CODE = [None]
-PMC_ROUNDS = ("r05", "r04", "r03")
+PMC_ROUNDS = ("r06", "r05", "r04", "r03")
 
 
 def _profile_json(stem, tus):

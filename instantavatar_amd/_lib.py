@@ -173,8 +173,14 @@ def lib():
         # built with IA_EXTRA_HIPCC_FLAGS carry the flags in their hashes, so the same variable must be set when they run.
         if os.environ.get("IA_ALLOW_STALE_LIB", "0") != "1":
             from . import build
-            have, want = build.library_manifest(LIB_PATH), build.source_manifest()
-            if have != want:
+            have = build.library_manifest(LIB_PATH)
+            try:
+                want = build.source_manifest()
+            except OSError:      # a csrc/ without the shared headers: nothing to compare against
+                want = {}
+            # (an installation that ships the library without its sources -- a wheel, a container layer -- has nothing to be
+            # stale against: the check only applies where there is a checkout to have edited)
+            if want and have != want:
                 diff = sorted(k for k in set(have) | set(want) if have.get(k) != want.get(k))
                 raise ImportError(
                     "instantavatar_amd: %s was built from other sources than this checkout (differs in: %s). Rebuild it "

@@ -48,7 +48,11 @@ def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, lo
     training.configure_scheduler).  Returns the last losses.
     world_size > 1: every rank calls this; replicas start from rank 0's state, rank r takes positions r, r + W, ... of the
     epoch's (shared) shuffle -- a frame's SMPL rows receive a gradient from the rank that drew the frame only, the average
-    over ranks scales it by 1 / W, which Adam's normalisation absorbs -- and an epoch is ceil(frames / W) steps."""
+    over ranks scales it by 1 / W, which Adam's normalisation absorbs -- and an epoch is ceil(frames / W) steps.
+    NOT a parity mode (the reference's fit.py is single-GPU): when the frame count is not a multiple of W the last step of an
+    epoch wraps around, so the first frames of the shuffle are drawn twice in that epoch, and the moments of SMPL rows that got
+    no gradient in a step still decay -- the optimisation trajectory differs from the 1-rank run's (same optimum, tested to
+    train: tests/test_gpu_drivers.py)."""
     from ..parallel import broadcast_module_state
     broadcast_module_state(model, world_size)
     opt = configure_optimizer(model, lr=lr, smpl_lr=smpl_lr)

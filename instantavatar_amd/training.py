@@ -716,6 +716,17 @@ class GraphedTrainStep:
         if not eager and self.inputs is not None and batch is not self.inputs:
             eager = self._signature(batch) != self._sig
         if eager:
+            if self._agreed and parallel.collectives_on(self.world_size) and m.global_step % self._update_period() == 0:
+                # occupancy-update steps run eagerly on EVERY rank at the same global steps: the place to agree on a capture
+                # that failed on one rank only AFTER the first agreement (a re-capture with a grown candidate capacity is a
+                # per-rank event) -- from here on all ranks launch eagerly together instead of one rank's eager collectives
+                # meeting the others' replays for the rest of the run
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if self.enabled else 0.0], device=next(m.parameters()).device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) == 0.0 and self.enabled:
+                    self.enabled = False
+                    self.capture_error = self.capture_error or "HIP-graph re-capture failed on another rank: all ranks launch eagerly"
             self.eager_steps += 1
             self._warmed = True
             return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
@@ -751,8 +762,6 @@ class GraphedTrainStep:
             self.graphs = {k: e for k, e in self.graphs.items() if k[1] == r.train_cand_capacity}
             err = None
             try:
-                if os.environ.get("IA_TEST_CAPTURE_FAIL_RANK") == os.environ.get("RANK", "0"):
-                    raise RuntimeError("capture failure injected by IA_TEST_CAPTURE_FAIL_RANK (test hook)")
                 entry = self._capture(key, use_noise)
             except Exception as e:  # capture not possible on this stack: stay eager (same kernels, host-launched)
                 err = repr(e)[:300]

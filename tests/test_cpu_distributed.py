@@ -502,8 +502,6 @@ def test_gloo_world2_animate_driver_shards_frames_and_gathers_the_gif(tmp_path):
 # GPU; here `_capture` is replaced by a stand-in whose "graph" replays an eager step, everything around it is the real code.
 def _graph_agreement_worker(rank, world, port, fail_rank, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank))
-    if fail_rank is not None:
-        os.environ["IA_TEST_CAPTURE_FAIL_RANK"] = str(fail_rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from instantavatar_amd import parallel, training
     from instantavatar_amd.models.structures.density_grid import DensityGrid
@@ -531,6 +529,9 @@ def _graph_agreement_worker(rank, world, port, fail_rank, q):
     assert stepper.enabled
 
     def fake_capture(key, use_noise):
+        if fail_rank is not None and rank == fail_rank:      # the fault is injected HERE, in the stand-in: no test hook in the product
+            raise RuntimeError("capture failure injected by the test")
+
         class G:
             def replay(self_inner):
                 entry["out"] = training.training_step(model, stepper.inputs, opt, loss_fn, world, _capturing=True)

@@ -67,7 +67,8 @@ def test_fit_fused_route_equals_dense_route(blend):
     state = copy.deepcopy(base.state_dict())
     grids = [(g.density_cached.clone(), g.density_field.clone(), g.occ_bits.clone()) for g in base.renderer.density_grid_train_all]
     res = {}
-    for fused in (True, False):
+    for route in ("fused", "fused-lbs+dense-render", "torch-lbs+dense-render"):
+        fused = route == "fused"
         model = fit_driver.build_fit_model(frames, body_model, torch.device(DEV))
         model.load_state_dict(state)
         model.net_coarse.mark_updated()
@@ -79,7 +80,7 @@ def test_fit_fused_route_equals_dense_route(blend):
         model.train()
         model.deformer.force_dense_train = not fused
         old = sdm.FUSED_LBS
-        sdm.FUSED_LBS = fused
+        sdm.FUSED_LBS = route != "torch-lbs+dense-render"
         try:
             batch = frames.batch(0, generator=torch.Generator(device=DEV).manual_seed(5))
             n_rays = batch["rays_o"].numel() // 3
@@ -92,28 +93,35 @@ def test_fit_fused_route_equals_dense_route(blend):
         grads["mlp_color"] = model.net_coarse.color_net.params.grad.detach().cpu().numpy().copy()
         n1 = model.net_coarse.sig_w1_size + 1024
         grads["mlp_sigma"] = model.net_coarse.encoder.params.grad.detach().cpu().numpy()[:n1].copy()
-        res[fused] = ({k: float(v) for k, v in out.items() if torch.is_tensor(v) and v.numel() == 1}, grads)
-    (l1, g1), (l0, g0) = res[True], res[False]
-    bad = []
-    for k in ("loss", "mse_loss", "loss_alpha_coarse", "reg_alpha", "reg_density", "loss_depth_reg"):
-        # (the two body-model routes agree to ~5e-5 on T_inv: a handful of samples change their nearest vertex / validity)
-        assert abs(l1[k] - l0[k]) <= 1e-3 * abs(l0[k]) + 1e-9, (k, l1[k], l0[k])
-    for k, b in g0.items():
-        a = g1[k].astype(np.float64).reshape(-1)
-        b = b.astype(np.float64).reshape(-1)
-        nb = np.linalg.norm(b)
-        if nb == 0:
-            assert np.linalg.norm(a) == 0, k
-            continue
-        cos, rel = float((a * b).sum() / (np.linalg.norm(a) * nb)), float(np.linalg.norm(a - b) / nb)
-        print("fit step d %-13s |g| %.3e cos %.7f rel %.2e" % (k, nb, cos, rel))
-        # (measured: cos >= 0.9999, rel <= 2e-2 -- the two body-model routes agree to ~5e-5 on T_inv and the vertices, so a handful
-        # of samples change their nearest vertex or their validity, and with them their gradient contributions: the tolerance of
-        # the refine tests, tests/test_gpu_refine.py; the body model alone agrees to 4e-7: test_smpl_deformer_prepare_three_routes...)
-        bad = bad + [(k, cos, rel)] if not (cos > 0.9995 and rel < 4e-2) else bad
-    assert not bad, bad
+        res[route] = ({k: float(v) for k, v in out.items() if torch.is_tensor(v) and v.numel() == 1}, grads)
+
+    def compare(r1, r0, c_min, r_max, l_tol):
+        (l1, g1), (l0, g0) = res[r1], res[r0]
+        bad = []
+        for k in ("loss", "mse_loss", "loss_alpha_coarse", "reg_alpha", "reg_density", "loss_depth_reg"):
+            if not abs(l1[k] - l0[k]) <= l_tol * abs(l0[k]) + 1e-9:
+                bad.append((k, l1[k], l0[k]))
+        for k, b in g0.items():
+            a = g1[k].astype(np.float64).reshape(-1)
+            b = b.astype(np.float64).reshape(-1)
+            nb = np.linalg.norm(b)
+            if nb == 0:
+                assert np.linalg.norm(a) == 0, k
+                continue
+            cos, rel = float((a * b).sum() / (np.linalg.norm(a) * nb)), float(np.linalg.norm(a - b) / nb)
+            print("fit step [%s vs %s] d %-13s |g| %.3e cos %.7f rel %.2e" % (r1, r0, k, nb, cos, rel))
+            if not (cos > c_min and rel < r_max):
+                bad.append((k, cos, rel))
+        assert not bad, (r1, r0, bad)
+    # (1) the RENDER routes on bit-identical T_inv / vertices (both from the fused body model): the same samples, the same nearest
+    #     vertices -> equal up to summation order (fp32 atomics of the scatters)
+    compare("fused", "fused-lbs+dense-render", 0.99999, 5e-3, 1e-4)
+    # (2) the two BODY-MODEL routes under the same (dense) render: T_inv and the vertices agree to ~5e-5 (and their gradients to 4e-7:
+    #     test_smpl_deformer_prepare_three_routes...), so a handful of samples change their nearest vertex or cross the 5 cm
+    #     validity threshold, and with them their gradient contributions (measured cos 0.9991 .. 0.99999, rel 2e-3 .. 6e-2)
+    compare("fused-lbs+dense-render", "torch-lbs+dense-render", 0.998, 8e-2, 2e-3)
     if blend:
-        assert np.linalg.norm(g1["betas"]) > 0
+        assert np.linalg.norm(res["fused"][1]["betas"]) > 0
 
 
 def test_ngp_loss_with_lpips_term_trains_on_the_device():

@@ -7,6 +7,6 @@ for mode in plain refine; do
   arg=""; [ $mode = plain ] && arg="--plain"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$mode -o r -- python $R/tools/prof_refine.py 100 $arg > $O/prof_$mode.log 2>&1
   grep it_per_sec $O/prof_$mode.log
-  cp $O/prof_$mode/r_kernel_stats.csv $O/r05_train_${mode}_kernel_stats.csv; rm -rf $O/prof_$mode
-  head -8 $O/r05_train_${mode}_kernel_stats.csv | cut -c1-110
+  cp $O/prof_$mode/r_kernel_stats.csv $O/${IA_PMC_ROUND:-r06}_train_${mode}_kernel_stats.csv; rm -rf $O/prof_$mode
+  head -8 $O/${IA_PMC_ROUND:-r06}_train_${mode}_kernel_stats.csv | cut -c1-110
 done
