@@ -539,6 +539,11 @@ int ia_sample_batch(const uint8_t *img_u8, const float *img_f, const float *mask
  * branch is floor(u * (H - patch)) (np.random.randint(0, H - patch)), chosen when coin >= ratio_mask.  rows / cols [n]. */
 int ia_patch_corners(const int32_t *row_mask, const int32_t *col_mask, const float *draws, int n, int H, int W,
                      int patch, float ratio_mask, int32_t *rows, int32_t *cols, void *stream);
+/* EdgeSampler's flat pixel indices (sampler.py:33-41) from the two ia_nonzero_select results and the draws [n_mask + n_edge + n_rand]:
+ * out = [row_mask W + col_mask | row_edge W + col_edge | floor(u H W)], row-major; a pick from an empty mask / band (-1) falls back
+ * to the uniform pixel of its own draw (the reference raises there: np.random.randint(0, 0)).                            */
+int ia_edge_indices(const int32_t *row_mask, const int32_t *col_mask, const int32_t *row_edge, const int32_t *col_edge,
+                    const float *draws, int n_mask, int n_edge, int n_rand, int H, int W, int32_t *out, void *stream);
 /* near / far of a frame's n rays (peoplesnapshot.py:146-150): |transl| -/+ 1, transl: DEVICE float[3].          */
 int ia_near_far(const float *transl, int n, float *near_out, float *far_out, void *stream);
 

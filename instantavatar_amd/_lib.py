@@ -91,6 +91,7 @@ _SIGS = {
                                     _VP, C.c_size_t, _VP]),
     "ia_patch_corners": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),
     "ia_near_far": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
+    "ia_edge_indices": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
     "ia_sample_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP,
                                   _VP, _VP, _VP, _VP, _VP]),
     "ia_field_frags_bytes": (C.c_size_t, []),

@@ -329,6 +329,34 @@ __global__ void k_near_far(const float *__restrict__ transl, int n, float *__res
   far_out[i] = d + 1.f;
 }
 
+// EdgeSampler's pixel indices (sampler.py:33-41): [mask picks | edge-band picks | uniform picks], flat row-major.  A pick from an
+// empty mask / band (row = col = -1 from ia_nonzero_select) falls back to a uniform pixel, floor(u H W) clamped to H W - 1.
+__global__ __launch_bounds__(256) void k_edge_indices(const int32_t *__restrict__ r_m, const int32_t *__restrict__ c_m,
+                                                      const int32_t *__restrict__ r_e, const int32_t *__restrict__ c_e,
+                                                      const float *__restrict__ draws, int n_mask, int n_edge, int n_rand, int H, int W,
+                                                      int32_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_mask + n_edge + n_rand) return;
+  const float hw = (float)(H * W);
+  const int uni = (int)fminf(floorf(draws[i] * hw), (float)(H * W - 1));
+  int v = uni;
+  if (i < n_mask) { const int p = r_m[i] * W + c_m[i]; if (p >= 0) v = p; }
+  else if (i < n_mask + n_edge) { const int k = i - n_mask; const int p = r_e[k] * W + c_e[k]; if (p >= 0) v = p; }
+  out[i] = v;
+}
+
+extern "C" int ia_edge_indices(const int32_t *row_mask, const int32_t *col_mask, const int32_t *row_edge, const int32_t *col_edge,
+                               const float *draws, int n_mask, int n_edge, int n_rand, int H, int W, int32_t *out, void *stream) {
+  const int n = n_mask + n_edge + n_rand;
+  IA_CHECK_ARG(n_mask >= 0 && n_edge >= 0 && n_rand >= 0 && H > 0 && W > 0, "ia_edge_indices: bad sizes");
+  if (n == 0) return IA_OK;
+  IA_CHECK_ARG(draws && out && (n_mask == 0 || (row_mask && col_mask)) && (n_edge == 0 || (row_edge && col_edge)), "ia_edge_indices: null pointer");
+  hipLaunchKernelGGL(k_edge_indices, dim3(ia_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, row_mask, col_mask, row_edge, col_edge, draws,
+                     n_mask, n_edge, n_rand, H, W, out);
+  IA_LAUNCH_CHECK("k_edge_indices");
+  return IA_OK;
+}
+
 extern "C" int ia_near_far(const float *transl, int n, float *near_out, float *far_out, void *stream) {
   IA_CHECK_ARG(n >= 0, "ia_near_far: n < 0");
   if (n == 0) return IA_OK;

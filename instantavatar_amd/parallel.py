@@ -66,7 +66,7 @@ def render_frame_tiled(model, batch, img_size, world_size=1, rank=0, jitter=None
         if jitter is None:
             # every rank rebuilds the occupancy grid itself: with a private draw per rank the blocks would come from DIFFERENT
             # grids and the gathered frame would be a patchwork, silently.  One draw, rank 0's, for all (3.9 MB, once per frame)
-            G = int(getattr(getattr(model.renderer, "density_grid_test", None), "grid_size", 64))   # (the grid's own size, not a literal)
+            G = int(getattr(getattr(getattr(model, "renderer", None), "density_grid_test", None), "grid_size", 64))   # (the grid's own size, not a literal)
             jitter = torch.rand((5, G ** 3, 3), device=batch["rays_o"].device)                       # 5 = DensityGrid.initialize's default iters
             dist.broadcast(jitter, src=0)
     outs = model.render_image_fast(sub, (r1 - r0, W), jitter=jitter) if r1 > r0 else None

@@ -536,9 +536,16 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         from .deformers.smpl_deformer import SMPLDeformer
         if isinstance(model.deformer, SMPLDeformer):
             batch["betas"] = body_params["betas"]
-        dist = torch.norm(batch["transl"], dim=-1, keepdim=True).detach()   # near / far follow the refined translation
-        batch["near"] = (dist - 1).reshape(1, *([1] * (batch["near"].dim() - 1))).expand_as(batch["near"]).contiguous()
-        batch["far"] = (dist + 1).reshape(1, *([1] * (batch["far"].dim() - 1))).expand_as(batch["far"]).contiguous()
+        # near / far follow the refined translation (DNeRF.py:124-127: |transl| -/+ 1 for every ray): one launch
+        tr = batch["transl"].detach().reshape(-1)[:3].float().contiguous()
+        if tr.is_cuda and batch["near"].is_cuda:
+            near, far = torch.empty_like(batch["near"], dtype=torch.float32).contiguous(), torch.empty_like(batch["far"], dtype=torch.float32).contiguous()
+            _lib.check(_lib.lib().ia_near_far(_lib.ptr(tr), near.numel(), _lib.ptr(near), _lib.ptr(far), _lib.stream()), "ia_near_far")
+            batch["near"], batch["far"] = near, far
+        else:
+            dist = torch.norm(batch["transl"], dim=-1, keepdim=True).detach()
+            batch["near"] = (dist - 1).reshape(1, *([1] * (batch["near"].dim() - 1))).expand_as(batch["near"]).contiguous()
+            batch["far"] = (dist + 1).reshape(1, *([1] * (batch["far"].dim() - 1))).expand_as(batch["far"]).contiguous()
     model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
     model.deformer.prepare_deformer(batch)
     reducer = parallel.GradReducer(world_size)

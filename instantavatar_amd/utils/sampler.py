@@ -74,14 +74,16 @@ class EdgeSampler:
         u_m, u_e, u_r = draws[:self.num_mask], draws[self.num_mask:self.num_mask + self.num_edge], draws[self.num_mask + self.num_edge:n]
         r_m, c_m, _ = nonzero_select(mask2d, (0, H, 0, W), u_m)
         r_e, c_e, _ = nonzero_select(self.edge_band(mask2d), (0, H, 0, W), u_e)
-        uniform = lambda u: torch.clamp((u.float() * float(H * W)).floor(), max=H * W - 1).to(torch.int32)
         # an empty mask / an empty band (all-zero or all-one mask) selects nothing: ia_nonzero_select returns row = col = -1.
-        # The reference raises there (np.random.randint(0, 0)); here those draws fall back to uniform pixels -- like
-        # PatchSampler's empty-mask branch -- instead of handing negative pixel indices to ia_sample_batch.
-        i_m, i_e = r_m * W + c_m, r_e * W + c_e
-        i_m = torch.where(i_m < 0, uniform(u_m), i_m)
-        i_e = torch.where(i_e < 0, uniform(u_e), i_e)
-        return torch.cat([i_m, i_e, uniform(u_r)])
+        # The reference raises there (np.random.randint(0, 0)); here those draws fall back to uniform pixels,
+        # clamp(floor(u H W), max = H W - 1) -- like PatchSampler's empty-mask branch -- instead of handing negative pixel indices
+        # to ia_sample_batch.  One launch (`ia_edge_indices`) for the index arithmetic, the fallbacks and the concatenation
+        # (it was ~20 small torch launches of a 1.2 ms refine step).
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        d = draws[:n].float().contiguous()
+        _lib.check(_lib.lib().ia_edge_indices(_lib.ptr(r_m), _lib.ptr(c_m), _lib.ptr(r_e), _lib.ptr(c_e), _lib.ptr(d), self.num_mask, self.num_edge,
+                                              self.num_rand, H, W, _lib.ptr(out), _lib.stream()), "ia_edge_indices")
+        return out
 
     def sample(self, mask, *args, draws=None, generator=None):
         mask2d = mask if mask.dim() == 2 else mask.reshape(mask.shape[0], -1)
