@@ -102,7 +102,7 @@ class ForwardDeformer(torch.nn.Module):
         return self._grid_c
 
     # -- per frame --------------------------------------------------------------
-    def precompute(self, tfs, want_voxel_d=True):
+    def precompute(self, tfs, want_voxel_d=True, want_bbox=True):
         _lib.require_cuda(tfs, self.lbs_voxel_final)
         assert tfs.shape[0] == 1, "skinning-voxel kernels are batch-1 (so are the reference's, SURVEY 2.1)"
         d, h, w = self.resolution // 4, self.resolution, self.resolution
@@ -115,10 +115,11 @@ class ForwardDeformer(torch.nn.Module):
                                    device=tfs.device)
         tfs_c = tfs.detach().float().contiguous()
         _lib.check(_lib.lib().ia_precompute_ws(_lib.ptr(self.lbs_voxel_final), _lib.ptr(tfs_c), _lib.ptr(fr["J"]),
-                                               _lib.ptr(fr["d"]) if want_voxel_d else None, _lib.ptr(fr["bbox"]),
+                                               _lib.ptr(fr["d"]) if want_voxel_d else None, _lib.ptr(fr["bbox"]) if want_bbox else None,
                                                C.byref(self.grid_desc()), _lib.ptr(fr["ws"]), fr["ws"].numel(), _lib.stream()),
                    "ia_precompute_ws")
-        self.voxel_J_cl, self.voxel_d, self.bbox_deformed = fr["J"], fr["d"], fr["bbox"]
+        # (voxel_d / bbox_deformed None: not computed for this frame -- SNARFDeformer.get_bbox_deformed recomputes on demand)
+        self.voxel_J_cl, self.voxel_d, self.bbox_deformed = fr["J"], (fr["d"] if want_voxel_d else None), (fr["bbox"] if want_bbox else None)
 
     @property
     def voxel_J(self):

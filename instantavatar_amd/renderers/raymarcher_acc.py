@@ -343,8 +343,18 @@ class Raymarcher(torch.nn.Module):
         grid = self.density_grid_train
         occ = self._occ_desc_cached(grid)
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        k = len(deformer.deformer.init_bones)
+        cand_cap = min(cap * k, self.train_cand_capacity)
+        from ..training import ZeroPool, field_autograd, pooled_zeros
+        if torch.is_grad_enabled():
+            # ONE zero-fill for the step's zero-initialised work tensors (closed by training_step): the two device counters,
+            # field outputs [V,3] + [V], dense weights [n,S], the compositor's candidate gradients [V,3] + [V], the loss values
+            ZeroPool.current = ZeroPool(8 * cand_cap + n * S + 2048, dev)
+        # the step's two device-side counters as ONE int32 pair: [samples, candidates] -- zeroed with the pool, copied to the host
+        # in one transfer (`_train_counts_post`)
+        counts = pooled_zeros((2,), dev).view(torch.int32)
         st = dict(s_pts=torch.empty((cap, 3), device=dev), s_z=torch.empty(cap, device=dev), s_slot=i32(cap),
-                  ray_off=i32(n), ray_cnt=i32(n), n_samples=i32(1), near=near, far=far, n=n, S=S)
+                  ray_off=i32(n), ray_cnt=i32(n), n_samples=counts[0:1], near=near, far=far, n=n, S=S)
         draws = getattr(self, "train_draws", None) or {}                           # injected by reproducible tests
         jitter = draws["ray_jitter"].to(dev).float().reshape(n, S).contiguous() if "ray_jitter" in draws else torch.rand((n, S), device=dev)  # :156
         want_J_inv = deformer.tfs.requires_grad and torch.is_grad_enabled() and deformer.deformer.version == 1
@@ -353,10 +363,8 @@ class Raymarcher(torch.nn.Module):
                                                 C.byref(occ), S, _lib.ptr(jitter), _lib.ptr(st["s_pts"]), _lib.ptr(st["s_z"]),
                                                 _lib.ptr(st["s_slot"]), _lib.ptr(st["ray_off"]), _lib.ptr(st["ray_cnt"]),
                                                 _lib.ptr(st["n_samples"]), cap, _lib.stream()), "ia_march_train_compact")
-            k = len(deformer.deformer.init_bones)
-            cand_cap = min(cap * k, self.train_cand_capacity)
             sc = deformer.search_compact(st["s_pts"], n_pts_dev=st["n_samples"], cap=cand_cap,
-                                         want_J_inv=want_J_inv)
+                                         want_J_inv=want_J_inv, n_cand_out=counts[1:2])
         # No host read: the field runs on a capacity-sized candidate buffer with the device-side
         # count (kernels clamp to it).  The counts of step i are copied to pinned memory and looked
         # at during step i+1: a step whose candidates exceeded the capacity (they were dropped) is
@@ -366,14 +374,9 @@ class Raymarcher(torch.nn.Module):
                   bg=bg_color.reshape(-1, 3).float().contiguous() if bg_color is not None else None,
                   noise=(draws["noise"].to(dev).float().reshape(n, S).contiguous() if "noise" in draws else torch.randn((n, S), device=dev))
                   if noise > 0 else None, noise_scale=float(noise))                # :167
-        from ..training import ZeroPool, field_autograd
-        if torch.is_grad_enabled():
-            # ONE zero-fill for the step's zero-initialised work tensors (closed by training_step): field outputs [V,3] + [V],
-            # dense weights [n,S], the compositor's candidate gradients [V,3] + [V], the loss values, + alignment slack
-            ZeroPool.current = ZeroPool(8 * cand_cap + n * S + 1024, dev)
         # (SMPL refinement: the candidates carry the implicit-differentiation gradient to tfs, deformer_torch.py:50-67)
         rgb_c, sig_c = field_autograd(net, deformer.candidates_with_grad(sc), n_dev=sc["n_cand"])
-        self._train_counts_post(st["n_samples"], sc["n_cand"], cand_cap)
+        self._train_counts_post(counts, cand_cap)
         # device-side overflow flag of THIS step: candidates past the capacity were dropped (in atomic-arrival order), so the
         # step's gradients are wrong -- `training_step` feeds the flag to the optimiser's found_inf, the update is skipped on
         # the device without a host read; the deferred count check then grows the capacity and the next steps are whole
@@ -390,10 +393,11 @@ class Raymarcher(torch.nn.Module):
     train_cand_capacity = 1 << 20
     train_overflow = 0
 
-    def _train_counts_post(self, n_samples, n_cand, cand_cap):
+    def _train_counts_post(self, counts, cand_cap):
+        """counts: device int32 [2] = [samples, candidates] of this step -> pinned host pair, one asynchronous copy"""
         if not hasattr(self, "_tc_host"):
             self._tc_host = torch.zeros(2, dtype=torch.int32).pin_memory()
-        self._tc_host.copy_(torch.cat([n_samples, n_cand]), non_blocking=True)
+        self._tc_host.copy_(counts, non_blocking=True)
         if getattr(self, "_graph_capture", False):
             return   # recorded into a graph: the replaying caller marks the copy with `_train_counts_posted`
         self._train_counts_posted(cand_cap)

@@ -547,7 +547,12 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
             batch["near"] = (dist - 1).reshape(1, *([1] * (batch["near"].dim() - 1))).expand_as(batch["near"]).contiguous()
             batch["far"] = (dist + 1).reshape(1, *([1] * (batch["far"].dim() - 1))).expand_as(batch["far"]).contiguous()
     model.renderer.idx = int(batch["idx"][0]) if "idx" in batch else 0
-    model.deformer.prepare_deformer(batch)
+    from .deformers.snarf_deformer import SNARFDeformer
+    prep = model.deformer.prepare_deformer
+    if type(model.deformer) is SNARFDeformer and getattr(prep, "__func__", None) is SNARFDeformer.prepare_deformer:
+        prep(batch, want_bbox=False)   # no consumer of the deformed-voxel box in a training step (computed on demand otherwise)
+    else:                              # (another deformer plugin, or a caller's wrapper around the method)
+        prep(batch)
     reducer = parallel.GradReducer(world_size)
     parallel.set_current_reducer(reducer if reducer.active else None)
     try:
