@@ -246,6 +246,34 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
+def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25):
+    """it/s of the fit stage (drivers/fit.py: `training_step` with the SMPLDeformer plugin, SMPLParamEmbedding tables for betas /
+    pose / translation under optimisation, NGPLoss with the depth term, PatchSampler 4 x 32^2) on synthetic frames: the body model
+    forward + backward as `ia_smpl_lbs_fwd/_bwd`, the render over compact samples (`render_train_fused_smpl`).  Wall clock of
+    `n_steps` eager steps between two device synchronisations."""
+    from instantavatar_amd.drivers import fit as fit_driver
+    from instantavatar_amd.training import NGPLoss, configure_optimizer, training_step
+    frames, body_model, _ = fit_driver.synthetic_frames(dev, res=res, n_frames=n_frames, noise=0.02, patch=32)
+    model = fit_driver.build_fit_model(frames, body_model, dev)
+    opt = configure_optimizer(model, lr=1e-3, smpl_lr=1e-4)
+    loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
+    model.train()
+    first = last = None
+    for it in range(warmup):
+        out = training_step(model, frames.batch(it % n_frames), opt, loss_fn)
+        first = float(out["mse_loss"]) if first is None else first
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(n_steps):
+        out = training_step(model, frames.batch(it % n_frames), opt, loss_fn)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = float(out["mse_loss"])
+    return {"it_per_sec": n_steps / dt, "ms_per_step": dt / n_steps * 1e3, "steps": n_steps, "mse_first": first, "mse_last": last,
+            "config": "SNARF_NGP_fitting analogue: SMPLDeformer + SMPLParamEmbedding (betas, pose, transl optimised), %d frames %dx%d, 4 x 32^2 patches, "
+                      "eager steps" % (n_frames, res, res), "launch_mode": "eager"}
+
+
 def frame_coherent_samples(model, batch, res):
     """Canonical-space field samples of one real frame, in the order the pipeline produces them:
     for every ray that hits the body a run of march steps around the rendered depth (ray-major,
@@ -1039,6 +1067,13 @@ def main():
                     result["train"]["refine"]["eager"] = {k: e[k] for k in ("it_per_sec", "launch_mode")}
             except Exception as e:
                 result["train"]["refine"] = {"error": repr(e)[:300]}
+            # the fit stage (fit.py with deformer=smpl: the step before train.py in the Neuman pipeline, bash/run-neuman-demo.sh:6):
+            # SMPLDeformer + SMPL parameter tables + a fresh field on 4 x 32^2 patches of 256^2 frames, eager steps
+            if world_size == 1:
+                try:
+                    result["train"]["fit_stage"] = fit_stage_throughput(dev, max(args.train_steps, 20))
+                except Exception as e:
+                    result["train"]["fit_stage"] = {"error": repr(e)[:300]}
             hj, hsrc = _profile_json("pmc_hgbwd", ("ia_field.hip",))
             # the training step's dominant kernel against the measured atomic-request ceiling (PMC pass on this build)
             result["train"]["hashgrid_bwd_atomics"] = dict(hj.get("k_hashgrid_bwd<16>", {}), source=hsrc) if hj is not None else {"source": hsrc}

@@ -115,7 +115,9 @@ def test_fit_fused_route_equals_dense_route(blend):
         assert not bad, (r1, r0, bad)
     # (1) the RENDER routes on bit-identical T_inv / vertices (both from the fused body model): the same samples, the same nearest
     #     vertices -> equal up to summation order (fp32 atomics of the scatters)
-    compare("fused", "fused-lbs+dense-render", 0.9999, 1e-2, 1e-4)     # (measured: cos >= 0.999993, rel 4e-5 .. 6e-3)
+    # (losses: reg_density = mean(entropy) + 0.313262 is the small difference of two numbers of size 0.313 -- 6.8e-4 -- so the two
+    #  summation orders of its 10^6-element mean show at ~1e-4 relative)
+    compare("fused", "fused-lbs+dense-render", 0.9999, 1e-2, 1e-3)     # (measured: cos >= 0.999993, rel 4e-5 .. 6e-3)
     # (2) the two BODY-MODEL routes under the same (dense) render: T_inv and the vertices agree to ~5e-5 (and their gradients to 4e-7:
     #     test_smpl_deformer_prepare_three_routes...), so a handful of samples change their nearest vertex or cross the 5 cm
     #     validity threshold, and with them their gradient contributions (measured cos 0.9991 .. 0.99999, rel 2e-3 .. 6e-2)
