@@ -169,10 +169,6 @@ size_t ia_precompute_workspace_bytes(const ia_snarf_grid *grid);
 int ia_precompute_ws(const float *voxel_w, const float *tfs, float *voxel_J,
                      float *voxel_d, float *bbox, const ia_snarf_grid *grid,
                      void *ws, size_t ws_bytes, void *stream);
-/* The same pass from a CHANNEL-LAST copy of the weights, voxel_w_cl [D,H,W,24] (what the implicit-differentiation kernels
- * read): both big streams contiguous, records staged through LDS.  Needs D*H*W % 128 == 0; results bit-identical.       */
-int ia_precompute_cl(const float *voxel_w_cl, const float *tfs, float *voxel_J, float *voxel_d, float *bbox,
-                     const ia_snarf_grid *grid, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- a4 + a5: Broyden search + duplicate filter ----------------------------
  * Replaces fuse_broyden(...) + filter(x, mask)

@@ -64,7 +64,6 @@ _SIGS = {
     "ia_precompute": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP]),
     "ia_precompute_workspace_bytes": (C.c_size_t, [C.POINTER(SnarfGrid)]),
     "ia_precompute_ws": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP, C.c_size_t, _VP]),
-    "ia_precompute_cl": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.POINTER(SnarfGrid), _VP, C.c_size_t, _VP]),
     "ia_snarf_search": (C.c_int, [_VP, C.c_int, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.POINTER(SnarfGrid),
                                   C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
     "ia_snarf_search_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int,

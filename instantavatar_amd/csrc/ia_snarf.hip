@@ -453,102 +453,6 @@ __global__ __launch_bounds__(256) void k_precompute(const float *__restrict__ vo
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// a3 from a CHANNEL-LAST copy of the skinning weights ([D][H][W][24] fp32: the layout the implicit-differentiation kernels
-// already use) -- both big streams contiguous.  k_precompute reads 24 channel-major planes 2 MB apart (a wave touches 24
-// streams, 1 KB each per trip); here a wave owns 128 consecutive voxels: it reads their 12 288 contiguous bytes with twelve
-// coalesced 16-byte loads per lane, stages them in LDS (row stride 7 float4: conflict-free for the per-voxel reads), blends
-// voxels `lane` and `lane + 64`, stages the 48-byte records in the same LDS and writes the 6 144 contiguous output bytes with
-// six coalesced stores per lane.  Same arithmetic, same order (j ascending, fmaf): bit-identical to k_precompute.
-// ---------------------------------------------------------------------------------------------------------------------
-#define IA_PCL_VOX 128   // voxels per wave
-__global__ __launch_bounds__(256) void k_precompute_cl(const float *__restrict__ voxel_w_cl, const float *__restrict__ tfs,
-                                                       float *__restrict__ voxel_J, float *__restrict__ voxel_d,
-                                                       float *__restrict__ partial, SnarfGridDev g) {
-  constexpr int RS = 7;                                   // float4 per staged weight row (6 used)
-  __shared__ float4 s_stage[4 * IA_PCL_VOX * RS];         // 57 344 B per workgroup
-  const int n = g.D * g.H * g.W;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 *const sw = s_stage + wave * (IA_PCL_VOX * RS);
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  const int n_runs = n / IA_PCL_VOX;                      // (host: n % 128 == 0)
-  for (int run = blockIdx.x * 4 + wave; run < n_runs; run += gridDim.x * 4) {
-    const int v0 = run * IA_PCL_VOX;
-    const float4 *src = reinterpret_cast<const float4 *>(voxel_w_cl + (size_t)v0 * 24);
-    float4 in[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) in[k] = src[k * 64 + lane];          // 768 float4 = 128 voxels x 6
-#pragma unroll
-    for (int k = 0; k < 12; k++) { const int e = k * 64 + lane; sw[(e / 6) * RS + e % 6] = in[k]; }
-    __builtin_amdgcn_wave_barrier();
-    float J[2][12];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-      for (int c = 0; c < 12; c++) J[h][c] = 0.f;
-    // precompute.cu:51-59: J[c] accumulates over j in joint order; tfs is wave-uniform (scalar loads), four joints per LDS read
-#pragma unroll 1
-    for (int q = 0; q < 6; q++) {
-      const float4 wa = sw[lane * RS + q], wb = sw[(lane + 64) * RS + q];
-      const float w0[4] = {wa.x, wa.y, wa.z, wa.w}, w1[4] = {wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int j = q * 4 + r;
-#pragma unroll
-        for (int c = 0; c < 12; c++) {
-          const float t = tfs[j * 16 + c];
-          J[0][c] = __builtin_fmaf(w0[r], t, J[0][c]);
-          J[1][c] = __builtin_fmaf(w1[r], t, J[1][c]);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();                                   // the weight rows are consumed: the stage is reused for the records
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int vl = lane + 64 * h;
-      sw[vl * 3 + 0] = make_float4(J[h][0], J[h][1], J[h][2], J[h][3]);
-      sw[vl * 3 + 1] = make_float4(J[h][4], J[h][5], J[h][6], J[h][7]);
-      sw[vl * 3 + 2] = make_float4(J[h][8], J[h][9], J[h][10], J[h][11]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    float4 *const o = reinterpret_cast<float4 *>(voxel_J + (size_t)v0 * 12);
-#pragma unroll
-    for (int k = 0; k < 6; k++) o[k * 64 + lane] = sw[k * 64 + lane];   // 384 float4 = 128 records, contiguous
-    __builtin_amdgcn_wave_barrier();
-    const int hw = g.H * g.W;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int index = v0 + lane + 64 * h;
-      const int idx_d = index / hw, idx_h = index % hw / g.W, idx_w = index % hw % g.W;
-      // precompute.cu:42-47
-      const float cx = (((float)idx_w) / (g.W - 1) * 2 - 1) / g.scl[0] - g.off[0];
-      const float cy = (((float)idx_h) / (g.H - 1) * 2 - 1) / g.scl[1] - g.off[1];
-      const float cz = (((float)idx_d) / (g.D - 1) * 2 - 1) / g.scl[2] - g.off[2];
-#pragma unroll
-      for (int i0 = 0; i0 < 3; i0++) {   // precompute.cu:66-70
-        const float xi = IA_DOT3(J[h][i0 * 4 + 0], cx, J[h][i0 * 4 + 1], cy, J[h][i0 * 4 + 2], cz) + J[h][i0 * 4 + 3];
-        mn[i0] = fminf(mn[i0], xi);
-        mx[i0] = fmaxf(mx[i0], xi);
-        if (voxel_d) voxel_d[(size_t)i0 * n + index] = xi;
-      }
-    }
-  }
-  if (partial) {
-    __shared__ float s_red[4][6];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float a = ia_wave_min(mn[c]), b = ia_wave_max(mx[c]);
-      if (lane == 0) { s_red[wave][c] = a; s_red[wave][3 + c] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-      float r = s_red[0][threadIdx.x];
-      for (int w = 1; w < 4; w++) r = threadIdx.x < 3 ? fminf(r, s_red[w][threadIdx.x]) : fmaxf(r, s_red[w][threadIdx.x]);
-      partial[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
-    }
-  }
-}
-
 // folds the per-workgroup extrema of k_precompute: one workgroup, component c = threadIdx.x % 6
 __global__ __launch_bounds__(384) void k_bbox_reduce(const float *__restrict__ partial, int n_blocks, float *__restrict__ bbox) {
   __shared__ float s_red[64][6];
@@ -627,31 +531,6 @@ extern "C" int ia_precompute_ws(const float *voxel_w, const float *tfs, float *v
   IA_LAUNCH_CHECK("k_precompute");
   if (partial) {
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(384), 0, s, partial, blocks, bbox);
-    IA_LAUNCH_CHECK("k_bbox_reduce");
-  }
-  return IA_OK;
-}
-
-// the same from the channel-last weights; ws: ia_precompute_workspace_bytes(grid) (needed only with bbox)
-extern "C" int ia_precompute_cl(const float *voxel_w_cl, const float *tfs, float *voxel_J, float *voxel_d, float *bbox,
-                                const ia_snarf_grid *grid, void *ws, size_t ws_bytes, void *stream) {
-  IA_CHECK_ARG(voxel_w_cl && tfs && voxel_J && grid, "ia_precompute_cl: null pointer");
-  IA_CHECK_ARG(grid->D > 1 && grid->H > 1 && grid->W > 1, "ia_precompute_cl: bad grid %d %d %d", grid->D, grid->H, grid->W);
-  const long n = (long)grid->D * grid->H * grid->W;
-  IA_CHECK_ARG(n % IA_PCL_VOX == 0, "ia_precompute_cl: the voxel count %ld must be a multiple of %d (use ia_precompute_ws)", n, IA_PCL_VOX);
-  hipStream_t s = (hipStream_t)stream;
-  long blocks = (n / IA_PCL_VOX + 3) / 4;
-  const int cap = ia_precompute_blocks(grid);     // the workspace holds six floats for at most this many workgroups
-  if (blocks > cap) blocks = cap;
-  float *partial = nullptr;
-  if (bbox) {
-    IA_CHECK_ARG(ws && ws_bytes >= (size_t)blocks * 6 * sizeof(float), "ia_precompute_cl: workspace of %zu bytes, %zu needed", ws_bytes, (size_t)blocks * 24);
-    partial = (float *)ws;
-  }
-  hipLaunchKernelGGL(k_precompute_cl, dim3((unsigned)blocks), dim3(256), 0, s, voxel_w_cl, tfs, voxel_J, voxel_d, partial, ia_make_grid_dev(grid));
-  IA_LAUNCH_CHECK("k_precompute_cl");
-  if (partial) {
-    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(384), 0, s, partial, (int)blocks, bbox);
     IA_LAUNCH_CHECK("k_bbox_reduce");
   }
   return IA_OK;
