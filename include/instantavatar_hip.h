@@ -134,7 +134,16 @@ size_t ia_smpl_query_workspace_bytes(int P);
 int ia_smpl_deform_query(const float *pts, int P, const int32_t *n_pts_dev, const float *verts,
                          const float *T_inv, int n_verts, float threshold, const ia_field *field,
                          float fill, int nan_to_num, float *rgb, float *sigma, void *ws,
-                         size_t ws_bytes, void *stream);
+                         size_t ws_bytes, const void *nn_grid, void *stream);
+/* Vertex grid for the fused SMPLDeformer queries (`nn_grid` above and in ia_smpl_nn_compact; NULL = brute force over all
+ * vertices).  The fused queries use a point's nearest vertex only when it is closer than `threshold` (smpl_deformer.py:102-104),
+ * and every such vertex lies in the 3 x 3 x 3 cells around the point when the cells are at least `threshold` wide: the posed
+ * vertices are binned once per frame (device-side counting sort; bounding box, dimensions and cell size are computed on the
+ * device, no host read) and a point is tested against the vertices of its 27 cells -- the same winner (smallest distance,
+ * lowest index among equals) for every valid point, nothing for the others.  grid: ia_smpl_nn_grid_bytes(n_verts) bytes,
+ * valid for the `verts` it was built from.  ia_smpl_nn_deform (every point, exact index) stays brute force.               */
+size_t ia_smpl_nn_grid_bytes(int n_verts);
+int ia_smpl_nn_grid_build(const float *verts, int n_verts, float threshold, void *grid, size_t grid_bytes, void *stream);
 
 /* ---- a20: skinning-weight voxelisation (one-time) ---------------------------
  * Replaces query_weights_smpl (fast_snarf/deformer_torch.py:225-244) including the
@@ -589,7 +598,7 @@ int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int
 /* ---- SMPLDeformer training query on compact samples (smpl_deformer.py:88-120 under autograd; fit stage) ----------------
  * ia_smpl_nn_compact:     nearest posed vertex of every sample point (K = 1 knn_points), pts_cano = T_inv[nearest] [pts, 1],
  *                         valid = dist^2 < threshold^2; the valid points compacted: cand_xc [<= P,3], cand_pt [<= P] (the point of
- *                         a candidate), idx [P] (vertex of every point), pt_off [P] / pt_cnt [P] (0 | 1: the compositor's
+ *                         a candidate), idx [P] (vertex of every point; with `nn_grid`: of every VALID point, -1 elsewhere), pt_off [P] / pt_cnt [P] (0 | 1: the compositor's
  *                         candidate lists with n_init = 1), *n_cand (device counter, zeroed by the call).
  * ia_smpl_nn_compact_bwd: d_cand_xc [cap,3] -> d_T_inv [V,4,4] (zero-filled by the call; d T_inv[idx] += g [x, 1]^T, rows 0..2)
  *                         and d_pts [P,3] (zero-filled; R(T_inv[idx])^T g for the points that have a candidate).  Either may be NULL.
@@ -597,7 +606,7 @@ int ia_selftest_jinv_update(const float *Ji, const float *x, const float *g, int
  *                         d_o [n_rays,3] = sum over the ray's compact samples of d_pts, d_d = the same weighted with z.    */
 int ia_smpl_nn_compact(const float *pts, int P, const int32_t *n_pts_dev, const float *verts, const float *T_inv,
                        int n_verts, float threshold, float *cand_xc, int32_t *cand_pt, int32_t *idx, int32_t *pt_off,
-                       uint8_t *pt_cnt, int32_t *n_cand, void *stream);
+                       uint8_t *pt_cnt, int32_t *n_cand, const void *nn_grid, void *stream);
 int ia_smpl_nn_compact_bwd(const float *pts, int P, const int32_t *cand_pt, const int32_t *idx, const int32_t *n_cand, int cap,
                            const float *T_inv, int n_verts, const float *d_cand_xc, float *d_T_inv, float *d_pts,
                            void *stream);

@@ -99,7 +99,9 @@ _SIGS = {
     "ia_smpl_nn_deform": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP]),
     "ia_smpl_query_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ia_smpl_deform_query": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, C.POINTER(Field), C.c_float,
-                                       C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+                                       C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP]),
+    "ia_smpl_nn_grid_bytes": (C.c_size_t, [C.c_int]),
+    "ia_smpl_nn_grid_build": (C.c_int, [_VP, C.c_int, C.c_float, _VP, C.c_size_t, _VP]),
     "ia_snarf_implicit_bwd_workspace_bytes": (C.c_size_t, [C.c_long]),
     "ia_snarf_implicit_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, _VP, C.POINTER(SnarfGrid), _VP, _VP, C.c_size_t, _VP]),
     "ia_snarf_implicit_bwd_compact": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, C.c_int, C.POINTER(SnarfGrid), _VP, _VP, C.c_size_t, _VP]),
@@ -147,7 +149,7 @@ _SIGS = {
     "ia_search_kernel_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "ia_frame_stats": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "ia_pack_rgba8": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
-    "ia_smpl_nn_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ia_smpl_nn_compact": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ia_smpl_nn_compact_bwd": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "ia_ray_samples_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ia_smpl_lbs_workspace_bytes": (C.c_size_t, [C.c_int]),

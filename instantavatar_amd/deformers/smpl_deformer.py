@@ -162,6 +162,7 @@ class SMPLDeformer():
             if not self.initialized:     # `initialize` (the reference re-runs it every frame: betas may change)
                 self.bbox = get_bbox_from_smpl(verts_t.detach())
             self.T_inv, self.vertices, self.w2s = T_inv, verts, w2s
+            self._build_nn_grid()
             return
         if not self.initialized:
             self.initialize(smpl_params["betas"], device)  # the reference re-initialises every frame (betas may change)
@@ -179,6 +180,33 @@ class SMPLDeformer():
         self.T_inv = small_matmul(self.T_template, T_inv).float().contiguous()
         self.vertices = ((out.vertices @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]).float().contiguous()
         self.w2s = w2s
+        self._build_nn_grid()
+
+    #: the fused queries look for the nearest vertex in a per-frame vertex grid (`ia_smpl_nn_grid_build`) instead of testing
+    #: all vertices; False = brute force (the checker: tests/test_gpu_smpl_deformer.py)
+    use_nn_grid = True
+
+    def _build_nn_grid(self):
+        """bin this frame's posed vertices (four small launches, no host read); the buffer is per deformer and reused"""
+        self._nn_grid_ok = False
+        if not (self.use_nn_grid and torch.is_tensor(self.vertices) and self.vertices.is_cuda and self.vertices.shape[0] == 1):
+            return
+        L = _lib.lib()
+        V = self.vertices.shape[1]
+        buf = _lib.scratch(self, "_nn_grid_buf", L.ia_smpl_nn_grid_bytes(V), self.vertices.device)
+        v = self.vertices.detach()
+        _lib.check(L.ia_smpl_nn_grid_build(_lib.ptr(v), V, float(self.threshold), _lib.ptr(buf), buf.numel(), _lib.stream()), "ia_smpl_nn_grid_build")
+        self._nn_grid_ok = True
+        self._nn_grid_key = (self.vertices.data_ptr(), self.vertices._version, float(self.threshold))
+
+    def nn_grid_ptr(self):
+        """device pointer of the vertex grid of the CURRENT vertices, or None (brute force)"""
+        if not (getattr(self, "_nn_grid_ok", False) and self.use_nn_grid):
+            return None
+        v = self.vertices     # (somebody replaced or rewrote the vertices, or changed the threshold, after prepare_deformer: brute force)
+        if self._nn_grid_key != (v.data_ptr(), v._version, float(self.threshold)):
+            return None
+        return _lib.ptr(self._nn_grid_buf)
 
     def release_graph(self):
         """drop the autograd graph held by the per-frame attributes (see SNARFDeformer.release_graph)"""
@@ -240,7 +268,7 @@ class SMPLDeformer():
         _lib.check(L.ia_smpl_deform_query(_lib.ptr(x), P, None, _lib.ptr(self.vertices), _lib.ptr(self.T_inv),
                                           self.vertices.shape[1], float(self.threshold), C.byref(net.field_desc(P)),
                                           float(fill), int(nan_to_num), _lib.ptr(rgb), _lib.ptr(sigma), _lib.ptr(ws),
-                                          ws.numel(), _lib.stream()), "ia_smpl_deform_query")
+                                          ws.numel(), self.nn_grid_ptr(), _lib.stream()), "ia_smpl_deform_query")
         return rgb, sigma
 
     @staticmethod

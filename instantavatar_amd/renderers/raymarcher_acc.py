@@ -85,7 +85,7 @@ class _SmplDeformCompactFn(torch.autograd.Function):
         n_cand = torch.empty(1, dtype=torch.int32, device=dev)
         _lib.check(L.ia_smpl_nn_compact(_lib.ptr(x), P, _lib.ptr(n_pts_dev), _lib.ptr(deformer.vertices.detach()), _lib.ptr(Ti), V,
                                         float(deformer.threshold), _lib.ptr(cand_xc), _lib.ptr(cand_pt), _lib.ptr(idx), _lib.ptr(pt_off),
-                                        _lib.ptr(pt_cnt), _lib.ptr(n_cand), _lib.stream()), "ia_smpl_nn_compact")
+                                        _lib.ptr(pt_cnt), _lib.ptr(n_cand), deformer.nn_grid_ptr(), _lib.stream()), "ia_smpl_nn_compact")
         out.update(pt_off=pt_off, pt_cnt=pt_cnt, n_cand=n_cand)
         ctx.save_for_backward(x, Ti, cand_pt, idx, n_cand)
         ctx.shapes = (pts.shape, T_inv.shape)

@@ -91,6 +91,56 @@ def test_fused_query_matches_oracle_and_generic_route(oracle, sw):
     assert np.array_equal(sig_t[valid_o], sig_g[valid_o])
 
 
+def test_vertex_grid_query_equals_brute_force(oracle, sw):
+    """The fused queries with the per-frame vertex grid (`ia_smpl_nn_grid_build`: a point is tested against the vertices of its
+    27 cells) against the brute-force search over all 6 890 vertices: identical validity, identical nearest vertex and canonical
+    position for every valid point, identical (rgb, sigma) -- on points around the body, far away, on the grid's faces, at vertices
+    (distance 0: ties between coincident ring vertices are broken by the lowest index) and non-finite."""
+    import ctypes as C
+    from instantavatar_amd import _lib
+    model = sw[0]
+    _prep(oracle, sw, 4)
+    d, net = model.deformer, model.net_coarse
+    assert d.nn_grid_ptr() is not None
+    v = d.vertices[0].cpu().numpy()
+    rng = np.random.RandomState(12)
+    n = 60011
+    pts = (v[rng.randint(0, len(v), n)] + rng.randn(n, 3).astype(np.float32) * 0.04).astype(np.float32)
+    pts[:2000] = v[rng.randint(0, len(v), 2000)]                                   # exactly on vertices
+    pts[2000:4000] = rng.uniform(-3, 3, (2000, 3)).astype(np.float32)              # mostly far from the body
+    lo, hi = v.min(0), v.max(0)
+    pts[4000:5000] = (lo + (hi - lo) * rng.randint(0, 2, (1000, 3))) + rng.randn(1000, 3).astype(np.float32) * 0.06   # around the box corners / faces
+    pts[5000] = [np.nan, 0, 0]; pts[5001] = [np.inf, 0, 0]; pts[5002] = [1e30, -1e30, 0]
+    x = torch.as_tensor(pts, device=DEV)
+    res = {}
+    for use in (True, False):
+        d.use_nn_grid = use
+        try:
+            with torch.no_grad():
+                rgb, sig = d(x, net, eval_mode=True)
+            P, V = n, d.vertices.shape[1]
+            out = dict(cand=torch.empty((P, 3), device=DEV), cand_pt=torch.empty(P, dtype=torch.int32, device=DEV), idx=torch.empty(P, dtype=torch.int32, device=DEV),
+                       off=torch.empty(P, dtype=torch.int32, device=DEV), cnt=torch.empty(P, dtype=torch.uint8, device=DEV), n=torch.empty(1, dtype=torch.int32, device=DEV))
+            _lib.check(_lib.lib().ia_smpl_nn_compact(_lib.ptr(x), P, None, _lib.ptr(d.vertices), _lib.ptr(d.T_inv), V, float(d.threshold), _lib.ptr(out["cand"]),
+                                                     _lib.ptr(out["cand_pt"]), _lib.ptr(out["idx"]), _lib.ptr(out["off"]), _lib.ptr(out["cnt"]), _lib.ptr(out["n"]),
+                                                     d.nn_grid_ptr(), _lib.stream()), "ia_smpl_nn_compact")
+            assert (d.nn_grid_ptr() is not None) == use
+        finally:
+            d.use_nn_grid = True
+        res[use] = (rgb.cpu(), sig.cpu(), {k: t.cpu().numpy() for k, t in out.items()})
+    (r1, s1, o1), (r0, s0, o0) = res[True], res[False]
+    assert torch.equal(r1, r0) and torch.equal(s1, s0)
+    valid = o0["cnt"].astype(bool)
+    assert np.array_equal(o1["cnt"], o0["cnt"]) and int(o1["n"][0]) == int(o0["n"][0]) == int(valid.sum())
+    assert 0.3 < valid.mean() < 0.95 and not valid[5000:5003].any()
+    assert np.array_equal(o1["idx"][valid], o0["idx"][valid]) and (o1["idx"][~valid] == -1).all()
+    assert np.array_equal(o1["cand"][o1["off"][valid]], o0["cand"][o0["off"][valid]])
+    assert np.array_equal(o1["cand_pt"][o1["off"][valid]], np.flatnonzero(valid))
+    # ... and the brute-force reference of both is the oracle's nearest-vertex search
+    _, valid_o, idx_o = oracle.smpl_nn_deform(pts, v, d.T_inv[0].cpu().numpy(), d.threshold)
+    assert np.array_equal(valid_o, valid) and np.array_equal(idx_o[valid], o1["idx"][valid])
+
+
 def test_rendered_frame_matches_oracle(oracle, sw):
     """render_image_fast with the SMPLDeformer plugin (occupancy build + wave-front loop through the
     renderer's generic closure route) against the oracle: rgb / alpha within 1e-3."""
