@@ -30,6 +30,12 @@ class SMPLOutput:  # smplx/utils.py:59 (fields used on the path)
     pose_offsets: Optional[torch.Tensor] = None
 
 
+def _abs_smpl(p):
+    """model_path as the plugins resolve it (hydra.utils.to_absolute_path when hydra is there, the path itself otherwise)"""
+    from .snarf_deformer import _abs_path
+    return _abs_path(p)
+
+
 def batch_rodrigues(rot_vecs):
     """lbs.py:295-329"""
     angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)

@@ -116,16 +116,32 @@ def synthetic_frames(device, res=128, n_frames=4, noise=0.02, seed=0, patch=32, 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--synthetic", action="store_true", required=True)
+    ap.add_argument("--synthetic", action="store_true", help="frames rendered from the synthetic avatar, perturbed initial SMPL parameters")
+    ap.add_argument("--frames", help="npz of a pre-decoded sequence (drivers.train --frames: images uint8 [N,H,W,3], masks, K, (c2w), betas, "
+                                     "global_orient, body_pose, transl = the initial SMPL parameters, e.g. the output of a pose estimator)")
+    ap.add_argument("--smpl-dir", default="./data/SMPLX/smpl")
+    ap.add_argument("--gender", default="neutral")
+    ap.add_argument("--synthetic-body", action="store_true", help="--frames: the synthetic SMPL-like body instead of a SMPL pickle from --smpl-dir")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--out", default="outputs/fit")
     args = ap.parse_args(argv)
+    if bool(args.synthetic) == bool(args.frames):
+        ap.error("exactly one of --synthetic / --frames <npz> is required")
     from .launch import Launch
     launch = Launch.from_env(who="fit")
     try:
         device = launch.device
-        frames, body_model, _ = synthetic_frames(device, res=args.res)
+        if args.frames:
+            # confs/SNARF_NGP_fitting.yaml: deformer=smpl, sampler=patch -- the sequence from pre-decoded arrays (see drivers/train.py)
+            from . import config as cfg
+            from .train import load_frames
+            from ..deformers.smplx import _abs_smpl
+            confs = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "confs")
+            frames = load_frames(args.frames, cfg.instantiate(cfg.load_group(confs, "sampler", "patch", {})), device)
+            body_model = (SMPL.from_dict(synthetic.make_body()) if args.synthetic_body else SMPL(_abs_smpl(args.smpl_dir), gender=args.gender)).to(device)
+        else:
+            frames, body_model, _ = synthetic_frames(device, res=args.res)
         model = build_fit_model(frames, body_model, device)
         losses = fit_sequence(model, frames, args.steps, rank=launch.rank, world_size=launch.world_size, log_every=50 if launch.is_main else 0)
         if launch.is_main:     # replicas are identical: rank 0 exports

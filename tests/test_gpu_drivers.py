@@ -161,3 +161,9 @@ def test_train_driver_takes_a_pre_decoded_sequence(tmp_path):
     assert torch.load(ckpt, weights_only=False)["global_step"] == 120
     with pytest.raises(AssertionError):
         _run("instantavatar_amd.drivers.train", ["--steps", "1"])          # neither --synthetic nor --frames
+    # the fit stage (fit.py, deformer=smpl) takes the same file: the SMPL parameters in it are the initial guesses it optimises
+    out = str(tmp_path / "fit")
+    text = _run("instantavatar_amd.drivers.fit", ["--frames", seq, "--synthetic-body", "--steps", "30", "--out", out])
+    assert "saved " in text and os.path.exists(os.path.join(out, "poses", "train.npz")), text
+    z = np.load(os.path.join(out, "poses", "train.npz"))
+    assert z["body_pose"].shape == (4, 69) and np.abs(z["body_pose"] - true["body_pose"]).max() > 0
