@@ -246,11 +246,12 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
             "note": "global batch = n_gpus x 4096 rays (weak scaling); occupancy update every 20 steps included"}
 
 
-def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25):
+def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25, graphed=True):
     """it/s of the fit stage (drivers/fit.py: `training_step` with the SMPLDeformer plugin, SMPLParamEmbedding tables for betas /
     pose / translation under optimisation, NGPLoss with the depth term, PatchSampler 4 x 32^2) on synthetic frames: the body model
-    forward + backward as `ia_smpl_lbs_fwd/_bwd`, the render over compact samples (`render_train_fused_smpl`).  Wall clock of
-    `n_steps` eager steps between two device synchronisations."""
+    forward + backward as `ia_smpl_lbs_fwd/_bwd`, the render over compact samples (`render_train_fused_smpl`), every frame's step
+    replayed from its own captured HIP graph (as drivers/fit.py runs it).  Wall clock of `n_steps` steps between two device
+    synchronisations."""
     from instantavatar_amd.drivers import fit as fit_driver
     from instantavatar_amd.training import NGPLoss, configure_optimizer, training_step
     frames, body_model, _ = fit_driver.synthetic_frames(dev, res=res, n_frames=n_frames, noise=0.02, patch=32)
@@ -258,20 +259,25 @@ def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25):
     opt = configure_optimizer(model, lr=1e-3, smpl_lr=1e-4)
     loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
     model.train()
+    from instantavatar_amd.training import GraphedTrainStep
+    stepper = GraphedTrainStep(model, opt, loss_fn, enabled=graphed)     # one captured graph per frame (a frame has its own occupancy grid)
     first = last = None
     for it in range(warmup):
-        out = training_step(model, frames.batch(it % n_frames), opt, loss_fn)
+        out = stepper(frames.batch(it % n_frames, out=stepper.inputs))
         first = float(out["mse_loss"]) if first is None else first
     torch.cuda.synchronize()
+    r0, e0 = stepper.replays, stepper.eager_steps
     t0 = time.perf_counter()
     for it in range(n_steps):
-        out = training_step(model, frames.batch(it % n_frames), opt, loss_fn)
+        out = stepper(frames.batch(it % n_frames, out=stepper.inputs))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     last = float(out["mse_loss"])
+    mode = ("hip_graph (%d replays, %d eager steps, %d graphs)" % (stepper.replays - r0, stepper.eager_steps - e0, len(stepper.graphs))
+            if stepper.enabled else "eager")
     return {"it_per_sec": n_steps / dt, "ms_per_step": dt / n_steps * 1e3, "steps": n_steps, "mse_first": first, "mse_last": last,
-            "config": "SNARF_NGP_fitting analogue: SMPLDeformer + SMPLParamEmbedding (betas, pose, transl optimised), %d frames %dx%d, 4 x 32^2 patches, "
-                      "eager steps" % (n_frames, res, res), "launch_mode": "eager"}
+            "config": "SNARF_NGP_fitting analogue: SMPLDeformer + SMPLParamEmbedding (betas, pose, transl optimised), %d frames %dx%d, 4 x 32^2 patches"
+                      % (n_frames, res, res), "launch_mode": mode, "graph_capture_error": stepper.capture_error}
 
 
 def frame_coherent_samples(model, batch, res):

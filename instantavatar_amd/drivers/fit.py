@@ -25,7 +25,7 @@ from ..models.networks.ngp import NeRFNGPNet
 from ..models.structures.body_model_param import SMPLParamEmbedding
 from ..pipeline import AvatarModel, build_synthetic_model, make_batch
 from ..renderers.raymarcher_acc import Raymarcher
-from ..training import NGPLoss, configure_optimizer, configure_scheduler, training_step
+from ..training import GraphedTrainStep, NGPLoss, configure_optimizer, configure_scheduler, training_step
 from ..utils.sampler import PatchSampler
 
 
@@ -42,7 +42,7 @@ def build_fit_model(frames, body_model, device, threshold=0.05, n_levels=16):
 
 
 def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, loss_opt=None, log_every=50, out=sys.stdout,
-                 generator=None, check_val_every_n_epoch=10, rank=0, world_size=1):
+                 generator=None, check_val_every_n_epoch=10, rank=0, world_size=1, graphed=True):
     """The optimisation loop of fit.py (trainer.fit with SNARF_NGP_fitting.yaml: Adam lr 1e-3, SMPL tables lr 1e-4, one frame
     per step; the LambdaLR steps once per validation run = every `check_val_every_n_epoch` epochs, DNeRF.py:163-166 -- see
     training.configure_scheduler).  Returns the last losses.
@@ -59,6 +59,9 @@ def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, lo
     sched = configure_scheduler(opt, max_epochs)
     loss_fn = NGPLoss(loss_opt or dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
     model.train()
+    # graphed (one rank): every frame's step is captured once -- a frame has its own occupancy grid, so one HIP graph per frame --
+    # and replayed afterwards; occupancy-update steps and a capture that fails run eagerly (training.GraphedTrainStep)
+    stepper = GraphedTrainStep(model, opt, loss_fn, world_size=world_size, enabled=graphed)
     n = len(frames)
     if generator is None and world_size > 1:
         generator = torch.Generator().manual_seed(42)      # the ranks must shuffle alike (pl.seed_everything(42) in the reference)
@@ -71,7 +74,7 @@ def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, lo
             if (it // per_epoch) % check_val_every_n_epoch == 0:
                 sched.step()
             order = torch.randperm(n, generator=generator).tolist()   # DataLoader(shuffle=True)
-        losses = training_step(model, frames.batch(order[((it % per_epoch) * world_size + rank) % n]), opt, loss_fn, world_size=world_size)
+        losses = stepper(frames.batch(order[((it % per_epoch) * world_size + rank) % n], out=stepper.inputs))
         if log_every and (it + 1) % log_every == 0:
             torch.cuda.synchronize()
             print("fit step %d  loss %.5f  mse %.5f  %.1f it/s" % (it + 1, float(losses["loss"].detach()), float(losses["mse_loss"].detach()),

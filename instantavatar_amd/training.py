@@ -633,6 +633,9 @@ class GraphedTrainStep:
     the graphs so that they are captured again with the grown capacity.  Learning rates are turned into
     device tensors, so that an `lr_scheduler` keeps working across replays."""
 
+    #: captured graphs kept alive (one per (noise, capacity, per-frame grid) state; each holds its own activation buffers)
+    max_graphs = 256
+
     def __init__(self, model, optimizer, loss_fn, world_size=1, is_refine=False, enabled=True, graph_collectives=None):
         """graph_collectives: capture the step of a multi-rank job too -- the bucketed RCCL all-reduce is recorded into the
         graph together with the kernels (collectives are capturable), so that an N-rank step is launched the same way as a
@@ -650,8 +653,14 @@ class GraphedTrainStep:
             # SMPL parameters under optimisation: capturable on the fused SNARF route only (the SMPLDeformer's training
             # query -- fit stage -- reads validity counts on the host and inverts 6 890 vertex transforms with the LU library)
             fused = getattr(model.deformer, "fused_train_route", None)
-            inner = getattr(model.deformer, "deformer", None)      # (SNARFDeformer; the SMPLDeformer's fit stage steps eagerly)
-            self.enabled = self.enabled and fused is not None and inner is not None and getattr(inner, "version", 1) == 1
+            inner = getattr(model.deformer, "deformer", None)      # SNARFDeformer's ForwardDeformer (version 2 + SMPL tables: dense route)
+            from .deformers.smpl_deformer import SMPLDeformer
+            if isinstance(model.deformer, SMPLDeformer):
+                # the fit stage (fit.py): capturable since round 6 (fused body model + compact render); one rank only -- every rank
+                # walks its own frames, so per-frame captures would happen at different steps on different ranks
+                self.enabled = self.enabled and fused is not None and not parallel.collectives_on(world_size)
+            else:
+                self.enabled = self.enabled and fused is not None and inner is not None and getattr(inner, "version", 1) == 1
         from .optim import FusedAdam
         if isinstance(optimizer, FusedAdam) and self.enabled:
             optimizer.fused_zero_grad = True    # the step leaves every gradient buffer zero-filled for the next one
@@ -759,7 +768,10 @@ class GraphedTrainStep:
         r._train_counts_check()                      # (pending event of a preceding eager step, if any)
         r._train_counts_peek(r.train_cand_capacity)
         use_noise = m.global_step < 1000 and not self.is_refine
-        key = (bool(use_noise), r.train_cand_capacity)
+        # (a renderer with one occupancy grid PER FRAME -- Raymarcher.initialize(N_frames), raymarcher_acc.py:45-50: the fit stage -- bakes
+        # the frame's grid into the captured launches: one graph per frame then, at most `max_graphs` of them alive)
+        grid_key = int(r.idx) if len(getattr(r, "density_grid_train_all", ())) > 1 else 0
+        key = (bool(use_noise), r.train_cand_capacity, grid_key)
         entry = self.graphs.get(key)
         if entry is None and not self._warmed:
             # one eager step on these inputs before the first capture of this state: lazy initialisation (pinned counter
@@ -772,6 +784,8 @@ class GraphedTrainStep:
             return training_step(m, self.inputs, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         if entry is None:
             self.graphs = {k: e for k, e in self.graphs.items() if k[1] == r.train_cand_capacity}
+            while len(self.graphs) >= self.max_graphs:          # oldest first (dicts keep insertion order)
+                self.graphs.pop(next(iter(self.graphs)))
             err = None
             try:
                 entry = self._capture(key, use_noise)
