@@ -249,8 +249,8 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
 def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25, graphed=True):
     """it/s of the fit stage (drivers/fit.py: `training_step` with the SMPLDeformer plugin, SMPLParamEmbedding tables for betas /
     pose / translation under optimisation, NGPLoss with the depth term, PatchSampler 4 x 32^2) on synthetic frames: the body model
-    forward + backward as `ia_smpl_lbs_fwd/_bwd`, the render over compact samples (`render_train_fused_smpl`), every frame's step
-    replayed from its own captured HIP graph (as drivers/fit.py runs it).  Wall clock of `n_steps` steps between two device
+    forward + backward as `ia_smpl_lbs_fwd/_bwd`, the render over compact samples (`render_train_fused_smpl`), the step replayed
+    from a captured HIP graph (as drivers/fit.py runs it).  Wall clock of `n_steps` steps between two device
     synchronisations."""
     from instantavatar_amd.drivers import fit as fit_driver
     from instantavatar_amd.training import NGPLoss, configure_optimizer, training_step
@@ -260,7 +260,7 @@ def fit_stage_throughput(dev, n_steps, res=256, n_frames=4, warmup=25, graphed=T
     loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
     model.train()
     from instantavatar_amd.training import GraphedTrainStep
-    stepper = GraphedTrainStep(model, opt, loss_fn, enabled=graphed)     # one captured graph per frame (a frame has its own occupancy grid)
+    stepper = GraphedTrainStep(model, opt, loss_fn, enabled=graphed)
     first = last = None
     for it in range(warmup):
         out = stepper(frames.batch(it % n_frames, out=stepper.inputs))

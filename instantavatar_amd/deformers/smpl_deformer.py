@@ -210,7 +210,8 @@ class SMPLDeformer():
 
     def release_graph(self):
         """drop the autograd graph held by the per-frame attributes (see SNARFDeformer.release_graph)"""
-        for name in ("T_inv", "vertices", "w2s"):
+        # (the template quantities of `initialize` carry the betas' graph on the torch route: the reference recomputes them every frame)
+        for name in ("T_inv", "vertices", "w2s", "T_template", "vs_template", "pose_offset_t", "shape_offset_t"):
             v = getattr(self, name, None)
             if torch.is_tensor(v) and v.requires_grad:
                 setattr(self, name, v.detach())

@@ -282,8 +282,12 @@ class SNARFDeformer():
             rays.near, rays.far = near.reshape(o.shape[:-1]), far.reshape(o.shape[:-1])
             return
         w2s = self.w2s
-        rays.o = (o @ w2s[:, :3, :3].permute(0, 2, 1)) + w2s[:, None, :3, 3]
-        rays.d = (d @ w2s[:, :3, :3].permute(0, 2, 1)).to(d)
+        # (the differentiable branch -- w2s under optimisation: fit stage, version 2 -- as broadcast multiply + sum: a [n,3] x [3,3]
+        # product is a library GEMM launch here, ~40 us forward and two more backward, and the only BLAS call of a fit step)
+        R = w2s[:, :3, :3]
+        shp_o, shp_d = o.shape, d.shape
+        rays.o = ((o.reshape(1, -1, 1, 3) * R[:, None, :, :]).sum(-1) + w2s[:, None, :3, 3]).reshape(shp_o)
+        rays.d = (d.reshape(1, -1, 1, 3) * R[:, None, :, :]).sum(-1).reshape(shp_d).to(d)
         dist = torch.norm(rays.o, dim=-1)
         rays.near, rays.far = dist - 1, dist + 1
 

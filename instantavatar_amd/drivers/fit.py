@@ -59,7 +59,7 @@ def fit_sequence(model, frames, steps, lr=1e-3, smpl_lr=1e-4, max_epochs=300, lo
     sched = configure_scheduler(opt, max_epochs)
     loss_fn = NGPLoss(loss_opt or dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
     model.train()
-    # graphed (one rank): every frame's step is captured once -- a frame has its own occupancy grid, so one HIP graph per frame --
+    # graphed (one rank): the step is captured once (once per frame with `smpl_init`, where every frame has its own occupancy grid)
     # and replayed afterwards; occupancy-update steps and a capture that fails run eagerly (training.GraphedTrainStep)
     stepper = GraphedTrainStep(model, opt, loss_fn, world_size=world_size, enabled=graphed)
     n = len(frames)

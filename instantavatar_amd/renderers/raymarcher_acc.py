@@ -53,7 +53,11 @@ class _RaySamplesFn(torch.autograd.Function):
     def forward(ctx, o, d, st):
         ctx.st = st
         ctx.shapes = (o.shape, d.shape)
-        return st["s_pts"]          # (written by the march kernel from the same o, d)
+        # (written by the march kernel from the same o, d.  A NEW tensor object on the same memory: autograd attaches the node to the
+        # object a Function returns -- returning the dict's own entry would make `st["s_pts"]` a non-leaf whose grad_fn owns `st`: a
+        # reference cycle that keeps the step's whole graph, and the AccumulateGrad nodes of the SMPL tables, alive into the next
+        # step -- and a HIP-graph capture on another stream then dies in capture_end)
+        return st["s_pts"].detach()
 
     @staticmethod
     def backward(ctx, d_pts):

@@ -656,9 +656,10 @@ class GraphedTrainStep:
             inner = getattr(model.deformer, "deformer", None)      # SNARFDeformer's ForwardDeformer (version 2 + SMPL tables: dense route)
             from .deformers.smpl_deformer import SMPLDeformer
             if isinstance(model.deformer, SMPLDeformer):
+                from .deformers import smpl_deformer as _sdm
                 # the fit stage (fit.py): capturable since round 6 (fused body model + compact render); one rank only -- every rank
                 # walks its own frames, so per-frame captures would happen at different steps on different ranks
-                self.enabled = self.enabled and fused is not None and not parallel.collectives_on(world_size)
+                self.enabled = self.enabled and fused is not None and _sdm.FUSED_LBS and not parallel.collectives_on(world_size)
             else:
                 self.enabled = self.enabled and fused is not None and inner is not None and getattr(inner, "version", 1) == 1
         from .optim import FusedAdam
@@ -768,7 +769,7 @@ class GraphedTrainStep:
         r._train_counts_check()                      # (pending event of a preceding eager step, if any)
         r._train_counts_peek(r.train_cand_capacity)
         use_noise = m.global_step < 1000 and not self.is_refine
-        # (a renderer with one occupancy grid PER FRAME -- Raymarcher.initialize(N_frames), raymarcher_acc.py:45-50: the fit stage -- bakes
+        # (a renderer with one occupancy grid PER FRAME -- Raymarcher(smpl_init=True).initialize(N_frames), raymarcher_acc.py:66-70 -- bakes
         # the frame's grid into the captured launches: one graph per frame then, at most `max_graphs` of them alive)
         grid_key = int(r.idx) if len(getattr(r, "density_grid_train_all", ())) > 1 else 0
         key = (bool(use_noise), r.train_cand_capacity, grid_key)

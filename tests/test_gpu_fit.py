@@ -130,9 +130,9 @@ def test_fit_fused_route_equals_dense_route(blend):
 
 
 def test_fit_steps_replay_from_per_frame_graphs():
-    """The fit step captured into HIP graphs (training.GraphedTrainStep, as drivers/fit.py runs it on one rank): the renderer holds
-    one occupancy grid PER FRAME (raymarcher_acc.py:45-50), so every frame gets its own graph; replayed steps follow the eager loss
-    curve, the SMPL tables keep moving, occupancy-update steps stay eager."""
+    """The fit step captured into a HIP graph (training.GraphedTrainStep, as drivers/fit.py runs it on one rank; with
+    `Raymarcher(smpl_init=True)` -- one occupancy grid per frame, raymarcher_acc.py:66-70 -- one graph per frame): replayed steps
+    follow the eager loss curve, the SMPL tables keep moving, occupancy-update steps stay eager."""
     from instantavatar_amd.training import GraphedTrainStep
     curves, tabs, info = [], [], None
     for graphed in (False, True):
@@ -152,7 +152,7 @@ def test_fit_steps_replay_from_per_frame_graphs():
             assert float(out["skipped_non_finite"]) == 0.0
         if graphed:
             assert stepper.capture_error is None, stepper.capture_error
-            assert len(stepper.graphs) == 3 and stepper.replays >= 20, (len(stepper.graphs), stepper.replays, stepper.eager_steps)
+            assert len(stepper.graphs) == 1 and stepper.replays >= 20, (len(stepper.graphs), stepper.replays, stepper.eager_steps)
             info = (stepper.replays, stepper.eager_steps)
         curves.append(ls)
         tabs.append({k: getattr(model.SMPL_param, k).weight.detach().cpu().numpy().copy() for k in ("betas", "body_pose", "transl")})
