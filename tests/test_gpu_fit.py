@@ -158,8 +158,8 @@ def test_fit_steps_replay_from_per_frame_graphs():
         tabs.append({k: getattr(model.SMPL_param, k).weight.detach().cpu().numpy().copy() for k in ("betas", "body_pose", "transl")})
     e, gr = np.array(curves[0]), np.array(curves[1])
     print("fit eager", e[::5], "graphed", gr[::5], "replays / eager steps", info)
-    assert np.isfinite(gr).all() and np.mean(gr[-6:]) < np.mean(gr[:6])
-    assert np.allclose(np.convolve(e, np.ones(6) / 6, "valid"), np.convolve(gr, np.ones(6) / 6, "valid"), rtol=0.25)
+    # same seeds, same draws: the replayed steps reproduce the eager ones (measured: 6 digits; what differs is the order of the atomics)
+    assert np.isfinite(gr).all() and np.allclose(e, gr, rtol=2e-2, atol=1e-6), (e, gr)
     for k in tabs[1]:      # the replayed steps really optimise the SMPL tables (betas included: the fit stage hands them to the deformer)
         assert np.abs(tabs[1][k] - frames.smpl_params[k].cpu().numpy()).max() > 0, k
 
