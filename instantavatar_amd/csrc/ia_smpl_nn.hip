@@ -276,6 +276,25 @@ __global__ __launch_bounds__(IA_NN_THREADS) void k_smpl_nn_grid(
   }
 }
 
+// Zero-fill as a kernel of this library, not hipMemsetAsync: recorded into a HIP graph a memset becomes a memset NODE, and a graph
+// with memset nodes replayed back-to-back without host synchronisation faulted on ROCm 7.2 (fit stage, round 6: "Memory access fault
+// by GPU" at a non-deterministic replay, never with a synchronisation between replays, never in eager mode; NOTES.md).  Every other
+// zero-fill of the library already was a kernel.
+__global__ void k_zero_words(uint32_t *__restrict__ p, size_t n_words) {
+  size_t n4 = n_words / 4;
+  uint4 *p4 = reinterpret_cast<uint4 *>(p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[n4 * 4 + threadIdx.x] = 0;
+}
+
+// bytes: multiple of 4; p: 16-byte aligned (torch allocations, workspace slices)
+static void zero_fill(void *p, size_t bytes, hipStream_t s) {
+  size_t n_words = bytes / 4;
+  if (n_words == 0) return;
+  int blocks = (int)std::min<size_t>((n_words / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(k_zero_words, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, n_words);
+}
+
 static int launch_nn_grid(const float *pts, int P, const int32_t *n_pts_dev, const void *grid, int NV, const float *T_inv, float threshold,
                           int32_t *idx, float *cand_xc, int32_t *pt_off, uint8_t *pt_cnt, int32_t *n_cand, int32_t *cand_pt, hipStream_t s) {
   NnGrid g = nn_grid_carve(const_cast<void *>(grid), NV);
@@ -338,7 +357,7 @@ extern "C" int ia_smpl_deform_query(const float *pts, int P, const int32_t *n_pt
   float *cand_xc = w.take<float>((size_t)P * 3);
   float *cand_rgb = w.take<float>((size_t)P * 3);
   float *cand_sigma = w.take<float>(P);
-  (void)hipMemsetAsync(n_cand, 0, 4, s);
+  zero_fill(n_cand, 4, s);
   // nn_grid (ia_smpl_nn_grid_build on THESE vertices with a cell >= threshold): the nearest vertex is looked for in the 27 cells
   // around the point only -- the same result for every point that has a vertex within `threshold`, nothing for the others
   if (nn_grid) rc = launch_nn_grid(pts, P, n_pts_dev, nn_grid, n_verts, T_inv, threshold, nullptr, cand_xc, pt_off, pt_cnt, n_cand, nullptr, s);
@@ -368,7 +387,7 @@ extern "C" int ia_smpl_nn_compact(const float *pts, int P, const int32_t *n_pts_
   IA_CHECK_ARG(P >= 0, "ia_smpl_nn_compact: P < 0");
   IA_CHECK_ARG(n_cand, "ia_smpl_nn_compact: null counter");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(n_cand, 0, 4, s);
+  zero_fill(n_cand, 4, s);
   if (P == 0) return IA_OK;
   IA_CHECK_ARG(pts && verts && T_inv && cand_xc && cand_pt && idx && pt_off && pt_cnt, "ia_smpl_nn_compact: null pointer");
   IA_CHECK_ARG(n_verts > 0 && (size_t)n_verts * 12 <= 160 * 1024 - 4096, "ia_smpl_nn_compact: %d vertices do not fit LDS", n_verts);
@@ -406,8 +425,8 @@ extern "C" int ia_smpl_nn_compact_bwd(const float *pts, int P, const int32_t *ca
                                       void *stream) {
   IA_CHECK_ARG(P >= 0 && cap >= 0 && n_verts > 0, "ia_smpl_nn_compact_bwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  if (d_T_inv) (void)hipMemsetAsync(d_T_inv, 0, (size_t)n_verts * 64, s);
-  if (d_pts && P > 0) (void)hipMemsetAsync(d_pts, 0, (size_t)P * 12, s);
+  if (d_T_inv) zero_fill(d_T_inv, (size_t)n_verts * 64, s);
+  if (d_pts && P > 0) zero_fill(d_pts, (size_t)P * 12, s);
   if (cap == 0 || P == 0) return IA_OK;
   IA_CHECK_ARG(pts && cand_pt && idx && n_cand && T_inv && d_cand_xc, "ia_smpl_nn_compact_bwd: null pointer");
   hipLaunchKernelGGL(k_smpl_nn_bwd, dim3(ia_div_up(cap, 256)), dim3(256), 0, s, pts, cand_pt, idx, n_cand, cap, T_inv, d_cand_xc, d_T_inv, d_pts);
