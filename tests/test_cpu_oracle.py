@@ -619,6 +619,20 @@ def test_density_grid_update_oracle_semantics(oracle, small_world):
     assert outs[0]["density_field"].any() and (outs[0]["density"] >= 0).all() and (outs[0]["density"] < 1).all()
 
 
+def test_no_memset_nodes_on_capturable_paths():
+    """Every stream-ordered zero-fill of the library is a kernel: hipMemsetAsync recorded into a HIP graph becomes a memset node, and
+    a graph with memset nodes replayed back-to-back faulted on ROCm 7.2 (fit stage, round 6; NOTES.md).  Only the profiling hooks
+    (ia_prof.hip: synchronous hipMemset, never captured) may call the runtime's memset."""
+    import glob, os, re
+    from instantavatar_amd import build
+    src_dir = os.path.dirname(build.__file__) + "/csrc"
+    for path in sorted(glob.glob(src_dir + "/*.hip") + glob.glob(src_dir + "/*.h") + glob.glob(src_dir + "/*.cpp")):
+        text = re.sub(r"//[^\n]*", "", open(path).read())
+        assert "hipMemsetAsync" not in text and "hipMemset2D" not in text, path
+        if not path.endswith("ia_prof.hip"):
+            assert "hipMemset(" not in text, path
+
+
 def test_voxeliser_has_no_cpu_route():
     from instantavatar_amd import _lib
     from instantavatar_amd.deformers.fast_snarf.forward_deformer import voxelise_skinning_weights

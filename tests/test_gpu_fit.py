@@ -164,6 +164,41 @@ def test_fit_steps_replay_from_per_frame_graphs():
         assert np.abs(tabs[1][k] - frames.smpl_params[k].cpu().numpy()).max() > 0, k
 
 
+def test_fit_graph_replays_back_to_back_without_host_sync():
+    """Regression (round 6): 230 fit steps at the bench configuration (4 frames 256^2, 4 x 32^2 patches), replayed from the captured
+    graph with NO host read between the replays.  With hipMemsetAsync inside the captured step (memset nodes) this aborted the process
+    with "Memory access fault by GPU" somewhere past replay ~30-200; with the zero-fills as kernels it runs (NOTES.md).  A fault cannot
+    be caught in-process: the steps run in a child process and the test reads its exit code."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch
+from instantavatar_amd.drivers import fit as fit_driver
+from instantavatar_amd.training import GraphedTrainStep, NGPLoss, configure_optimizer
+dev = torch.device("cuda:0")
+frames, body_model, true = fit_driver.synthetic_frames(dev, res=256, n_frames=4, noise=0.03, patch=32)
+model = fit_driver.build_fit_model(frames, body_model, dev)
+opt = configure_optimizer(model, lr=1e-3, smpl_lr=1e-4)
+loss_fn = NGPLoss(dict(w_rgb=1.0, w_alpha=0.1, w_reg=0.1, w_lpips=0.0, w_depth_reg=0.01))
+model.train()
+st = GraphedTrainStep(model, opt, loss_fn)
+first = None
+for it in range(230):
+    out = st(frames.batch(it %% 4, out=st.inputs))
+    if it == 1: first = float(out["mse_loss"])
+torch.cuda.synchronize()
+print("RESULT", st.replays, st.eager_steps, len(st.graphs), st.capture_error, first, float(out["mse_loss"]))
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    replays, eager, graphs, err, first, last = int(line[1]), int(line[2]), int(line[3]), line[4], float(line[5]), float(line[6])
+    print("unsynchronised fit replays", replays, "eager", eager, "mse", first, "->", last)
+    assert err == "None" and graphs == 1 and replays >= 210 and eager <= 20, line
+    assert np.isfinite(last) and last < 0.6 * first, (first, last)
+
+
 def test_ngp_loss_with_lpips_term_trains_on_the_device():
     """The refine configuration's loss (confs/SNARF_NGP_refine.yaml: NGPLoss with w_lpips) on the device: the LPIPS term is
     present for patch batches, differentiable through the renderer, and its module equals its CPU evaluation.  (Random trunk
