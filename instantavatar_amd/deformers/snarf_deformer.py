@@ -135,6 +135,18 @@ class _SmplTfsFn(torch.autograd.Function):
         return d_pose[:3].reshape(s_go), d_pose[3:].reshape(s_bp), d_tr.reshape(s_tr), None
 
 
+def _pose72(go, bp):
+    """[1,72] axis-angle vector (global orientation, then the 23 body joints) for `ia_smpl_tfs`.  When the two inputs already
+    are the adjacent parts of ONE 72-float record (a row of a pose table, pipeline.GraphedRenderer's static inputs) the
+    record is used in place; otherwise they are concatenated (one launch)."""
+    g, b = go.reshape(-1), bp.reshape(-1)
+    if (g.dtype == torch.float32 and b.dtype == torch.float32 and g.numel() == 3 and b.numel() == 69 and g.is_contiguous()
+            and b.is_contiguous() and b.data_ptr() == g.data_ptr() + 12
+            and g.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()):
+        return torch.as_strided(g, (1, 72), (72, 1))
+    return torch.cat([go.reshape(1, 3), bp.reshape(1, 69)], dim=1).float().contiguous()
+
+
 class SNARFDeformer():
     #: capacity (candidates) of one training-mode field call (`query_train_fused`, the probe of DensityGrid.update).
     #: None = points x init bones: every candidate fits by construction, nothing can be dropped (262 144 probe points x 13
@@ -227,7 +239,7 @@ class SNARFDeformer():
             A = out.A
         else:
             fo = self._frame_out
-            pose = torch.cat([go.reshape(1, 3), bp.reshape(1, 69)], dim=1).float().contiguous()
+            pose = _pose72(go, bp)
             trc = tr.reshape(3).float().contiguous()
             _lib.check(_lib.lib().ia_smpl_tfs(_lib.ptr(self._joints_rest), _lib.ptr(self._parents32), _lib.ptr(pose),
                                               _lib.ptr(trc), _lib.ptr(self.tfs_inv_t), _lib.ptr(fo["tfs"]),

@@ -155,7 +155,7 @@ def _make_renderer(model, first, size, in_flight, probes, jitter):
     return PipelinedRenderer(model, first, size, n_in_flight=in_flight, margin=1, probe_batches=probes, jitter=jitter)
 
 
-def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_flight=2, jitter=None, make_renderer=None, log=print,
+def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_flight=3, jitter=None, make_renderer=None, log=print,
                     max_buffer_bytes=1 << 30):
     """animate.py:104-118 / novel_view.py:117-127 for one rank of a job of `launch.world_size` ranks.
 
@@ -241,7 +241,7 @@ def render_sequence(model, seq, out_dir, gif="animation.gif", launch=None, in_fl
 
 
 def add_launch_args(ap):
-    ap.add_argument("--in-flight", type=int, default=2, help="frames in flight per GPU (captured HIP graphs replayed round-robin on their own streams)")
+    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (captured HIP graphs replayed round-robin on their own streams)")
     ap.add_argument("--jitter-seed", type=int, default=None,
                     help="use ONE occupancy-probe jitter for all frames (drawn from this seed) instead of a fresh draw per frame "
                          "(density_grid.py:98): the files no longer depend on how many ranks rendered the sequence")

@@ -88,10 +88,10 @@ class DensityGrid(torch.nn.Module):
         G = self.grid_size
         L = _lib.lib()
         ws = self._workspace(L.ia_occupancy_workspace_bytes(G))
-        out8 = torch.empty((G, G, G), dtype=torch.uint8, device=density.device)
+        out8 = torch.empty((G, G, G), dtype=torch.bool, device=density.device)   # written as bytes 0 / 1 by the kernel
         _lib.check(L.ia_occupancy_from_density(_lib.ptr(density.contiguous()), G, _lib.ptr(self.occ_bits), _lib.ptr(out8),
                                                _lib.ptr(ws), ws.numel(), _lib.stream()), "ia_occupancy_from_density")
-        self.density_field = out8.bool()
+        self.density_field = out8
 
     # -- test-time grid (per frame) ----------------------------------------------
     batched_probes = True
@@ -103,7 +103,15 @@ class DensityGrid(torch.nn.Module):
         (torch.rand_like, density_grid.py:100)."""
         G = self.grid_size
         bb = deformer.get_bbox_deformed()
-        self.aabb = torch.stack([bb[0], bb[1]])
+        if (bb[0].is_contiguous() and bb[1].is_contiguous() and bb[0].numel() == 3 and bb[1].dtype == bb[0].dtype
+                and bb[1].data_ptr() == bb[0].data_ptr() + 3 * bb[0].element_size()
+                and bb[0].untyped_storage().data_ptr() == bb[1].untyped_storage().data_ptr()):
+            # the two corners are the halves of ONE 6-float record (the voxel pass of the frame writes it: ia_precompute): `aabb` is a
+            # [2,3] VIEW of that record -- no stack launch per frame.  It follows the deformer's prepared frame, as this grid does
+            # (it is rebuilt by every render_image_fast); clone it to keep the box of an earlier frame.
+            self.aabb = torch.as_strided(bb[0], (2, 3), (3, 1))
+        else:
+            self.aabb = torch.stack([bb[0], bb[1]])
         dev = self.density_cached.device
         if jitter is None:
             jitter = torch.rand((iters, G * G * G, 3), device=dev)
@@ -123,7 +131,7 @@ class DensityGrid(torch.nn.Module):
             else:
                 ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
             density = torch.empty((G, G, G), device=dev)
-            out8 = torch.empty((G, G, G), dtype=torch.uint8, device=dev)
+            out8 = torch.empty((G, G, G), dtype=torch.bool, device=dev)   # the kernel writes the bytes 0 / 1: a bool tensor's storage
             tfs = deformer.tfs.detach().float().contiguous()
             _lib.check(L.ia_density_grid_init(_lib.ptr(jitter), iters, G, _lib.ptr(self.aabb_tensor()),
                                               _lib.ptr(deformer.deformer.voxel_J_cl), _lib.ptr(tfs),
@@ -131,7 +139,7 @@ class DensityGrid(torch.nn.Module):
                                               C.byref(net.field_desc(G * G * G * k * iters)), _lib.ptr(density), _lib.ptr(self.occ_bits),
                                               _lib.ptr(out8), _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "ia_density_grid_init")
-            self.density_field = out8.bool()
+            self.density_field = out8
             self.density_probe = density
             return
         density = torch.zeros_like(self.coords[..., 0])

@@ -78,6 +78,12 @@ class GraphedRenderer:
         instead of a fresh draw -- frames then depend on their pose only, whichever rank / replica / replay renders them."""
         self.model, self.img_size, self.sync_check, self.jitter = model, img_size, sync_check, jitter
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        go, bp = self.static.get("global_orient"), self.static.get("body_pose")
+        if torch.is_tensor(go) and torch.is_tensor(bp) and go.numel() == 3 and bp.numel() == 69 and go.dtype == bp.dtype == torch.float32:
+            # the two pose inputs as the halves of ONE 72-float record: prepare_deformer hands the record to ia_smpl_tfs as it
+            # is (snarf_deformer._pose72) -- no concatenation launch in the captured frame
+            rec = torch.cat([go.reshape(-1), bp.reshape(-1)])
+            self.static["global_orient"], self.static["body_pose"] = rec[:3].view(go.shape), rec[3:].view(bp.shape)
         r = model.renderer
         need = 0
         for b in probe_batches:
@@ -157,13 +163,28 @@ class PipelinedRenderer:
     """`n_in_flight` frames in flight: one captured HIP graph per replica (GraphedRenderer), replayed round-robin on its own
     stream.  A frame is a chain of ~60 dependent launches of which only the Broyden search and the encoder fill the chip;
     the marcher, the compositor, the occupancy post-process and the small first / last wave-front iterations are latency
-    bound and leave most CUs idle -- a second, independent frame (animate.py renders independent frames: BASELINE config 3)
-    runs in those gaps.  Measured on MI355X: 395 -> 483 frames/s with two frames in flight; per-frame latency rises from
-    2.5 to ~4.1 ms.  Outputs of call i stay valid until call i + n_in_flight (same replica, same stream: no extra ordering needed)."""
+    bound and leave most CUs idle -- other, independent frames (animate.py renders independent frames: BASELINE config 3)
+    run in those gaps.  Outputs of call i stay valid until call i + n_in_flight (same replica, same stream: no extra ordering
+    needed).
 
-    def __init__(self, model, batch, img_size, n_in_flight=2, margin=1, probe_batches=(), jitter=None):
+    Stream priorities (round 6): with equal priorities the hardware queues share the dispatcher evenly and a third frame LOSES
+    (513 vs 553 frames/s with two); with the FIRST replica's stream at high priority and the others at normal priority three
+    frames in flight WIN (580 sustained / 598 over the 20-frame driver window at 512^2: `profiles/r06_ab_in_flight_priorities.txt`):
+    the high-priority frame's chain of small launches is dispatched the moment it is ready instead of queueing behind the
+    thousands of pending search workgroups of the other frames, which fill what it leaves free.  Two in flight gain nothing from
+    it (545 vs 553), four and five lose to three.  Default: (high, normal, normal, ...) from three frames in flight on, equal
+    below; `priorities` (a list, HIP convention: lower = higher priority, range `torch.cuda.Stream.priority_range()`) or the
+    environment variable IA_STREAM_PRIORITIES ("-1,0,0") override.  Measured on MI355X: one frame in flight 450 frames/s
+    (2.2 ms latency), two 553, three 580."""
+
+    def __init__(self, model, batch, img_size, n_in_flight=3, margin=1, probe_batches=(), jitter=None, priorities=None):
+        import os
         self.replicas = [model] + [clone_for_stream(model) for _ in range(n_in_flight - 1)]
-        self.streams = [torch.cuda.Stream(device=batch["rays_o"].device) for _ in self.replicas]
+        env = [int(v) for v in os.environ.get("IA_STREAM_PRIORITIES", "").split(",") if v.strip()]
+        if priorities is None:
+            priorities = env or ([-1] + [0] * (n_in_flight - 1) if n_in_flight >= 3 else [0] * n_in_flight)
+        self.priorities = [int(priorities[k % len(priorities)]) for k in range(n_in_flight)]
+        self.streams = [torch.cuda.Stream(device=batch["rays_o"].device, priority=p) for p in self.priorities]
         self.graphs = []
         for m, s in zip(self.replicas, self.streams):
             s.wait_stream(torch.cuda.current_stream())

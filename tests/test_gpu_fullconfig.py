@@ -89,11 +89,11 @@ def _eager_graph_pipelined(oracle, bench_world, frames, seed0, what):
         assert g.finish() == 0
     finally:
         grid.initialize = orig
-    # two frames in flight: replica 0 renders the even calls, replica 1 the odd ones; each replica reads its own static
-    # jitter buffer, refreshed before the call that uses it
+    # frames in flight, as the product runs them (PipelinedRenderer's defaults: three replicas, the first one's stream at high
+    # priority) and with two replicas: replica k renders the calls k, k + n_rep, ...; each replica reads its own static jitter
+    # buffer, refreshed before the call that uses it
     import instantavatar_amd.pipeline as P
     from instantavatar_amd.pipeline import PipelinedRenderer
-    jit_rep = [torch.as_tensor(jits[0], device=DEV).clone(), torch.as_tensor(jits[min(1, n - 1)], device=DEV).clone()]
     patched, real_clone = [], P.clone_for_stream
 
     def patch(m, jd):
@@ -102,28 +102,38 @@ def _eager_graph_pipelined(oracle, bench_world, frames, seed0, what):
         gr.initialize = lambda deformer, net, iters=5, jitter=None, _o=o: _o(deformer, net, iters=iters, jitter=jd)
         patched.append((gr, o))
 
-    def patched_clone(m):
-        c = real_clone(m)
-        patch(c, jit_rep[1])
-        return c
-    patch(model, jit_rep[0])
-    P.clone_for_stream = patched_clone
     try:
-        pr = PipelinedRenderer(model, batch(0), (res, res), n_in_flight=2)
-        order = list(range(n)) + list(range(n))      # every frame passes through both replicas when n is odd
-        got = []
-        jits_dev = [torch.as_tensor(j, device=DEV) for j in jits]
-        torch.cuda.synchronize()
-        for call, i in enumerate(order):
-            k = call % 2
-            with torch.cuda.stream(pr.streams[k]):    # behind the replica's previous frame, ahead of its next replay; the
-                jit_rep[k].copy_(jits_dev[i])          # other replica's stream is not made to wait: two frames stay in flight
-            pr(batch(i), consume=lambda out, kk: got.append(([t.clone() for t in out], pr.replicas[kk].renderer.density_grid_test.density_field.clone())))
-        pr.synchronize()
-        assert pr.finish() == 0
-        for call, i in enumerate(order):
-            out, occ = got[call]
-            _check(out[0], out[2], out[3], occ, refs[i], "%s 512^2 two in flight, call %d frame %d" % (what, call, i))
+        for n_rep in (3, 2):
+            jit_rep = [torch.as_tensor(jits[min(k, n - 1)], device=DEV).clone() for k in range(n_rep)]
+            made = [0]
+
+            def patched_clone(m):
+                made[0] += 1
+                c = real_clone(m)
+                patch(c, jit_rep[made[0]])
+                return c
+            patch(model, jit_rep[0])
+            P.clone_for_stream = patched_clone
+            pr = PipelinedRenderer(model, batch(0), (res, res), n_in_flight=n_rep) if n_rep != 3 else PipelinedRenderer(model, batch(0), (res, res))
+            assert len(pr.replicas) == n_rep and pr.priorities == ([-1, 0, 0] if n_rep == 3 else [0, 0]), pr.priorities
+            order = list(range(n)) * n_rep               # every frame passes through several replicas
+            got = []
+            jits_dev = [torch.as_tensor(j, device=DEV) for j in jits]
+            torch.cuda.synchronize()
+            for call, i in enumerate(order):
+                k = call % n_rep
+                with torch.cuda.stream(pr.streams[k]):    # behind the replica's previous frame, ahead of its next replay; the
+                    jit_rep[k].copy_(jits_dev[i])          # other replicas' streams are not made to wait: the frames stay in flight
+                pr(batch(i), consume=lambda out, kk: got.append(([t.clone() for t in out], pr.replicas[kk].renderer.density_grid_test.density_field.clone())))
+            pr.synchronize()
+            assert pr.finish() == 0
+            for call, i in enumerate(order):
+                out, occ = got[call]
+                _check(out[0], out[2], out[3], occ, refs[i], "%s 512^2 %d in flight, call %d frame %d" % (what, n_rep, call, i))
+            P.clone_for_stream = real_clone
+            for gr, o in patched:
+                gr.initialize = o
+            del patched[:]
     finally:
         P.clone_for_stream = real_clone
         for gr, o in patched:

@@ -482,8 +482,9 @@ def test_hip_graph_replay_equals_eager(gpu_world):
         grid.initialize = orig
 
 
-def test_pipelined_renderer_two_frames_in_flight_equal_eager(gpu_world):
-    """PipelinedRenderer: two replicas (shared weights, own workspaces), one captured graph and one stream each.  Every
+@pytest.mark.parametrize("n_in_flight", [2, 3])
+def test_pipelined_renderer_frames_in_flight_equal_eager(gpu_world, n_in_flight):
+    """PipelinedRenderer: two / three replicas (shared weights, own workspaces), one captured graph and one stream each.  Every
     frame must equal the eager render bit for bit whichever replica rendered it, and both replicas must see a weight
     update (the network parameters are shared by reference, not copied)."""
     from instantavatar_amd.pipeline import PipelinedRenderer, clone_for_stream
@@ -512,9 +513,10 @@ def test_pipelined_renderer_two_frames_in_flight_equal_eager(gpu_world):
             return c
         P.clone_for_stream = patched_clone
         try:
-            pr = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=2)
+            pr = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=n_in_flight)
         finally:
             P.clone_for_stream = real_clone
+        assert pr.priorities == ([0, 0] if n_in_flight == 2 else [-1, 0, 0])   # (the first replica's stream at high priority from three on)
         outs = []
         for i in (1, 4, 6, 2):
             o, k = pr(make_batch(DEV, res, poses[i], tr[i]), consume=lambda out, k: outs.append([t.clone() for t in out]))
