@@ -160,12 +160,12 @@ def clone_for_stream(model):
 
 
 class PipelinedRenderer:
-    """`n_in_flight` frames in flight: one captured HIP graph per replica (GraphedRenderer), replayed round-robin on its own
-    stream.  A frame is a chain of ~60 dependent launches of which only the Broyden search and the encoder fill the chip;
+    """`n_in_flight` frames in flight: one captured HIP graph per replica (GraphedRenderer), replayed on its own
+    stream (round robin, or the least loaded replica: `schedule`).  A frame is a chain of ~60 dependent launches of which only the Broyden search and the encoder fill the chip;
     the marcher, the compositor, the occupancy post-process and the small first / last wave-front iterations are latency
     bound and leave most CUs idle -- other, independent frames (animate.py renders independent frames: BASELINE config 3)
-    run in those gaps.  Outputs of call i stay valid until call i + n_in_flight (same replica, same stream: no extra ordering
-    needed).
+    run in those gaps.  Outputs of a call stay valid until the replica that rendered it is called again (with the round-robin
+    schedule: call i + n_in_flight); consumers belong into `consume`, which runs on the replica's stream right behind the frame.
 
     Stream priorities (round 6): with equal priorities the hardware queues share the dispatcher evenly and a third frame LOSES
     (513 vs 553 frames/s with two); with the FIRST replica's stream at high priority and the others at normal priority three
@@ -177,7 +177,11 @@ class PipelinedRenderer:
     environment variable IA_STREAM_PRIORITIES ("-1,0,0") override.  Measured on MI355X: one frame in flight 450 frames/s
     (2.2 ms latency), two 553, three 580."""
 
-    def __init__(self, model, batch, img_size, n_in_flight=3, margin=1, probe_batches=(), jitter=None, priorities=None):
+    def __init__(self, model, batch, img_size, n_in_flight=3, margin=1, probe_batches=(), jitter=None, priorities=None, schedule=None,
+                 max_queued=2):
+        """schedule: "round_robin" (call i -> replica i mod n) or "least_loaded" (the replica with the fewest unfinished frames,
+        the higher-priority one on a tie, at most `max_queued` frames queued per replica -- the host waits for the oldest one
+        beyond that).  Default: IA_PIPELINE_SCHEDULE, else round robin."""
         import os
         self.replicas = [model] + [clone_for_stream(model) for _ in range(n_in_flight - 1)]
         env = [int(v) for v in os.environ.get("IA_STREAM_PRIORITIES", "").split(",") if v.strip()]
@@ -193,6 +197,24 @@ class PipelinedRenderer:
             torch.cuda.current_stream().wait_stream(s)
         self.events = [torch.cuda.Event() for _ in self.replicas]
         self.calls = 0
+        self.schedule = schedule or os.environ.get("IA_PIPELINE_SCHEDULE", "") or "round_robin"
+        assert self.schedule in ("round_robin", "least_loaded"), self.schedule
+        self.max_queued = int(os.environ.get("IA_PIPELINE_MAX_QUEUED", max_queued))
+        self._unfinished = [[] for _ in self.replicas]     # per replica: events of the frames enqueued and not yet seen finished
+        self._call_ids = [[] for _ in self.replicas]       # per replica: the global call number of its local calls
+        self.frames_per_replica = [0 for _ in self.replicas]
+
+    def _pick(self):
+        n = len(self.graphs)
+        if self.schedule == "round_robin":
+            return self.calls % n
+        for q in self._unfinished:
+            while q and q[0].query():
+                q.pop(0)
+        k = min(range(n), key=lambda j: (len(self._unfinished[j]), self.priorities[j], (j - self.calls) % n))
+        if len(self._unfinished[k]) >= self.max_queued:     # every replica has its queue full: wait for the oldest frame of this one
+            self._unfinished[k].pop(0).synchronize()
+        return k
 
     def __call__(self, batch, consume=None):
         """Launch one frame on the next replica's stream and return (outputs, replica index) without making any other
@@ -201,7 +223,9 @@ class PipelinedRenderer:
         waits on `self.events[k]` (recorded behind `consume`) or calls `synchronize()`.  The replica's stream first waits
         for what the CALLER's stream has enqueued so far (the producers of `batch`; keep frame consumers off that stream,
         or the frames serialise behind them)."""
-        k = self.calls % len(self.graphs)
+        k = self._pick()
+        self._call_ids[k].append(self.calls)
+        self.frames_per_replica[k] += 1
         self.streams[k].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.streams[k]):
             out = self.graphs[k](batch)
@@ -210,6 +234,9 @@ class PipelinedRenderer:
                     batch[key].record_stream(self.streams[k])
             if consume is not None:
                 consume(out, k)
+            if self.schedule == "least_loaded":
+                self.events[k] = torch.cuda.Event()
+                self._unfinished[k].append(self.events[k])
             self.events[k].record()
         self.calls += 1
         return out, k
@@ -228,8 +255,7 @@ class PipelinedRenderer:
 
     @property
     def incomplete_calls(self):
-        n = len(self.graphs)
-        return sorted(c * n + k for k, g in enumerate(self.graphs) for c in g.incomplete_calls)
+        return sorted(self._call_ids[k][c] for k, g in enumerate(self.graphs) for c in g.incomplete_calls)
 
     def finish(self):
         return sum(g.finish() for g in self.graphs)

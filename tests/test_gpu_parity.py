@@ -482,8 +482,8 @@ def test_hip_graph_replay_equals_eager(gpu_world):
         grid.initialize = orig
 
 
-@pytest.mark.parametrize("n_in_flight", [2, 3])
-def test_pipelined_renderer_frames_in_flight_equal_eager(gpu_world, n_in_flight):
+@pytest.mark.parametrize("n_in_flight,schedule", [(2, "round_robin"), (3, "round_robin"), (3, "least_loaded")])
+def test_pipelined_renderer_frames_in_flight_equal_eager(gpu_world, n_in_flight, schedule):
     """PipelinedRenderer: two / three replicas (shared weights, own workspaces), one captured graph and one stream each.  Every
     frame must equal the eager render bit for bit whichever replica rendered it, and both replicas must see a weight
     update (the network parameters are shared by reference, not copied)."""
@@ -513,7 +513,7 @@ def test_pipelined_renderer_frames_in_flight_equal_eager(gpu_world, n_in_flight)
             return c
         P.clone_for_stream = patched_clone
         try:
-            pr = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=n_in_flight)
+            pr = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=n_in_flight, schedule=schedule)
         finally:
             P.clone_for_stream = real_clone
         assert pr.priorities == ([0, 0] if n_in_flight == 2 else [-1, 0, 0])   # (the first replica's stream at high priority from three on)
@@ -530,10 +530,12 @@ def test_pipelined_renderer_frames_in_flight_equal_eager(gpu_world, n_in_flight)
         with torch.no_grad():
             model.net_coarse.color_net.params.mul_(0.5)
         pr.refresh_weights()
-        a, _ = pr(make_batch(DEV, res, poses[1], tr[1]))
-        b, _ = pr(make_batch(DEV, res, poses[1], tr[1]))
+        ab = []      # (cloned on the replica's stream: with the least-loaded schedule both calls may land on the same replica)
+        for _ in range(n_in_flight):
+            pr(make_batch(DEV, res, poses[1], tr[1]), consume=lambda out, k: ab.append(out[0].clone()))
         pr.synchronize()
-        assert torch.equal(a[0], b[0]) and not torch.equal(a[0], outs[0][0])
+        assert all(torch.equal(ab[0], x) for x in ab[1:]) and not torch.equal(ab[0], outs[0][0])
+        assert sum(pr.frames_per_replica) == pr.calls == 4 + n_in_flight and sorted(c for ids in pr._call_ids for c in ids) == list(range(pr.calls))
     finally:
         with torch.no_grad():
             model.net_coarse.color_net.params.mul_(2.0)
