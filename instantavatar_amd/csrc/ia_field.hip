@@ -294,8 +294,11 @@ __device__ __forceinline__ void encode_all(const FieldDev &F, const uint32_t *__
 // Hashed levels use the x-neighbour pairing: for even cx the two corners differ in
 // index bit 0 only -> one aligned 8-byte load; odd cx adds a predicated 4-byte load.
 // ---------------------------------------------------------------------------
+#ifndef IA_ENC_QUAD
+#define IA_ENC_QUAD 1  // hashed levels: one aligned 16-byte group of four entries per (y, z) pair (see hashed_quad_loads)
+#endif
 #ifndef IA_ENC_S
-#define IA_ENC_S 4  // samples per thread (gathers in flight per lane = 8 * S)
+#define IA_ENC_S (IA_ENC_QUAD ? 3 : 4)  // samples per thread (table gathers in flight per lane: 4-5 (group) or 4-8 (pair) per sample)
 #endif
 #define IA_ENC_THREADS 256
 #define IA_ENC_TILE (IA_ENC_S * IA_ENC_THREADS)
@@ -380,6 +383,67 @@ __device__ __forceinline__ uint32_t hashed_pair_reduce(const float w[3], const u
   return o.u;
 }
 
+// IA_ENC_QUAD (round 6): the aligned 16-byte GROUP of four table entries around corner x instead of its aligned pair.  With tcnn's
+// hash the x-neighbour of a corner is entry (x + 1) ^ h: inside the same aligned pair when x is even, inside the same aligned group
+// of four unless x mod 4 == 3.  One dwordx4 gather per (y, z) pair then serves both x-corners for 3 lanes in 4 (the pair version: 2
+// in 4), and the second, separate gather of the others touches a quarter instead of half of the wave's lanes: 4 x 64 + 4 x 16 = 320
+// line look-ups per wave and level instead of 4 x 64 + 4 x 32 = 384 -- the vector L1's look-up rate is what bounds this kernel.
+// Measured (tools/ab_encode_quad.sh, profiles/r06_ab_encode_quad.txt): 2^20 random points 342 -> 325 us, a frame's samples 204 -> 190 us,
+// features bit-identical; 578 -> 587-589 frames/s.  Three samples per thread (122 VGPRs, four waves per SIMD) instead of four with the
+// wider records (160 VGPRs otherwise); the pair version (IA_ENC_QUAD=0, IA_ENC_S=4) stays for A/B runs.
+__device__ __forceinline__ uint32_t quad_select(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t s) {
+  const uint32_t lo = (s & 1u) ? y : x, hi = (s & 1u) ? w : z;
+  return (s & 2u) ? hi : lo;
+}
+__device__ __forceinline__ void hashed_quad_loads(const uint32_t *__restrict__ tab, float scale, uint32_t mask, const float xn[3],
+                                                  float w[3], uint32_t qx[4], uint32_t qy[4], uint32_t qz[4], uint32_t qw[4],
+                                                  uint32_t ext[4], uint32_t &meta) {
+  uint32_t g[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float pos = __builtin_fmaf(xn[d], scale, 0.5f);
+    const float fl = floorf(pos);
+    g[d] = (uint32_t)(int)fl;
+    w[d] = pos - fl;
+  }
+  const bool far = (g[0] & 3u) == 3u;   // x + 1 carries out of the two low bits: its entry lies in another group
+  meta = far ? (1u << 16) : 0u;
+#pragma unroll
+  for (int pr = 0; pr < 4; pr++) {
+    const uint32_t cy = g[1] + (pr & 1), cz = g[2] + (pr >> 1);
+    const uint32_t hsh = (cy * 2654435761u) ^ (cz * 805459861u);
+    const uint32_t i0 = (g[0] ^ hsh) & mask, i1 = ((g[0] + 1) ^ hsh) & mask;
+    const uint4 v = *reinterpret_cast<const uint4 *>(tab + (i0 & ~3u));
+    qx[pr] = v.x; qy[pr] = v.y; qz[pr] = v.z; qw[pr] = v.w;
+    meta |= ((i0 & 3u) | ((i1 & 3u) << 2)) << (4 * pr);
+    ext[pr] = 0u;
+    if (far) ext[pr] = tab[i1];
+  }
+}
+__device__ __forceinline__ uint32_t hashed_quad_reduce(const float w[3], const uint32_t qx[4], const uint32_t qy[4], const uint32_t qz[4],
+                                                       const uint32_t qw[4], const uint32_t ext[4], uint32_t meta) {
+  _Float16 r0 = (_Float16)0.f, r1 = (_Float16)0.f;
+  const bool far = meta & (1u << 16);
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {   // the same eight weighted fp16 accumulations, in the same order, as hashed_pair_reduce
+    float wt = 1.f;
+    wt *= (idx & 1) ? w[0] : 1.f - w[0];
+    wt *= (idx & 2) ? w[1] : 1.f - w[1];
+    wt *= (idx & 4) ? w[2] : 1.f - w[2];
+    const int pr = idx >> 1;
+    const uint32_t sel = (meta >> (4 * pr)) & 15u;
+    const uint32_t c0 = quad_select(qx[pr], qy[pr], qz[pr], qw[pr], sel & 3u);
+    const uint32_t c1 = far ? ext[pr] : quad_select(qx[pr], qy[pr], qz[pr], qw[pr], sel >> 2);
+    union { uint32_t u; half2v h; } c;
+    c.u = (idx & 1) ? c1 : c0;
+    r0 = r0 + (_Float16)(wt * (float)c.h.x);
+    r1 = r1 + (_Float16)(wt * (float)c.h.y);
+  }
+  union { uint32_t u; half2v h; } o;
+  o.h.x = r0; o.h.y = r1;
+  return o.u;
+}
+
 template <int L>
 __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__restrict__ x, int V,
                                                                 const int32_t *__restrict__ n_dev, FieldDev F,
@@ -410,6 +474,18 @@ __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__re
       const uint32_t *tab = F.table + F.hash_base + (uint32_t)(lev_h - ND) * F.hash_size;
       const float scale = F.lv.scale[lev_h];
       float w[IA_ENC_S][3];
+      uint32_t *out = planes + (size_t)lev_h * stride;
+#if IA_ENC_QUAD
+      uint32_t qx[IA_ENC_S][4], qy[IA_ENC_S][4], qz[IA_ENC_S][4], qw[IA_ENC_S][4], ext[IA_ENC_S][4], meta[IA_ENC_S];
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) hashed_quad_loads(tab, scale, F.hash_size - 1, xn[k], w[k], qx[k], qy[k], qz[k], qw[k], ext[k], meta[k]);
+#pragma unroll
+      for (int k = 0; k < IA_ENC_S; k++) {
+        const int i = base + k * IA_ENC_THREADS;
+        const uint32_t f = hashed_quad_reduce(w[k], qx[k], qy[k], qz[k], qw[k], ext[k], meta[k]);
+        if (i < V) out[i] = f;
+      }
+#else
       uint32_t px[IA_ENC_S][4], py[IA_ENC_S][4], ext[IA_ENC_S][4], meta[IA_ENC_S];
       if (IA_ENC_POL_H_LO != IA_ENC_POL_H_HI && lev_h - ND < 4) {  // (wave-uniform)
 #pragma unroll
@@ -418,13 +494,13 @@ __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__re
 #pragma unroll
         for (int k = 0; k < IA_ENC_S; k++) hashed_pair_loads<IA_ENC_POL_H_HI>(tab, scale, F.hash_size - 1, xn[k], w[k], px[k], py[k], ext[k], meta[k]);
       }
-      uint32_t *out = planes + (size_t)lev_h * stride;
 #pragma unroll
       for (int k = 0; k < IA_ENC_S; k++) {
         const int i = base + k * IA_ENC_THREADS;
         const uint32_t f = hashed_pair_reduce(w[k], px[k], py[k], ext[k], meta[k]);
         if (i < V) out[i] = f;
       }
+#endif
     }
     if (lev_d >= 0) {
       const uint32_t *tab = F.table + F.lv.offset[lev_d];
