@@ -38,7 +38,7 @@ class DensityGrid(torch.nn.Module):
         G = grid_size
         self.register_buffer("density_cached", torch.zeros(G, G, G))
         self.register_buffer("density_field", torch.zeros(G, G, G, dtype=torch.bool))
-        self.register_buffer("occ_bits", torch.zeros(G * G * G // 32 + 1, dtype=torch.int32), persistent=False)
+        self.register_buffer("occ_bits", torch.zeros(G * G * G // 32 + 8, dtype=torch.int32), persistent=False)   # + flag word + occupied-cell bounds (ia_occupancy_*)
         self.aabb = aabb
         self.initialized = False
         self.smpl_init = smpl_init

@@ -251,6 +251,9 @@ def test_occupancy_components_adversarial_cases(oracle, gpu_world):
         assert np.array_equal(unpacked, got), what
         border = got.copy(); border[1:-1, 1:-1, 1:-1] = False
         assert int(words[G ** 3 // 32]) == (0 if border.any() else 1), what   # flag word: 1 = no border cell occupied
+        occ = np.argwhere(got)                                                # the six words behind it: bounds of the occupied cells
+        want = [v for c in range(3) for v in ((int(occ[:, c].min()), int(occ[:, c].max())) if len(occ) else (0x7fffffff, -1))]
+        assert words[G ** 3 // 32 + 1:G ** 3 // 32 + 7].view(np.int32).tolist() == want, (what, want)
         return int(got.sum())
 
     d = np.zeros((G, G, G), np.float32)
@@ -286,6 +289,18 @@ def test_occupancy_components_adversarial_cases(oracle, gpu_world):
     d[24:27, 24:27, 24:27] = 70
     g32._postprocess(torch.as_tensor(d, device=DEV))
     assert np.array_equal(g32.density_field.cpu().numpy(), oracle.occupancy_from_density(d, 32).astype(bool))
+    # flag + bounds of the occupied cells behind the bit grid on other grid sizes (32: the power-of-two route of k_occ_bounds, 24 and
+    # 40: the generic one -- a word of the bit grid spans several z-columns there)
+    for Gx in (32, 24, 40):
+        gx = DensityGrid(Gx).to(DEV)
+        d = np.zeros((Gx, Gx, Gx), np.float32)
+        d[3:9, 5:Gx - 4, 2:7] = rng.rand(6, Gx - 9, 5) * 100 + 20
+        gx._postprocess(torch.as_tensor(d, device=DEV))
+        got = gx.density_field.cpu().numpy()
+        assert np.array_equal(got, oracle.occupancy_from_density(d, Gx).astype(bool)) and got.any()
+        occ = np.argwhere(got)
+        tail = gx.occ_bits.cpu().numpy()[Gx ** 3 // 32:Gx ** 3 // 32 + 7].tolist()
+        assert tail == [1] + [v for c in range(3) for v in (int(occ[:, c].min()), int(occ[:, c].max()))], (Gx, tail)
 
 
 def test_raymarch_and_composite_kernels(oracle, gpu_world):
@@ -312,7 +327,7 @@ def test_raymarch_and_composite_kernels(oracle, gpu_world):
                                        aabb[0].ctypes.data_as(C.c_void_p), step.ctypes.data_as(C.c_void_p), Ns,
                                        pts.ctypes.data_as(C.c_void_p), dn.ctypes.data_as(C.c_void_p), zn.ctypes.data_as(C.c_void_p))
         t = lambda a: torch.as_tensor(a, device=DEV)
-        bits = torch.zeros(G ** 3 // 32 + 1, dtype=torch.int32, device=DEV)  # + border-flag word
+        bits = torch.zeros(G ** 3 // 32 + 8, dtype=torch.int32, device=DEV)  # + border flag + occupied-cell bounds (8 tail words)
         tocc = t(occ)
         _lib.check(_lib.lib().ia_occupancy_pack(_lib.ptr(tocc), G, _lib.ptr(bits), _lib.stream()))
         og = _lib.OccGrid(); og.G = G; og.aabb_min[:] = aabb[0].tolist(); og.aabb_max[:] = aabb[1].tolist()
@@ -480,6 +495,74 @@ def test_hip_graph_replay_equals_eager(gpu_world):
         assert g.finish() == 0
     finally:
         grid.initialize = orig
+
+
+def test_march_empty_space_skip_is_exact(gpu_world):
+    """k_march_compact skips the occupancy arithmetic of the steps that cannot be occupied when the grid's border flag says that
+    no border cell is occupied (the clamped cell of a point outside the grid is a border cell, raymarcher.cu:49-51): the part of a
+    ray outside the box of the interior cells advances by the same float adds only.  Exactness: the same frame rendered with the
+    flag as the occupancy post-process computed it (1) and with the flag word cleared (0 = every step tested, rounds 1-5) must be
+    identical bit for bit -- on real poses, and on an adversarial grid whose occupied cells fill the whole interior box (rays
+    graze its faces, edges and corners one cell inside the border layer)."""
+    model, body, fp, init, poses, tr = gpu_world
+    res = 160
+    grid = model.renderer.density_grid_test
+    G = grid.grid_size
+
+    FLAG = G ** 3 // 32      # tail of the bit grid: [flag, x_min, x_max, y_min, y_max, z_min, z_max, spare]
+
+    def both(b, what):
+        flag = int(grid.occ_bits[FLAG])
+        outs = []
+        for f in (flag, 0):
+            grid.occ_bits[FLAG] = f
+            with torch.no_grad():
+                d = model.forward(b, eval_mode=True)
+            outs.append({k: v.clone() for k, v in d.items() if torch.is_tensor(v)})
+        grid.occ_bits[FLAG] = flag
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (what, k, int((outs[0][k] != outs[1][k]).sum()))
+        return flag, outs[0]
+
+    flags = []
+    for i in (0, 3, 5, 7):
+        b = make_batch(DEV, res, poses[i], tr[i])
+        model.render_image_fast(b, (res, res))          # prepares the deformer and builds the pose's occupancy grid (+ flag)
+        flag, out = both(b, "pose %d" % i)
+        flags.append(flag)
+        occ = grid.density_field.nonzero()
+        if flag == 1:     # the bounds the post-process left behind the flag are those of the occupied cells
+            want = [v for c in range(3) for v in (int(occ[:, c].min()), int(occ[:, c].max()))]
+            assert grid.occ_bits[FLAG + 1:FLAG + 7].tolist() == want, (grid.occ_bits[FLAG:FLAG + 7].tolist(), want)
+        assert float(out["alpha_coarse"].max()) > 0.5
+    assert 1 in flags, flags     # (a body that touched its bounding box in every pose would leave the skip untested)
+    # adversarial grid: every interior cell occupied, the border layer empty
+    b = make_batch(DEV, res, poses[3], tr[3])
+    model.render_image_fast(b, (res, res))
+    keep = (grid.density_field.clone(), grid.occ_bits.clone())
+    try:
+        f = torch.zeros((G, G, G), dtype=torch.bool, device=DEV)
+        f[1:G - 1, 1:G - 1, 1:G - 1] = True
+        grid.density_field = f
+        grid.pack_bits()
+        assert grid.occ_bits[FLAG:FLAG + 7].tolist() == [1, 1, G - 2, 1, G - 2, 1, G - 2]
+        flag, out = both(b, "full interior box")
+        assert float(out["counter_coarse"].max()) > 10
+        f[0, G // 2, G // 2] = True                      # one occupied border cell: the flag must drop, nothing may be skipped
+        grid.density_field = f
+        grid.pack_bits()
+        assert grid.occ_bits[FLAG:FLAG + 3].tolist() == [0, 0, G - 2]
+        # a thin diagonal set of cells: rays cross the bounds box at every angle, most of them without a hit
+        f = torch.zeros((G, G, G), dtype=torch.bool, device=DEV)
+        ar = torch.arange(8, G - 8, device=DEV)
+        f[ar, ar, (ar * 3) % (G - 16) + 8] = True
+        grid.density_field = f
+        grid.pack_bits()
+        assert int(grid.occ_bits[FLAG]) == 1 and grid.occ_bits[FLAG + 1:FLAG + 5].tolist() == [8, G - 9, 8, G - 9]
+        both(b, "diagonal cells")
+    finally:
+        grid.density_field, _ = keep
+        grid.occ_bits.copy_(keep[1])
 
 
 @pytest.mark.parametrize("n_in_flight,schedule", [(2, "round_robin"), (3, "round_robin"), (3, "least_loaded")])
