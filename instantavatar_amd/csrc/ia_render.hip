@@ -800,12 +800,51 @@ __global__ __launch_bounds__(256) void k_composite_compact(
     float c0 = color[(size_t)n * 3], c1 = color[(size_t)n * 3 + 1], c2 = color[(size_t)n * 3 + 2];
     float dep = depth[n];
     int s = 0;
-    // `delta > 0` (raymarcher.cu:218) == slot filled; dt > 0 for filled slots
+    // `delta > 0` (raymarcher.cu:218) == slot filled; dt > 0 for filled slots.
+    // Four samples per trip (round 6): the chain sample -> candidate range -> candidate densities -> winner's colour is three
+    // dependent loads deep and the compositing is sequential in T only, so the loads of four samples are issued together (the
+    // candidate scan runs over the four ranges in lock-step) and the four compositing steps follow in order, each behind the
+    // reference's `T > 1e-4` test -- the same arithmetic in the same order as one sample per trip; a ray that terminates inside a
+    // group has loaded up to three samples for nothing.
     while (s < cnt && (double)T > 1e-4 && dt > 0) {
-      float sg, c[3];
-      cand_max(cand_rgb, cand_sigma, pt_off[off + s], pt_cnt[off + s], n_init, 0.f, true, sg, c);
-      composite_step(sg, dt, s_t[off + s], c, thresh, T, c0, c1, c2, dep);
-      s++;
+      const int m = min(4, cnt - s);
+      int po[4], pc[4], bi[4];
+      float tz[4], best[4], rgb[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = off + s + (j < m ? j : 0);
+        po[j] = pt_off[q]; pc[j] = j < m ? (int)pt_cnt[q] : 0; tz[j] = s_t[q];
+        best[j] = pc[j] < n_init ? 0.f : -INFINITY;   // cand_max(fill = 0, nan_to_num = true), see there
+        bi[j] = -1;
+      }
+      const int cmax = max(max(pc[0], pc[1]), max(pc[2], pc[3]));
+      for (int c = 0; c < cmax; c++) {
+        float sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv[j] = c < pc[j] ? cand_sigma[po[j] + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (c < pc[j]) {
+            float v = sv[j];
+            if (!isfinite(v)) v = 0.f;
+            if (v > best[j] || (bi[j] < 0 && pc[j] >= n_init && c == 0)) { best[j] = v; bi[j] = c; }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          float v = bi[j] >= 0 ? cand_rgb[(size_t)(po[j] + bi[j]) * 3 + k] : 0.f;
+          if (!isfinite(v)) v = 0.f;
+          rgb[j][k] = v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (j < m && (double)T > 1e-4) composite_step(best[j], dt, tz[j], rgb[j], thresh, T, c0, c1, c2, dep);
+      }
+      s += m;
     }
     color[(size_t)n * 3] = c0; color[(size_t)n * 3 + 1] = c1; color[(size_t)n * 3 + 2] = c2;
     depth[n] = dep;
