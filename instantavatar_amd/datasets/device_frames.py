@@ -47,6 +47,12 @@ class DeviceFrames:
         self.rays_o, self.rays_d = make_rays(K, c2w, H, W, images_u8.device)
         dev = images_u8.device
         self.smpl_params = {k: torch.as_tensor(np.asarray(v, np.float32), device=dev) for k, v in smpl_params.items()}
+        go, bp = self.smpl_params.get("global_orient"), self.smpl_params.get("body_pose")
+        if go is not None and bp is not None and go.dim() == 2 and bp.dim() == 2 and go.shape[1] == 3 and bp.shape[1] == 69 and go.shape[0] == bp.shape[0]:
+            # the two pose tables as column ranges of ONE [N, 72] table: a frame's (global_orient, body_pose) pair is one contiguous
+            # 72-float record then, which prepare_deformer hands to ia_smpl_tfs in place (snarf_deformer._pose72: no concatenation launch)
+            pose72 = torch.cat([go, bp], dim=1).contiguous()
+            self.smpl_params["global_orient"], self.smpl_params["body_pose"] = pose72[:, :3], pose72[:, 3:]
         self.sampler = sampler
         self.near, self.far = near, far
         self._idx_all = torch.arange(N, device=dev)   # `idx_dev` of a batch is a one-element view: no host -> device copy per step

@@ -17,7 +17,7 @@ class SMPLParamEmbedding(nn.Module):
     def __init__(self, **tables) -> None:
         super().__init__()
         for name, init in tables.items():  # betas [1,10], global_orient [N,3], transl [N,3], body_pose [N,69]
-            table = nn.Embedding.from_pretrained(torch.as_tensor(init).float(), freeze=False)
+            table = nn.Embedding.from_pretrained(torch.as_tensor(init).float().contiguous().clone(), freeze=False)   # (its own dense storage: callers hand over views of larger tables)
             self.add_module(name, table)
 
     def forward(self, idx):

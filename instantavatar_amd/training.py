@@ -754,6 +754,12 @@ class GraphedTrainStep:
             return training_step(m, batch, self.optimizer, self.loss_fn, self.world_size, self.is_refine)
         if self.inputs is None:
             self.inputs = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in batch.items()}
+            go, bp = self.inputs.get("global_orient"), self.inputs.get("body_pose")
+            if torch.is_tensor(go) and torch.is_tensor(bp) and go.is_cuda and go.numel() == 3 and bp.numel() == 69 and go.dtype == bp.dtype == torch.float32:
+                # the two static pose inputs as the halves of ONE 72-float record (see snarf_deformer._pose72: used in place by the
+                # joint-chain kernel, one concatenation launch less in the captured step)
+                rec = torch.cat([go.reshape(-1), bp.reshape(-1)])
+                self.inputs["global_orient"], self.inputs["body_pose"] = rec[:3].view(go.shape), rec[3:].view(bp.shape)
             self._sig = self._signature(batch)
         elif batch is not self.inputs:
             for k, v in batch.items():
