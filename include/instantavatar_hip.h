@@ -287,11 +287,14 @@ int ia_field_fwd_train(const float *x, int V, const int32_t *n_dev, const ia_fie
  * d_rgb [n_rays,3], d_alpha [n_rays], d_weight [n_weights] = d loss / d input.
  * weight: the dense weight_coarse tensor [n_rays x MAX_SAMPLES] (raymarcher_acc.py:181-186).
  * poison: optional device scalar; > 0 multiplies the loss and all gradients by NaN (the step of a training render that
- * dropped candidates is then skipped by the optimiser's non-finite check, the way GradScaler skips a step: DNeRF.py:151-154). */
+ * dropped candidates is then skipped by the optimiser's non-finite check, the way GradScaler skips a step: DNeRF.py:151-154).
+ * overflow_count / overflow_cap: optional device counter + capacity; *overflow_count > overflow_cap poisons the step the same
+ * way (the render's candidate count against the capacity of its buffers, decided inside this kernel), and out5 then has a SIXTH
+ * value: out5[5] = 1 if the step was poisoned by the counter, else 0.                                                          */
 int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha,
                  const float *tgt_alpha, const float *weight, int n_rays, long long n_weights,
-                 float w_rgb, float w_alpha, float w_reg, const float *poison, float *out5, float *d_rgb,
-                 float *d_alpha, float *d_weight, void *stream);
+                 float w_rgb, float w_alpha, float w_reg, const float *poison, const int32_t *overflow_count,
+                 int overflow_cap, float *out5, float *d_rgb, float *d_alpha, float *d_weight, void *stream);
 
 /* Fused backward of both tiny MLPs (tcnn FullyFusedMLP backward; reached in the reference
  * through autograd of ngp.py:78,81).  acts: the activation record of ia_field_fwd_train;

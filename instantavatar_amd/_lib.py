@@ -109,7 +109,7 @@ _SIGS = {
     "ia_snarf_inverse_skinning_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, C.c_long, _VP, _VP, C.c_int, C.POINTER(SnarfGrid), _VP, _VP,
                                                 _VP, _VP, C.c_size_t, _VP]),
     "ia_expand_candidate_points": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, C.c_int, _VP]),
-    "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP] * 6),
+    "ia_nerf_loss": (C.c_int, [_VP] * 5 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_float] + [_VP, _VP, C.c_int] + [_VP] * 5),
     "ia_field_grad_scale": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "ia_field_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ia_field_bwd": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, C.POINTER(Field)] + [_VP] * 7 + [C.c_size_t, _VP]),

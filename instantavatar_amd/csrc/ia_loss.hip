@@ -28,12 +28,18 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
                                                    const float *__restrict__ alpha, const float *__restrict__ tgt_alpha,
                                                    const float *__restrict__ weight, int N, long long M, float w_rgb,
                                                    float w_alpha, float w_reg, const float *__restrict__ poison,
+                                                   const int32_t *__restrict__ overflow_count, int overflow_cap,
                                                    float *__restrict__ out,
                                                    float *__restrict__ d_rgb, float *__restrict__ d_alpha,
                                                    float *__restrict__ d_weight) {
   // poison (optional device scalar): > 0 turns the loss and every gradient into NaN -- a training render that dropped
   // candidates must not update anything; its NaN gradients make the optimiser's non-finite check skip the step on every rank
-  const float pz = (poison != nullptr && *poison > 0.f) ? __int_as_float(0x7fc00000) : 1.0f;
+  // overflow_count / overflow_cap (optional): the same, decided here from the device-side candidate count of the render
+  // (*overflow_count > overflow_cap) -- the compare + cast launches a caller would need to make `poison` out of the counter;
+  // out[5] reports the decision (1 / 0)
+  const bool over = overflow_count != nullptr && *overflow_count > overflow_cap;
+  const float pz = ((poison != nullptr && *poison > 0.f) || over) ? __int_as_float(0x7fc00000) : 1.0f;
+  if (overflow_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0) out[5] = over ? 1.f : 0.f;
   __shared__ float s_part[4][4];
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
   const float inv3n = 1.0f / (3.0f * (float)N), invn = 1.0f / (float)N, invm = M > 0 ? 1.0f / (float)M : 0.f;
@@ -100,8 +106,8 @@ __global__ __launch_bounds__(256) void k_nerf_loss(const float *__restrict__ rgb
 
 extern "C" int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float *alpha, const float *tgt_alpha,
                             const float *weight, int n_rays, long long n_weights, float w_rgb, float w_alpha,
-                            float w_reg, const float *poison, float *out5, float *d_rgb, float *d_alpha, float *d_weight,
-                            void *stream) {
+                            float w_reg, const float *poison, const int32_t *overflow_count, int overflow_cap, float *out5,
+                            float *d_rgb, float *d_alpha, float *d_weight, void *stream) {
   IA_CHECK_ARG(n_rays > 0 && n_weights >= 0, "ia_nerf_loss: bad sizes");
   IA_CHECK_ARG(rgb && tgt_rgb && alpha && tgt_alpha && out5 && d_rgb && d_alpha && (n_weights == 0 || (weight && d_weight)),
                "ia_nerf_loss: null pointer");
@@ -110,7 +116,7 @@ extern "C" int ia_nerf_loss(const float *rgb, const float *tgt_rgb, const float 
   if (blocks > 128) blocks = 128;           // ... but few workgroups: each ends in five atomics on the same words
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_nerf_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rgb, tgt_rgb, alpha, tgt_alpha,
-                     weight, n_rays, n_weights, w_rgb, w_alpha, w_reg, poison, out5, d_rgb, d_alpha, d_weight);
+                     weight, n_rays, n_weights, w_rgb, w_alpha, w_reg, poison, overflow_count, overflow_cap, out5, d_rgb, d_alpha, d_weight);
   IA_LAUNCH_CHECK("k_nerf_loss");
   return IA_OK;
 }

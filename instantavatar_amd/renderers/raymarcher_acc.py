@@ -323,6 +323,7 @@ class Raymarcher(torch.nn.Module):
                   if noise > 0 else None, noise_scale=float(noise))                # :167
         rgb_c, sig_c = field_autograd(net, cand, n_dev=st["n_cand"])
         self.train_overflow_flag = None      # one candidate per sample at most: the sample capacity bounds the candidates
+        self.train_overflow_src = None
         color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
         return {
             "rgb_coarse": color.reshape(rays.o.shape),
@@ -384,7 +385,8 @@ class Raymarcher(torch.nn.Module):
         # device-side overflow flag of THIS step: candidates past the capacity were dropped (in atomic-arrival order), so the
         # step's gradients are wrong -- `training_step` feeds the flag to the optimiser's found_inf, the update is skipped on
         # the device without a host read; the deferred count check then grows the capacity and the next steps are whole
-        self.train_overflow_flag = (sc["n_cand"] > cand_cap).to(torch.float32).reshape(())
+        self.train_overflow_flag = None
+        self.train_overflow_src = (sc["n_cand"], int(cand_cap))     # -> `training_step` (the loss kernel compares; `overflow_flag()` for others)
         color, depth, alpha, weights = _CompositeTrainFn.apply(rgb_c.float(), sig_c.float(), st)
         return {
             "rgb_coarse": color.reshape(rays.o.shape),
@@ -396,6 +398,17 @@ class Raymarcher(torch.nn.Module):
     #: capacity (candidates) of the training field call; 2^20 x 480 B of activations = 0.5 GB
     train_cand_capacity = 1 << 20
     train_overflow = 0
+    train_overflow_flag = None     # device scalar > 0: the last training render dropped candidates (set by callers / tests)
+    train_overflow_src = None      # (device int32 candidate counter, capacity) of the last fused training render
+
+    def overflow_flag(self):
+        """The overflow flag of the last training render as a device float scalar (None: the route cannot overflow)."""
+        if self.train_overflow_flag is not None:
+            return self.train_overflow_flag
+        if self.train_overflow_src is not None:
+            cnt, cap = self.train_overflow_src
+            return (cnt.reshape(-1)[0] > cap).to(torch.float32).reshape(())
+        return None
 
     def _train_counts_post(self, counts, cand_cap):
         """counts: device int32 [2] = [samples, candidates] of this step -> pinned host pair, one asynchronous copy"""

@@ -251,16 +251,21 @@ def field_autograd(net, x, n_dev=None):
     return _FieldFn.apply(x, net.encoder.params, net.color_net.params, net, n_dev)
 
 
-def _nerf_loss_kernel(rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg, poison=None):
-    """`ia_nerf_loss`: (out5 = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density}, d_rgb, d_alpha, d_weight), flat"""
+def _nerf_loss_kernel(rgb, alpha, weight, tgt_rgb, tgt_alpha, w_rgb, w_alpha, w_reg, poison=None, overflow_src=None):
+    """`ia_nerf_loss`: (out = {loss, mse_loss, loss_alpha_coarse, reg_alpha, reg_density[, overflow]}, d_rgb, d_alpha, d_weight), flat.
+    overflow_src = (device int32 counter [1], capacity): the kernel poisons the step itself when the counter exceeds the capacity
+    and reports that as the sixth value."""
     r, a, w = (t.detach().reshape(-1).float().contiguous() for t in (rgb, alpha, weight))
     tr, ta = tgt_rgb.detach().reshape(-1).float().contiguous(), tgt_alpha.detach().reshape(-1).float().contiguous()
-    out = pooled_zeros((5,), r.device)
+    out = pooled_zeros((6 if overflow_src is not None else 5,), r.device)
     d_r, d_a, d_w = torch.empty_like(r), torch.empty_like(a), torch.empty_like(w)
     pz = poison.detach().reshape(()).float().contiguous() if poison is not None else None
+    cnt, cap = overflow_src if overflow_src is not None else (None, 0)
+    if cnt is not None:
+        assert cnt.dtype == torch.int32 and cnt.is_cuda and cnt.numel() >= 1, "overflow counter: device int32"
     _lib.check(_lib.lib().ia_nerf_loss(_lib.ptr(r), _lib.ptr(tr), _lib.ptr(a), _lib.ptr(ta), _lib.ptr(w), a.numel(),
-                                       w.numel(), w_rgb, w_alpha, w_reg, _lib.ptr(pz), _lib.ptr(out), _lib.ptr(d_r), _lib.ptr(d_a),
-                                       _lib.ptr(d_w), _lib.stream()), "ia_nerf_loss")
+                                       w.numel(), w_rgb, w_alpha, w_reg, _lib.ptr(pz), _lib.ptr(cnt), int(cap), _lib.ptr(out),
+                                       _lib.ptr(d_r), _lib.ptr(d_a), _lib.ptr(d_w), _lib.stream()), "ia_nerf_loss")
     return out, d_r, d_a, d_w
 
 
@@ -303,14 +308,17 @@ class NeRFLoss(torch.nn.Module):
         """the loss is exactly the kernel's five terms (no LPIPS / depth term active): `value_and_grads` may replace autograd"""
         return bool(self.fused) and predicts["rgb_coarse"].is_cuda and type(self).forward is NeRFLoss.forward
 
-    def value_and_grads(self, predicts, targets, poison=None):
+    def value_and_grads(self, predicts, targets, poison=None, overflow_src=None):
         """The losses (detached) and d loss / d (rgb_coarse, alpha_coarse, weight_coarse) straight from the kernel: the caller
         seeds autograd with them (`torch.autograd.backward(outputs, grads)`) instead of building loss -> mul -> backward out of
-        nine small launches.  poison: device scalar, > 0 = NaN loss and gradients (see `ia_nerf_loss`)."""
+        nine small launches.  poison: device scalar, > 0 = NaN loss and gradients; overflow_src = (device int32 counter,
+        capacity): the same decided inside the kernel, reported as losses["skipped_overflow"] (see `ia_nerf_loss`)."""
         r, a, w = predicts["rgb_coarse"], predicts["alpha_coarse"], predicts["weight_coarse"]
         out, d_r, d_a, d_w = _nerf_loss_kernel(r, a, w, targets["rgb"], targets["alpha"], float(self.w_rgb), float(self.w_alpha),
-                                               float(self.w_reg), poison=poison)
+                                               float(self.w_reg), poison=poison, overflow_src=overflow_src)
         losses = {"mse_loss": out[1], "loss_alpha_coarse": out[2], "reg_alpha": out[3], "reg_density": out[4], "loss": out[0]}
+        if overflow_src is not None:
+            losses["skipped_overflow"] = out[5]
         return losses, (d_r.reshape(r.shape), d_a.reshape(a.shape), d_w.reshape(w.shape))
 
     def forward(self, predicts, targets):
@@ -565,6 +573,9 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         finally:
             model.renderer.train_draws = None
         overflow = getattr(model.renderer, "train_overflow_flag", None)
+        # (the fused render leaves the SOURCE of the flag -- its device-side candidate counter and the capacity of its buffers --
+        #  instead of a flag tensor: the loss kernel of the direct path compares them itself, two launches less per step)
+        overflow_src = getattr(model.renderer, "train_overflow_src", None) if overflow is None else None
         with_reg = reg is not None and not is_refine
         direct = (not with_reg) and hasattr(loss_fn, "direct_backward_ok") and loss_fn.direct_backward_ok(predicts) and \
             all(torch.is_tensor(predicts.get(k)) and predicts[k].requires_grad for k in ("rgb_coarse", "alpha_coarse", "weight_coarse"))
@@ -574,8 +585,12 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         if direct:
             # the loss kernel already holds d loss / d (rgb, alpha, weights): seed autograd with them (and let the kernel do the
             # NaN poisoning) instead of loss -> where -> mul -> backward -> foreach_mul: nine small launches less per step
-            losses, grads = loss_fn.value_and_grads(predicts, batch, poison=overflow)
+            losses, grads = loss_fn.value_and_grads(predicts, batch, poison=overflow, overflow_src=overflow_src)
+            if overflow_src is not None:
+                overflow = losses["skipped_overflow"]     # (device scalar written by the loss kernel; also fed to the optimiser below)
         else:
+            if overflow_src is not None:
+                overflow = (overflow_src[0].reshape(-1)[0] > overflow_src[1]).to(torch.float32).reshape(())
             losses = loss_fn(predicts, batch)
             if with_reg:
                 losses["reg"] = reg
@@ -595,6 +610,7 @@ def training_step(model, batch, optimizer, loss_fn, world_size=1, is_refine=Fals
         ZeroPool.current = None
     params = [p for g in optimizer.param_groups for p in g["params"]]
     model.renderer.train_overflow_flag = None
+    model.renderer.train_overflow_src = None
     losses["skipped_non_finite"] = optimizer_step_skip_non_finite(optimizer, params, extra_flag=overflow)
     if overflow is not None:
         losses["skipped_overflow"] = overflow
