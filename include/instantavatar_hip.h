@@ -383,7 +383,7 @@ int ia_raymarch_train(const float *rays_o, const float *rays_d,
  *   keep the largest 26-connected component.
  * density: [G,G,G] indexed [x][y][z].  Outputs: occ_bits (bit-packed, G^3/32 words + EIGHT tail words: [0] flag, 1 = no border
  * cell is occupied; [1..6] = x_min, x_max, y_min, y_max, z_min, z_max of the occupied cells (min > max: none); [7] spare -- read
- * by ia_render_test's marcher for its exact empty-space skip), occ_bool [G^3] uint8 or NULL.                                       */
+ * by ia_render_test's marcher for its exact empty-space skip; occ_bits must be 16-byte aligned), occ_bool [G^3] uint8 or NULL.    */
 size_t ia_occupancy_workspace_bytes(int G);
 int ia_occupancy_from_density(const float *density, int G, uint32_t *occ_bits,
                               uint8_t *occ_bool, void *ws, size_t ws_bytes,
