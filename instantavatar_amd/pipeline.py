@@ -172,7 +172,8 @@ class PipelinedRenderer:
     frames in flight WIN (580 sustained / 598 over the 20-frame driver window at 512^2: `profiles/r06_ab_in_flight_priorities.txt`):
     the high-priority frame's chain of small launches is dispatched the moment it is ready instead of queueing behind the
     thousands of pending search workgroups of the other frames, which fill what it leaves free.  Two in flight gain nothing from
-    it (545 vs 553), four and five lose to three.  Default: (high, normal, normal, ...) from three frames in flight on, equal
+    it (545 vs 553), four and five lose to three; handing each frame to the least loaded replica instead of round robin adds 1 %
+    (605 vs 600).  Default: (high, normal, normal, ...) from three frames in flight on, equal
     below; `priorities` (a list, HIP convention: lower = higher priority, range `torch.cuda.Stream.priority_range()`) or the
     environment variable IA_STREAM_PRIORITIES ("-1,0,0") override.  Measured on MI355X: one frame in flight 450 frames/s
     (2.2 ms latency), two 553, three 580."""
@@ -181,7 +182,10 @@ class PipelinedRenderer:
                  max_queued=2):
         """schedule: "round_robin" (call i -> replica i mod n) or "least_loaded" (the replica with the fewest unfinished frames,
         the higher-priority one on a tie, at most `max_queued` frames queued per replica -- the host waits for the oldest one
-        beyond that).  Default: IA_PIPELINE_SCHEDULE, else round robin."""
+        beyond that).  Default: IA_PIPELINE_SCHEDULE, else least loaded when the streams differ in priority (the high-priority
+        replica finishes its frames sooner and takes more of them: 600 -> 605 frames/s), round robin otherwise.  The frame ->
+        replica mapping of the least-loaded schedule depends on timing; the frames do not (a replay takes its random draws from
+        the process-wide generator in call order, whichever replica it runs on)."""
         import os
         self.replicas = [model] + [clone_for_stream(model) for _ in range(n_in_flight - 1)]
         env = [int(v) for v in os.environ.get("IA_STREAM_PRIORITIES", "").split(",") if v.strip()]
@@ -197,7 +201,7 @@ class PipelinedRenderer:
             torch.cuda.current_stream().wait_stream(s)
         self.events = [torch.cuda.Event() for _ in self.replicas]
         self.calls = 0
-        self.schedule = schedule or os.environ.get("IA_PIPELINE_SCHEDULE", "") or "round_robin"
+        self.schedule = schedule or os.environ.get("IA_PIPELINE_SCHEDULE", "") or ("least_loaded" if len(set(self.priorities)) > 1 else "round_robin")
         assert self.schedule in ("round_robin", "least_loaded"), self.schedule
         self.max_queued = int(os.environ.get("IA_PIPELINE_MAX_QUEUED", max_queued))
         self._unfinished = [[] for _ in self.replicas]     # per replica: events of the frames enqueued and not yet seen finished

@@ -114,8 +114,12 @@ def _eager_graph_pipelined(oracle, bench_world, frames, seed0, what):
                 return c
             patch(model, jit_rep[0])
             P.clone_for_stream = patched_clone
-            pr = PipelinedRenderer(model, batch(0), (res, res), n_in_flight=n_rep) if n_rep != 3 else PipelinedRenderer(model, batch(0), (res, res))
+            # (round robin: this test refreshes the jitter buffer of the replica that call i WILL run on; the product's default with
+            #  three replicas hands a frame to the least loaded one -- covered by test_pipelined_renderer_frames_in_flight_equal_eager)
+            pr = (PipelinedRenderer(model, batch(0), (res, res), n_in_flight=n_rep) if n_rep != 3
+                  else PipelinedRenderer(model, batch(0), (res, res), schedule="round_robin"))
             assert len(pr.replicas) == n_rep and pr.priorities == ([-1, 0, 0] if n_rep == 3 else [0, 0]), pr.priorities
+            assert pr.schedule == "round_robin" and PipelinedRenderer.__init__.__defaults__[0] == 3
             order = list(range(n)) * n_rep               # every frame passes through several replicas
             got = []
             jits_dev = [torch.as_tensor(j, device=DEV) for j in jits]
