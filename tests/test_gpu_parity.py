@@ -497,6 +497,61 @@ def test_hip_graph_replay_equals_eager(gpu_world):
         grid.initialize = orig
 
 
+def test_replays_with_too_few_wavefront_iterations_are_reported_and_rerendered(gpu_world):
+    """A captured frame holds a FIXED number of wave-front iterations (what the probe frames needed + margin); a frame whose rays
+    are still alive after them is incomplete.  The renderers must report exactly those calls (`incomplete_calls`, global call
+    numbers, whichever replica of a PipelinedRenderer rendered them -- least-loaded schedule included) so that the caller renders
+    them again (drivers/animate.py, bench.py): here the graphs are captured one iteration short of what the longest frame needs;
+    exactly the calls that need more are reported, every other call must equal the eager frame bit for bit."""
+    from instantavatar_amd.pipeline import GraphedRenderer, PipelinedRenderer
+    import instantavatar_amd.pipeline as P
+    model, body, fp, init, poses, tr = gpu_world
+    res = 96
+    jit = torch.rand((5, 64 ** 3, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(31))
+    frames = (1, 4, 6, 2, 7, 3, 5)
+    eager = {i: [t.clone() for t in model.render_image_fast(make_batch(DEV, res, poses[i], tr[i]), (res, res), jitter=jit)] for i in frames}
+    need = {}
+    for i in frames:
+        model.render_image_fast(make_batch(DEV, res, poses[i], tr[i]), (res, res), jitter=jit)
+        need[i] = model.renderer.iters_executed()
+    hint_before = model.renderer._iters_hint
+    model.render_image_fast(make_batch(DEV, res, poses[0], tr[0]), (res, res), jitter=jit)
+    need0 = model.renderer.iters_executed()               # what the renderers' warm-up on this batch will measure
+    margin = max(need.values()) - 1 - need0               # one iteration less than the longest frame needs: those frames are incomplete
+    try:
+        for make in ("graphed", "pipelined"):
+            if make == "graphed":
+                r = GraphedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), margin=margin, jitter=jit)
+                budget = [model.renderer._iters_hint]
+            else:
+                r = PipelinedRenderer(model, make_batch(DEV, res, poses[0], tr[0]), (res, res), n_in_flight=3, margin=margin, jitter=jit)
+                assert r.schedule == "least_loaded"
+                budget = [m.renderer._iters_hint for m in r.replicas]
+            outs = []
+            for i in frames:
+                b = make_batch(DEV, res, poses[i], tr[i])
+                if make == "graphed":
+                    outs.append([t.clone() for t in r(b)])
+                else:
+                    r(b, consume=lambda out, k: outs.append([t.clone() for t in out]))
+            if make == "pipelined":
+                r.synchronize()
+            n_bad = r.finish()
+            bad = sorted(r.incomplete_calls)
+            assert n_bad == len(bad) and all(0 <= c < len(frames) for c in bad), (make, n_bad, bad)
+            # a call is reported exactly when its frame needs more iterations than its graph holds (every replica holds the same number)
+            assert len(set(budget)) == 1
+            want = [c for c, i in enumerate(frames) if need[i] > budget[0]]
+            assert bad == want and len(bad) > 0, (make, bad, want, need, budget)
+            for c, i in enumerate(frames):
+                if c in bad:
+                    continue
+                for a, e in zip(outs[c], eager[i]):
+                    assert torch.equal(a, e), (make, c, i)
+    finally:
+        model.renderer._iters_hint = hint_before
+
+
 def test_march_empty_space_skip_is_exact(gpu_world):
     """k_march_compact skips the occupancy arithmetic of the steps that cannot be occupied when the grid's border flag says that
     no border cell is occupied (the clamped cell of a point outside the grid is a border cell, raymarcher.cu:49-51): the part of a
