@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent frames in flight per GPU (one captured graph and one HIP stream each; 1 = strictly one frame "
                          "after the other).  The frames of a sequence are independent units (animate.py)")
+    ap.add_argument("--graph-margin", type=int, default=1, help="wave-front iterations a captured frame holds beyond what the 12 probe "
+                    "poses needed (a frame that needs more is detected and rendered again eagerly, inside the timed region)")
     ap.add_argument("--train-only", action="store_true", help="headline = training throughput (rays/s over all ranks)")
     ap.add_argument("--force-collectives", action="store_true", help="with --gpus 1: start a 1-rank RCCL group and take the multi-rank "
                     "training path (bucketed all-reduce from inside the backward, density MAX-reduce) -- the eager-vs-graph gap of the "
@@ -794,9 +796,9 @@ def main():
                 probes.append(pb)
             if args.in_flight > 1:
                 from instantavatar_amd.pipeline import PipelinedRenderer
-                graphed = PipelinedRenderer(model, batches[0], (res, res), n_in_flight=args.in_flight, margin=1, probe_batches=probes)
+                graphed = PipelinedRenderer(model, batches[0], (res, res), n_in_flight=args.in_flight, margin=args.graph_margin, probe_batches=probes)
             else:
-                graphed = GraphedRenderer(model, batches[0], (res, res), margin=1, probe_batches=probes)
+                graphed = GraphedRenderer(model, batches[0], (res, res), margin=args.graph_margin, probe_batches=probes)
 
             def frame(i, consume=None):  # noqa: F811  (same work, replayed from the captured HIP graph(s))
                 f = my[i % n_total] % len(poses)
