@@ -617,6 +617,8 @@ def main():
         return dry_run(args, rank, world_size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    from instantavatar_amd import build as _ia_build
+    _ia_build.ensure_current(verbose=(rank == 0))   # (a snapshot may carry a library built before the last source edit; lock-protected)
     # IA_BENCH_SHARE_DEVICE=1 (development / tests/test_gpu_collectives.py): all ranks of an N > 1 run share cuda:0 and talk
     # over gloo -- RCCL refuses two ranks on one device.  Exercises the N-rank control flow of this file with the real kernels
     # on a one-GPU box (sharding, gathers, barriers, per-rank reports, the eager N-rank training step); the numbers it prints

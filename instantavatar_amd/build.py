@@ -142,6 +142,29 @@ def needs_build():
     return library_manifest() != source_manifest()
 
 
+def ensure_current(verbose=False):
+    """Entry points that are started on a copy of the tree (pytest on the GPU box, bench.py, __graft_entry__.smoke) call this first:
+    a library that is missing or was built from other sources than this checkout is REBUILT when the compiler is there (one process
+    at a time: an exclusive lock file next to the library; the others wait and find it current), and left alone otherwise --
+    `_lib.lib()` then refuses it loudly.  Not a fallback: the product still only ever runs the HIP library of this checkout."""
+    if os.environ.get("IA_EXTRA_HIPCC_FLAGS") or os.environ.get("IA_ALLOW_STALE_LIB") == "1":
+        return False      # an A/B variant is being run on purpose (tools/ab_lib.sh)
+    if not needs_build() or not have_compiler():
+        return False
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if needs_build():
+                if verbose:
+                    print("instantavatar_amd: library missing or stale, rebuilding it from this checkout", file=sys.stderr)
+                build(force=False, verbose=False)
+                return True
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return False
+
+
 def build(force=False, verbose=False):
     """Compile what changed (everything with force=True) and link.  Without a compiler a library whose manifest equals
     the checkout is used as it is; a stale one is an error, never silently run."""

@@ -88,6 +88,24 @@ def test_bench_quotes_a_counter_summary_only_for_the_device_code_it_runs(tmp_pat
     assert j is None and "no PMC summary" in src
 
 
+def test_ensure_current_rebuilds_a_stale_library_and_only_then(tmp_path, monkeypatch):
+    """`build.ensure_current()` (called by conftest, bench.py and __graft_entry__.smoke before anything loads the library): nothing
+    happens for a current library or while an A/B variant is run on purpose; a library that does not match the checkout is rebuilt
+    when the compiler is there -- the product then runs the HIP library of THIS checkout, never an older one and never anything else."""
+    from instantavatar_amd import build
+    assert not build.needs_build() and build.ensure_current() is False
+    calls = []
+    monkeypatch.setattr(build, "needs_build", lambda: True)
+    monkeypatch.setattr(build, "build", lambda force=False, verbose=False: calls.append(force) or build.OUT)
+    monkeypatch.setenv("IA_ALLOW_STALE_LIB", "1")
+    assert build.ensure_current() is False and calls == []          # a variant run: hands off
+    monkeypatch.delenv("IA_ALLOW_STALE_LIB")
+    monkeypatch.setattr(build, "have_compiler", lambda: False)
+    assert build.ensure_current() is False and calls == []          # no compiler: `_lib.lib()` will refuse the stale library
+    monkeypatch.setattr(build, "have_compiler", lambda: True)
+    assert build.ensure_current() is True and calls == [False]      # stale + compiler: rebuilt (what changed only)
+
+
 def test_no_cpu_fallback_fails_loudly():
     from instantavatar_amd import _lib
     from instantavatar_amd.models.networks.ngp import NeRFNGPNet
