@@ -76,6 +76,10 @@ typedef struct ia_field {
    * L2 (same results, higher gather rate); NULL = single fused kernel.            */
   uint32_t *enc_ws;
   size_t enc_ws_samples;
+  /* hint for the sharded encoding, 16-level tables: tiles of every four of its second level group (hashed 12-15 + dense 0-3) that
+   * XCDs 0-3 take.  3 for spatially coherent samples (ray-ordered candidates of a frame or a training batch: XCDs 0-3 own the
+   * cheap hashed levels 4-7 and finish them early), 2 for incoherent ones; 0 = 2.  Same results whatever the value.            */
+  int32_t enc_split;
 } ia_field;
 
 /* Occupancy grid (models/structures/density_grid.py): G^3 cells over aabb.   */

@@ -29,7 +29,7 @@ class Field(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("scale", C.c_float * 3), ("hash", HashDesc),
                 ("table", C.c_void_p), ("sig_w1", C.c_void_p), ("sig_w2", C.c_void_p),
                 ("col_w1", C.c_void_p), ("col_w2", C.c_void_p), ("col_w3", C.c_void_p), ("mlp_frags", C.c_void_p),
-                ("enc_ws", C.c_void_p), ("enc_ws_samples", C.c_size_t)]
+                ("enc_ws", C.c_void_p), ("enc_ws_samples", C.c_size_t), ("enc_split", C.c_int32)]
 
 
 class OccGrid(C.Structure):

@@ -61,6 +61,7 @@ struct FieldDev {
   const uint16_t *frags;  // prebuilt MFMA A-fragment image or null
   uint32_t *enc_ws;       // level-plane scratch of the XCD-sharded encoding or null
   size_t enc_ws_samples;
+  int enc_split;          // sharded encoding: tiles of every four of the second level group that XCDs 0-3 take (1..3)
   // set when all hashed levels have the same size and follow each other (tcnn default):
   // level l >= n_dense lives at table + hash_base + (l - n_dense) * hash_size
   uint32_t n_dense, hash_base, hash_size;

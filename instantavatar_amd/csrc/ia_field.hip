@@ -61,6 +61,7 @@ int ia_make_field_dev(const ia_field *f, FieldDev *o) {
   o->frags = f->mlp_frags;
   o->enc_ws = f->enc_ws;
   o->enc_ws_samples = f->enc_ws ? f->enc_ws_samples : 0;
+  o->enc_split = (f->enc_split >= 1 && f->enc_split <= 3) ? f->enc_split : 2;
   // uniform-hash pattern (lets the kernel derive per-level pointers instead of holding 16 of them)
   uint32_t nd = 0;
   while ((int)nd < L && !o->lv.hashed[nd]) nd++;
@@ -451,7 +452,14 @@ __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__re
   constexpr int ND = 4, NH = L - ND;  // tcnn default pattern (checked by the host)
   if (n_dev) V = min(V, *n_dev);
   const int n_tiles = (V + IA_ENC_TILE - 1) / IA_ENC_TILE;
-  const int n_items = (NH > 4 ? n_tiles : 0) + (n_tiles + 1) / 2;  // per XCD
+  // Work items of an XCD: (16 levels) first EVERY tile of hashed level 4 + xcd, then tiles of the second level group -- hashed level
+  // 12 + (xcd & 3) together with dense level (xcd & 3) -- which XCD k shares with XCD k + 4: of every four tiles XCD k takes the
+  // first `spl`, XCD k + 4 the rest.  spl = F.enc_split is the caller's hint (ia_field.enc_split): on spatially coherent samples
+  // (a frame's ray-ordered candidates, Morton-ordered probes) hashed levels 4-7 are much cheaper than 8-11 -- coarse cells, the
+  // lanes of a wave share lines -- so XCDs 0-3 are given three tiles of four; on incoherent samples every level costs the same
+  // and two of four is right (profiles/r06_ab_encode_quad.txt: 605 -> 612 frames/s with 3; random points 326 -> 393 us with 3).
+  const int spl = NH > 4 ? F.enc_split : 2, sph = 4 - spl, mx = spl > sph ? spl : sph;
+  const int n_items = (NH > 4 ? n_tiles : 0) + ((n_tiles + 3) >> 2) * mx;  // per XCD
   const int xcd = blockIdx.x & 7;
   for (int s = blockIdx.x >> 3; s < n_items; s += gridDim.x >> 3) {
     int tile, lev_h, lev_d;
@@ -459,7 +467,9 @@ __global__ __launch_bounds__(IA_ENC_THREADS) void k_encode_xcd(const float *__re
       tile = s; lev_h = ND + xcd; lev_d = -1;
     } else {
       const int sb = NH > 4 ? s - n_tiles : s;
-      tile = 2 * sb + (xcd >> 2); lev_h = (NH > 4 ? ND + 8 : ND) + (xcd & 3); lev_d = xcd & 3;
+      const int q = sb / mx, r = sb - q * mx;
+      if (r >= (xcd < 4 ? spl : sph)) continue;
+      tile = q * 4 + (xcd < 4 ? r : spl + r); lev_h = (NH > 4 ? ND + 8 : ND) + (xcd & 3); lev_d = xcd & 3;
     }
     if (tile >= n_tiles) continue;
     const int base = tile * IA_ENC_TILE + threadIdx.x;
@@ -530,7 +540,8 @@ static int ia_launch_encode_xcd(const float *x, int V, const int32_t *n_dev, con
                                 size_t stride, hipStream_t s) {
   const int tiles = (V + IA_ENC_TILE - 1) / IA_ENC_TILE;
   const int L = F.lv.n_levels;
-  int per_xcd = (L == 16 ? tiles : 0) + (tiles + 1) / 2;
+  const int spl = L == 16 ? F.enc_split : 2, mx = spl > 4 - spl ? spl : 4 - spl;
+  int per_xcd = (L == 16 ? tiles : 0) + ((tiles + 3) / 4) * mx;
   if (per_xcd > IA_ENC_MAX_WG_PER_XCD) per_xcd = IA_ENC_MAX_WG_PER_XCD;  // workgroups loop over their XCD's items
   if (L == 16)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_encode_xcd<16>), dim3(8 * per_xcd), dim3(IA_ENC_THREADS), 0, s, x, V, n_dev, F, planes, stride);

@@ -87,8 +87,14 @@ class _FieldFn(torch.autograd.Function):
         alloc = pooled_zeros if n_dev is not None else (lambda shp, device: torch.empty(shp, device=device))
         rgb = alloc((V, 3), device=x.device)
         sigma = alloc((V,), device=x.device)
-        _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, _lib.ptr(n_dev), C.byref(net.field_desc(V)), _lib.ptr(rgb),
-                                        _lib.ptr(sigma), _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
+        desc = net.field_desc(V)
+        split = desc.enc_split
+        desc.enc_split = int(getattr(net, "enc_split_train", split))   # (the training batches' own XCD balance hint: see NeRFNGPNet)
+        try:
+            _lib.check(L.ia_field_fwd_train(_lib.ptr(xc), V, _lib.ptr(n_dev), C.byref(desc), _lib.ptr(rgb),
+                                            _lib.ptr(sigma), _lib.ptr(acts), _lib.stream()), "ia_field_fwd_train")
+        finally:
+            desc.enc_split = split
         ctx.net = net
         ctx.need_dx = x.requires_grad
         ctx.n_dev = n_dev

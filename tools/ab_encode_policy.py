@@ -15,6 +15,7 @@ x = torch.rand((n, 3), device=dev, generator=g) * (bb[1] - bb[0]) + bb[0]
 poses, tr = syn.load_animation_track(os.path.join(bench.ROOT, "tests", "golden", "aist_demo_200.npz"))
 xc = bench.frame_coherent_samples(model, make_batch(dev, 512, poses[0], tr[0]), 512)
 for what, pts in (("random 2^20", x), ("frame-coherent %d" % xc.shape[0], xc)):
+    net.sample_coherence(not what.startswith("random"))     # (ia_field.enc_split: 2 for the random points, 3 for a frame's samples)
     us = min(bench._time_encode(net, pts, 30) for _ in range(3))
     with torch.no_grad():
         f = net.encode_planes(pts)

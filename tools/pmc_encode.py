@@ -30,6 +30,7 @@ else:
     g = torch.Generator(device=dev).manual_seed(0)
     V = 1 << 20
     x = torch.rand((V, 3), device=dev, generator=g) * (bb[1] - bb[0]) + bb[0]
+    net.sample_coherence(False)     # random points: the even split of the encoder's second level group (as bench.py measures them)
     for _ in range(4):
         net.encode(x)
         net.encode_planes(x)
