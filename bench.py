@@ -217,9 +217,9 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
     torch.cuda.synchronize()
     if world_size > 1:
         torch.distributed.barrier()
-    # one rank: three timed windows of n_steps, the median is quoted (a 70-180 ms window is at the mercy of one host hiccup: the
-    # uniform-ray leg read 923 / 1 035 / 1 185 instead of ~1 380 it/s in three of thirty bench runs of round 6); several ranks: one
-    # barrier-bracketed window
+    # one rank: three timed windows of n_steps (a 70-180 ms window is at the mercy of one host hiccup: the uniform-ray leg read
+    # 923 / 1 035 / 1 185 instead of ~1 380 it/s in three of thirty bench runs of round 6 -- the list shows it); several ranks:
+    # one barrier-bracketed window
     windows = []
     first = last = None
     for w in range(3 if world_size == 1 else 1):
@@ -233,7 +233,9 @@ def train_throughput(model, dev, poses, tr, rank, world_size, n_steps, res=512, 
         if world_size > 1:
             torch.distributed.barrier()
         windows.append(time.perf_counter() - t0)
-    dt = sorted(windows)[len(windows) // 2]
+    dt = windows[0]      # quoted: the FIRST window (steps 3 .. 3 + n_steps of a fresh model, as rounds 1-5 measured) -- the later windows
+                         # are further into training (patch 571 -> 606 -> 620 it/s as the field forms, refinement 919 -> 830 -> 811) and are
+                         # listed for the reader, who also sees a host hiccup in the first one by comparing
     if world_size > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
