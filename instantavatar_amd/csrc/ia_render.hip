@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void k_march_compact(
     n = (size_t)alive[i];
     r = load_ray(rays_o, rays_d, fars, step, n, aabb, aabb + 3, G);
     t_start = near_w[n];
+    t_end = t_start;
   }
   // Exact empty-space skip (round 6).  The occupancy post-process keeps a flag word behind the bit grid: 1 = no BORDER cell is
   // occupied (k_occ_final / k_occ_pack), and behind it the index bounds of the occupied cells (k_occ_bounds).  The cell of a step
@@ -713,7 +714,8 @@ __global__ __launch_bounds__(256) void k_march_compact(
     __syncthreads();
   }
   const uint32_t *bits = LDS_BITS ? s_bits : bits_global;
-  if (live) {
+  // (a ray with far <= near has step <= 0: the reference loop would never end on it -- such a ray takes no sample here)
+  if (live && r.dt > 0.f) {
     float t = t_start;
     t0 = t;
     bool found = false;

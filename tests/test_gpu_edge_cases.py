@@ -112,6 +112,33 @@ def test_rays_that_miss_everything(gw):
     assert model.renderer.last_iters >= 2
 
 
+def test_rays_with_an_empty_or_inverted_depth_range_take_no_sample(gw):
+    """far <= near gives a march step <= 0: the reference's loop `while (t < far && cnt < N)` would never advance on such a ray
+    (raymarcher.cu:44-69).  Here it takes no sample and dies in the first compaction; the other rays of the frame are untouched."""
+    from instantavatar_amd.models.structures.utils import Rays
+    model, poses, tr = gw
+    res = 48
+    batch = make_batch(DEV, res, poses[1], tr[1])
+    ref = [t.clone() for t in model.render_image_fast(batch, (res, res))]      # prepares the deformer and the occupancy grid
+    rays = Rays(o=batch["rays_o"], d=batch["rays_d"], near=batch["near"], far=batch["far"])
+    model.deformer.transform_rays_w2s(rays)
+    near, far = rays.near.clone(), rays.far.clone()
+    empty = torch.zeros_like(near, dtype=torch.bool); empty.view(-1)[::7] = True
+    inverted = torch.zeros_like(near, dtype=torch.bool); inverted.view(-1)[3::11] = True
+    far[empty] = near[empty]
+    far[inverted] = near[inverted] - 0.5
+    rays.near, rays.far = near, far
+    d = model.renderer.render_test_fused(rays, model.deformer, model.net_coarse)      # (`ia_render_test`: the fused wave-front loop)
+    torch.cuda.synchronize()
+    bad = (empty | inverted).reshape(-1)
+    alpha, counter = d["alpha_coarse"].reshape(-1), d["counter_coarse"].reshape(-1)
+    assert torch.all(alpha[bad] == 0) and torch.all(counter[bad] == 0)
+    # (the other rays: the same samples, the same colours -- only the wave-front batching differs with fewer rays alive)
+    good = ~bad
+    assert torch.allclose(d["rgb_coarse"].reshape(-1, 3)[good], ref[0].reshape(-1, 3)[good], atol=1e-5)
+    assert torch.equal(alpha[good] > 0.5, ref[2].reshape(-1)[good] > 0.5) and float((alpha[good] > 0.5).float().mean()) > 0.02
+
+
 def test_large_render_1024(gw):
     """BASELINE configs[4] image size: 1024x1024 = 1 048 576 rays (> MAX_BATCH_SIZE: N_step = 1 until rays retire)."""
     model, poses, tr = gw
