@@ -175,8 +175,11 @@ def test_xcd_sharded_encoding_equals_fused_kernel(gpu_world):
             x = (rng.rand(n, 3) * (bb[1] - bb[0]) * 1.1 + bb[0] - 0.05 * (bb[1] - bb[0])).astype(np.float32)
             xt = torch.as_tensor(x, device=DEV)
             row = net.encode(xt).view(torch.int32)                       # [V, L] packed half2
-            planes = net.encode_planes(xt)                               # [L, V]
-            assert torch.equal(planes.t().contiguous(), row), (n_levels, n)
+            for coherent in (True, False):                               # ia_field.enc_split: 3 / 2 tiles of four to XCDs 0-3
+                net.sample_coherence(coherent)
+                planes = net.encode_planes(xt)                           # [L, V]
+                assert torch.equal(planes.t().contiguous(), row), (n_levels, n, coherent)
+            net.sample_coherence(True)
             with torch.no_grad():
                 saved = net.max_encode_workspace_bytes
                 try:
